@@ -1,0 +1,92 @@
+/* C ABI of liblarva_hip.so -- the gfx950 (MI355X) kernels behind the LarvaNet hot path.
+ *
+ * The reference (Geunwoo-Jeon/LarvaNet) has no FFI: its hot path is torch.nn call sites inside
+ * models/LarvaNet.py / models/LarvaNetV2.py.  Every entry point below names the reference call
+ * site(s) it replaces (file:line into the reference tree).  INTEGRATION.md shows the ctypes
+ * binding a reference maintainer would add.
+ *
+ * Conventions: all tensors are contiguous fp32 NCHW device memory owned by the caller; `stream`
+ * is a hipStream_t passed as void*; every call is stream-ordered, never allocates, never
+ * synchronises, keeps no global mutable state (safe for hipGraph capture).  Return value: 0 on
+ * success, otherwise a hipError_t code (larva_error_string() gives the text).
+ */
+#ifndef LARVA_HIP_H
+#define LARVA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int larva_abi_version(void);
+const char* larva_error_string(int code);
+
+/* ---- weight packing ------------------------------------------------------------------------
+ * nn.Conv2d weights stay in PyTorch layout [cout][cin][3][3] (models/LarvaNet.py:210,212,227,
+ * 256,258; models/LarvaNetV2.py:318).  The conv kernel consumes a packed image
+ * [cin/16][9][16][stride(cout)]; the input-gradient pass consumes the tap-mirrored,
+ * channel-transposed image [cout/16][9][16][stride(cin)].  `w_cin_total`/`w_cin_off` select a
+ * channel slice [w_cin_off, w_cin_off+cin) of a wider weight; channels >= w_cin_total pack as 0
+ * (3-channel head conv padded to 16).  Either output may be NULL. */
+long long larva_packed_weight_floats(int cout, int cin);
+int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout, int cin,
+                       int w_cin_total, int w_cin_off, void* stream);
+
+/* ---- fused 3x3 convolution (forward and input-gradient) -----------------------------------
+ * Replaces nn.Conv2d(k=3,s=1,p=1) plus its elementwise neighbours:
+ *   conv+ReLU                 models/LarvaNet.py:210-211, 256-257
+ *   conv + torch.add(x,res)   models/LarvaNet.py:212, 217-220      (res0)
+ *   ... + outer body skip     models/LarvaNet.py:246-248            (res0, res1)
+ *   conv->PixelShuffle(4)->+= base   models/LarvaNet.py:258,261,263-267   (mode 1)
+ *   torch.cat(features)+merge_conv   models/LarvaNetV2.py:328-330  (n_src > 1)
+ * and, fed with the `wpk_bwd` image, autograd's conv input-gradient with the ReLU-backward
+ * mask (mask) and the skip-connection gradient adds (res0/res1) fused.
+ * src: n_src (<= 8) tensors [N][cin_per_src][H][W] (cin_per_src % 16 == 0) read as one
+ * channel-concatenated input.  cout in {32, 48, 64}.
+ * Epilogue order: +bias -> relu -> (mask > 0 ? v : 0) -> +res0 -> +res1.
+ * mode 0: out [N][cout][H][W]; supported fusions: none | relu | mask | res0 | res0+res1.
+ * mode 1: out [N][cout/16][4H][4W] = PixelShuffle(4)(conv) (+ base, same shape, may be NULL). */
+int larva_conv3x3_fwd(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                      const float* bias, const float* res0, const float* res1, const float* mask,
+                      const float* base, float* out, int N, int cout, int H, int W, int relu,
+                      int mode, void* stream);
+
+/* ---- weight / bias gradient ---------------------------------------------------------------
+ * Replaces autograd's conv weight/bias gradient for the call sites above (loss.backward(),
+ * models/LarvaNet.py:113).  njobs (<= 16) same-shape layers per call; job i reads dy[i]
+ * [N][cout][H][W] and x[i] [N][cin][H][W], uses partial[i] (larva_wgrad_partial_floats()
+ * floats) as workspace and OVERWRITES dw[i] ([cout][w_cin_total[i]][3][3], channels
+ * [cin_off[i], cin_off[i]+cin_valid[i])) and db[i] ([cout], may be NULL).
+ * (cout, cin) in {(48,48), (48,16), (32,32), (64,64)}.  Deterministic (no atomics). */
+long long larva_wgrad_partial_floats(int cout, int cin, int splits);
+int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* const* partial,
+                        float* const* dw, float* const* db, const int* cin_off,
+                        const int* cin_valid, const int* w_cin_total, int njobs, int splits,
+                        int N, int cout, int cin, int H, int W, void* stream);
+
+/* ---- base image -----------------------------------------------------------------------------
+ * F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False), models/LarvaNet.py:283-285.
+ * in [N][C][H][W] -> out [N][C][4H][4W]. */
+int larva_bicubic4_fwd(const float* in, float* out, int N, int C, int H, int W, void* stream);
+
+/* ---- L1 loss ---------------------------------------------------------------------------------
+ * nn.L1Loss() forward/backward, models/LarvaNet.py:85,108,113.  Pointers 16-byte aligned. */
+int larva_l1_workspace_floats(void);
+int larva_l1_fwd(const float* a, const float* b, long long numel, float* partial, float* loss,
+                 void* stream);
+int larva_l1_bwd(const float* a, const float* b, const float* gout, long long numel, float* ga,
+                 void* stream);
+
+/* ---- PixelShuffle(4) backward (models/LarvaNet.py:261): in [N][C][4H][4W] -> out [N][16C][H][W] */
+int larva_pixel_unshuffle4(const float* in, float* out, int N, int C, int H, int W, void* stream);
+
+/* ---- AdamW over a flat buffer (optim.AdamW, models/LarvaNet.py:86-88,114) ------------------
+ * step_lr: device floats {step (1-based), lr}.  g is multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce). */
+int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* step_lr,
+                     float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                     long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LARVA_HIP_H */

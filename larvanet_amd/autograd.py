@@ -1,0 +1,224 @@
+"""torch.autograd glue: the reference trains with `loss.backward()` (models/LarvaNet.py:113), so
+the HIP forward/backward passes are exposed as autograd Functions at the granularity of the
+reference's sub-modules (head, body_i, body_i.leg, tail, loss).  No arithmetic happens here --
+only the order of kernel launches and which activations are kept for the backward pass.
+
+Backward structure of one residual block  y = x + conv2(relu(conv1(x)))  given g = dL/dy:
+    dh = dgrad(conv2)(g) * [h > 0]          (mask fused into the conv epilogue)
+    dx = g + dgrad(conv1)(dh)               (skip gradient fused as a residual operand)
+    dW2, db2 = wgrad(g, h);  dW1, db1 = wgrad(dh, x)
+All weight gradients of a module are computed by ONE batched launch at the end of its backward.
+"""
+import torch
+
+from . import kernels as K
+
+# Workgroups per weight-gradient launch: one per CU of an MI355X.
+_WGRAD_WORKGROUPS = 256
+
+
+class PackedConv:
+    """Packed (kernel-layout) images of one conv weight, rebuilt when the weight changes."""
+
+    __slots__ = ("weight", "bias", "cin_pad", "slices", "_key", "_packs")
+
+    def __init__(self, weight, bias, cin_pad=None, slices=None):
+        self.weight, self.bias, self.cin_pad = weight, bias, cin_pad
+        self.slices = slices  # list of (cin_off, cin) for a conv over concatenated inputs, or None
+        self._key = None
+        self._packs = None
+
+    def invalidate(self):
+        self._key = None
+
+    def get(self):
+        """-> list of (wpk_fwd, wpk_bwd) per slice (a single entry when slices is None)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if key != self._key:
+            with torch.no_grad():
+                if self.slices is None:
+                    self._packs = [K.pack_weights(w.detach(), cin_pad=self.cin_pad, want_bwd=self.cin_pad is None)]
+                else:
+                    whole = K.pack_weights(w.detach(), want_bwd=False)[0]
+                    self._packs = [(whole, None)] + [K.pack_weights(w.detach(), cin_off=o, cin=c) for (o, c) in self.slices]
+            self._key = key
+        return self._packs
+
+
+def _splits(njobs):
+    return max(1, _WGRAD_WORKGROUPS // njobs)
+
+
+def _wgrad(jobs, cout, cin):
+    """jobs: list of (dy, x, weight_like_for_shape, cin_off, cin_valid, want_bias) ->
+    list of (dw, db) fresh tensors."""
+    out, batch = [], []
+    for (dy, x, wshape, cin_off, cin_valid, dw_shared) in jobs:
+        dw = dw_shared if dw_shared is not None else torch.empty(wshape, device=dy.device, dtype=torch.float32)
+        db = torch.empty((cout,), device=dy.device, dtype=torch.float32)
+        batch.append({"dy": dy, "x": x, "dw": dw, "db": db, "cin_off": cin_off, "cin_valid": cin_valid})
+        out.append((dw, db))
+    for i in range(0, len(batch), 16):
+        chunk = batch[i:i + 16]
+        K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
+    return out
+
+
+class HeadFn(torch.autograd.Function):
+    """LarvaHead.forward (models/LarvaNet.py:223-233): conv3x3 3->48, no activation.  The
+    3-channel image is zero-padded to one 16-channel K chunk and runs on the same MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pc):
+        N, C, H, W = x.shape
+        x16 = torch.zeros((N, 16, H, W), device=x.device, dtype=torch.float32)
+        x16[:, :C] = x
+        (fwd, _), = pc.get()
+        out = K.conv3x3(x16, fwd, int(weight.shape[0]), bias=bias.detach())
+        ctx.save_for_backward(x16)
+        ctx.wshape = tuple(weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x16,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        cout, cin = ctx.wshape[0], ctx.wshape[1]
+        (dw, db), = _wgrad([(dy, x16, ctx.wshape, 0, cin, None)], cout, 16)
+        return None, dw, db, None
+
+
+class BodyFn(torch.autograd.Function):
+    """LarvaBody.forward (models/LarvaNet.py:236-248): x + res_blocks(x), each block
+    x + conv2(relu(conv1(x))) (models/LarvaNet.py:205-220).  2 launches per block forward."""
+
+    @staticmethod
+    def forward(ctx, x, pcs, *params):
+        # params = (w1, b1, w2, b2) per block; pcs = [PackedConv] in the same conv order
+        nb = len(params) // 4
+        keep = [x]
+        fea = x
+        for j in range(nb):
+            w1, b1, w2, b2 = params[4 * j:4 * j + 4]
+            (f1, _), = pcs[2 * j].get()
+            (f2, _), = pcs[2 * j + 1].get()
+            c = int(w1.shape[0])
+            h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True)
+            if j == nb - 1:
+                nxt = K.conv3x3(h, f2, c, bias=b2.detach(), res0=fea, res1=x)
+            else:
+                nxt = K.conv3x3(h, f2, c, bias=b2.detach(), res0=fea)
+            keep.append(h)
+            if j < nb - 1:
+                keep.append(nxt)
+            fea = nxt
+        ctx.save_for_backward(*keep)
+        ctx.pcs = pcs
+        ctx.nb = nb
+        ctx.wshape = tuple(params[0].shape)
+        return fea
+
+    @staticmethod
+    def backward(ctx, dy):
+        keep = ctx.saved_tensors
+        nb, pcs = ctx.nb, ctx.pcs
+        dy = dy.contiguous()
+        c = ctx.wshape[0]
+        # keep = [x, h0, fea1, h1, fea2, ..., h_{nb-1}]
+        g = dy
+        jobs = [None] * (2 * nb)
+        dx = None
+        for j in reversed(range(nb)):
+            fea_j = keep[0] if j == 0 else keep[2 * j]
+            h_j = keep[2 * j + 1]
+            (_, bw1), = pcs[2 * j].get()
+            (_, bw2), = pcs[2 * j + 1].get()
+            dh = K.conv3x3(g, bw2, c, mask=h_j)
+            jobs[2 * j + 1] = (g, h_j, ctx.wshape, 0, c, None)
+            jobs[2 * j] = (dh, fea_j, ctx.wshape, 0, c, None)
+            if j > 0:
+                g = K.conv3x3(dh, bw1, c, res0=g)
+            else:
+                dx = K.conv3x3(dh, bw1, c, res0=g, res1=dy)
+        grads = _wgrad(jobs, c, c)
+        flat = []
+        for (dw, db) in grads:
+            flat += [dw, db]
+        return (dx, None) + tuple(flat)
+
+
+class LegFn(torch.autograd.Function):
+    """LarvaLeg.forward (models/LarvaNet.py:251-267): conv+ReLU, conv -> PixelShuffle(4) -> += base,
+    the shuffle and the base add fused into the second conv's store."""
+
+    @staticmethod
+    def forward(ctx, fea, base, pcs, w1, b1, w2, b2):
+        (f1, _), = pcs[0].get()
+        (f2, _), = pcs[1].get()
+        c = int(w1.shape[0])
+        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True)
+        out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base)
+        ctx.save_for_backward(fea, h)
+        ctx.pcs = pcs
+        ctx.wshape = tuple(w1.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        fea, h = ctx.saved_tensors
+        pcs = ctx.pcs
+        c = ctx.wshape[0]
+        (_, bw1), = pcs[0].get()
+        (_, bw2), = pcs[1].get()
+        dyl = K.pixel_unshuffle4(dout.contiguous())
+        dh = K.conv3x3(dyl, bw2, c, mask=h)
+        dfea = K.conv3x3(dh, bw1, c)
+        (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c, None), (dyl, h, ctx.wshape, 0, c, None)], c, c)
+        # base comes from a parameter-free interpolation of the network input: no gradient
+        return dfea, None, None, dw1, db1, dw2, db2
+
+
+class MergeFn(torch.autograd.Function):
+    """LarvaTail's torch.cat(features, 1) + merge_conv (models/LarvaNetV2.py:328-330) without
+    materialising the concatenation: the conv kernel walks the feature tensors as K chunks."""
+
+    @staticmethod
+    def forward(ctx, pc, weight, bias, *feats):
+        packs = pc.get()
+        cout = int(weight.shape[0])
+        out = K.conv3x3(list(feats), packs[0][0], cout, bias=bias.detach())
+        ctx.save_for_backward(*feats)
+        ctx.pc = pc
+        ctx.wshape = tuple(weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        feats = ctx.saved_tensors
+        packs = ctx.pc.get()
+        dy = dy.contiguous()
+        cout = ctx.wshape[0]
+        c = int(feats[0].shape[1])
+        dfeats = [K.conv3x3(dy, packs[1 + i][1], c) for i in range(len(feats))]
+        dw = torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
+        jobs = [(dy, f, ctx.wshape, i * c, c, dw) for i, f in enumerate(feats)]
+        res = _wgrad(jobs, cout, c)
+        db = res[0][1]
+        return (None, dw, db) + tuple(dfeats)
+
+
+class L1LossFn(torch.autograd.Function):
+    """nn.L1Loss() (models/LarvaNet.py:85,108)."""
+
+    @staticmethod
+    def forward(ctx, out, truth):
+        out = out.contiguous()
+        truth = truth.contiguous()
+        ctx.save_for_backward(out, truth)
+        return K.l1_fwd(out, truth)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, truth = ctx.saved_tensors
+        return K.l1_bwd(out, truth, g.contiguous()), None

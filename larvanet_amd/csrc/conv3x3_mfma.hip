@@ -1,0 +1,491 @@
+// Fused 3x3 convolution (stride 1, zero pad 1, NCHW fp32) for gfx950 as an implicit GEMM on
+// v_mfma_f32_16x16x4_f32, with the reference's elementwise neighbours fused into the epilogue.
+//
+// Replaces, per launch, these reference call sites (file:line into the reference tree):
+//   conv+ReLU                      models/LarvaNet.py:210-211, 256-257
+//   conv + torch.add(x, res)       models/LarvaNet.py:212, 217-220
+//   last block conv + outer skip   models/LarvaNet.py:246-248   (two residual operands)
+//   conv -> PixelShuffle(4) -> += base   models/LarvaNet.py:258, 261, 263-267   (mode 1)
+//   torch.cat(features) + merge conv     models/LarvaNetV2.py:328-330  (several source tensors)
+// and, with tap-flipped / channel-transposed packed weights, the input-gradient (dgrad) of each
+// of them, with the ReLU-backward mask and the skip-gradient add fused the same way.
+//
+// GEMM view per workgroup:  D[cout][pixel] = sum_k W[cout][k] * im2col[k][pixel],
+//   k = (channel chunk of 16) x (tap 0..8) x (4 k-steps of 4 channels).
+//   MFMA A operand = weights (M = cout), B operand = activations (N = pixel), so each lane ends
+//   up with 4 consecutive output channels of ONE pixel: that is exactly the (i, j) sub-pixel
+//   quad... of PixelShuffle(4) for i = lane>>4, j = reg, which makes the shuffle store free.
+//
+// Roofline: fp32 MFMA (2*9*Cin*Cout FLOP per pixel; 41 472 at 48 channels) -- see DESIGN.md.
+#include "larva_common.h"
+
+namespace larva {
+
+struct ConvArgs {
+  const float* src[kMaxSrc];  // channel-concatenated inputs, each [N][cin_per_src][H][W]
+  const float* wpk;           // packed weights [n_chunks][9][16][CS]
+  const float* bias;          // [COUT] or null
+  const float* res0;          // [N][COUT][H][W] or null   (added first)
+  const float* res1;          // [N][COUT][H][W] or null   (added second)
+  const float* mask;          // [N][COUT][H][W] or null   (v = mask > 0 ? v : 0, before the adds)
+  const float* base;          // mode 1: [N][COUT/16][4H][4W] or null
+  float* out;                 // mode 0: [N][COUT][H][W]; mode 1: [N][COUT/16][4H][4W]
+  int cin_per_src;            // multiple of 16
+  int n_chunks;               // total input channels / 16
+  int N, H, W;
+  int tiles_x, tiles_y;
+  int relu;                   // v = max(v, 0) first
+  int mode;                   // 0 = NCHW store, 1 = pixel-shuffle(4) store
+  int vec_ok;                 // W % 4 == 0 and every source pointer 16-byte aligned
+};
+
+// Epilogue variants (compile-time so that every residual/mask load of a wave is in flight at
+// once instead of one dependent L2 round trip per runtime branch).
+enum Epi : int {
+  kEpiPlain = 0,        // out = acc + bias
+  kEpiRelu = 1,         // out = max(acc + bias, 0)
+  kEpiMask = 2,         // out = mask > 0 ? acc + bias : 0            (ReLU backward)
+  kEpiRes1 = 3,         // out = (acc + bias) + res0
+  kEpiRes2 = 4,         // out = ((acc + bias) + res0) + res1
+  kEpiShuffle = 5,      // pixel-shuffle(4) store
+  kEpiShuffleBase = 6,  // pixel-shuffle(4) store, + base
+  kEpiCount = 7
+};
+
+template <int COUT>
+struct ConvCfg {
+  static constexpr int CT = COUT / 16;
+  static constexpr int CS = cout_stride(COUT);
+  static constexpr int PS = 304;  // plane stride of a staged channel: >= 5*kRS and == 16 (mod 32)
+  static constexpr int IN_FLOATS = kChunk * PS;
+  static constexpr int W_FLOATS = 9 * kChunk * CS;
+  static constexpr int STAGE_FLOATS = IN_FLOATS + W_FLOATS;
+  static constexpr int IN_SLOTS = kChunk * kHaloRows * (kRS / 4);  // float4 slots
+  static constexpr int IN_ITERS = (IN_SLOTS + 255) / 256;
+  static constexpr int W_SLOTS = W_FLOATS / 4;
+  static constexpr int W_ITERS = (W_SLOTS + 255) / 256;
+  static constexpr size_t LDS_BYTES = 2 * STAGE_FLOATS * sizeof(float);
+};
+
+// Registers that carry one chunk (16 channels of halo tile + its 9x16xCOUT weights) from
+// global memory to LDS: loads are issued before the MFMA block of the previous chunk, the LDS
+// writes happen after it.
+template <int COUT>
+struct Staging {
+  f32x4 in[ConvCfg<COUT>::IN_ITERS];
+  f32x4 w[ConvCfg<COUT>::W_ITERS];
+  uint32_t ok;  // VEC path: bit i = slot i lies inside the image (applied at LDS-write time so
+                // that nothing consumes a load result before the MFMA block)
+};
+
+template <int COUT, bool VEC>
+__device__ __forceinline__ void load_chunk(const ConvArgs& a, int chunk, int n, int y0, int x0,
+                                           int tid, Staging<COUT>& st) {
+  using C = ConvCfg<COUT>;
+  const int c0 = chunk * kChunk;
+  const int s_idx = c0 / a.cin_per_src;
+  const int c_in_src = c0 - s_idx * a.cin_per_src;
+  const float* __restrict__ src = a.src[s_idx];
+  const size_t plane = (size_t)a.H * a.W;
+  const float* img = src + ((size_t)n * a.cin_per_src + c_in_src) * plane;
+  // Branch-free: every lane loads from a clamped (always valid) address and zeroes what lies
+  // outside the image when it writes LDS, so all loads of a chunk are in flight together.
+  uint32_t okbits = 0;
+#pragma unroll
+  for (int i = 0; i < C::IN_ITERS; ++i) {
+    int s = tid + i * 256;
+    const bool live = s < C::IN_SLOTS;
+    s = live ? s : 0;
+    const int ci = s / (kHaloRows * (kRS / 4));
+    const int rem = s - ci * (kHaloRows * (kRS / 4));
+    const int r = rem / (kRS / 4);
+    const int q = rem - r * (kRS / 4);
+    const int gy = y0 - 1 + r;
+    const int gx = x0 - 4 + 4 * q;
+    const bool row_ok = live && gy >= 0 && gy < a.H;
+    const int cy = min(max(gy, 0), a.H - 1);
+    const float* row = img + (size_t)ci * plane + (size_t)cy * a.W;
+    f32x4 v;
+    if constexpr (VEC) {
+      const bool ok = row_ok && gx >= 0 && gx < a.W;
+      const int cx = min(max(gx, 0), a.W - 4);
+      v = *reinterpret_cast<const f32x4*>(row + cx);
+      okbits |= (ok ? 1u : 0u) << i;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = gx + e;
+        const bool ok = row_ok && x >= 0 && x < a.W;
+        v[e] = row[min(max(x, 0), a.W - 1)];
+        okbits |= (ok ? 1u : 0u) << (4 * i + e);
+      }
+    }
+    st.in[i] = v;
+  }
+  st.ok = okbits;
+  const float* wsrc = a.wpk + (size_t)chunk * C::W_FLOATS;
+#pragma unroll
+  for (int i = 0; i < C::W_ITERS; ++i) {
+    const int s = min(tid + i * 256, C::W_SLOTS - 1);
+    st.w[i] = *reinterpret_cast<const f32x4*>(wsrc + 4 * s);
+  }
+}
+
+template <int COUT, bool VEC>
+__device__ __forceinline__ void store_chunk(float* stage, int tid, const Staging<COUT>& st) {
+  using C = ConvCfg<COUT>;
+#pragma unroll
+  for (int i = 0; i < C::IN_ITERS; ++i) {
+    const int s = tid + i * 256;
+    if (i * 256 + 255 < C::IN_SLOTS || s < C::IN_SLOTS) {
+      const int ci = s / (kHaloRows * (kRS / 4));
+      const int rem = s - ci * (kHaloRows * (kRS / 4));
+      const int r = rem / (kRS / 4);
+      const int q = rem - r * (kRS / 4);
+      f32x4 v = st.in[i];
+      if constexpr (VEC) {
+        v = ((st.ok >> i) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((st.ok >> (4 * i + e)) & 1u) ? v[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(stage + ci * C::PS + r * kRS + 4 * q) = v;
+    }
+  }
+  float* wdst = stage + C::IN_FLOATS;
+#pragma unroll
+  for (int i = 0; i < C::W_ITERS; ++i) {
+    const int s = tid + i * 256;
+    if (i * 256 + 255 < C::W_SLOTS || s < C::W_SLOTS) *reinterpret_cast<f32x4*>(wdst + 4 * s) = st.w[i];
+  }
+}
+
+// Operands of k-step `step` (= tap*4 + kk) of one chunk.
+template <int COUT, int NCT, int PG0, int NPG>
+__device__ __forceinline__ void read_operands(const float* a_base, const float* b_base, int step,
+                                              float (&av)[NCT], float (&bv)[NPG]) {
+  using C = ConvCfg<COUT>;
+  const int tap = step >> 2, kk = step & 3;
+  const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) av[c] = a_base[(tap * kChunk + kk * 4) * C::CS + c * 16];
+#pragma unroll
+  for (int p = 0; p < NPG; ++p) {
+    const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+    bv[p] = b_base[kk * 4 * C::PS + (prow + ky) * kRS + pcol * 16 + kx];
+  }
+}
+
+// One chunk of K (16 channels x 9 taps = 36 k-steps) for a wave that owns cout groups
+// [ct0, ct0+NCT) and pixel groups [PG0, PG0+NPG) of the tile.  One wave per SIMD means nobody
+// else hides the LDS latency, so the operands of step s+1 are read while step s multiplies.
+template <int COUT, int NCT, int PG0, int NPG>
+__device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int lane,
+                                           f32x4 (&acc)[NCT][NPG]) {
+  using C = ConvCfg<COUT>;
+  const int lr = lane & 15, lq = lane >> 4;
+  const float* a_base = stage + C::IN_FLOATS + lq * C::CS + lr + ct0 * 16;
+  const float* b_base = stage + lq * C::PS + lr + 3;
+  float av[2][NCT], bv[2][NPG];
+  read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, 0, av[0], bv[0]);
+#pragma unroll
+  for (int step = 0; step < 36; ++step) {
+    if (step + 1 < 36)
+      read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+    // hipcc otherwise sinks every ds_read to just above its first use (lgkmcnt(0) per pair of
+    // MFMAs): pin "reads of step s+1, then MFMAs of step s".
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p)
+        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][c], bv[step & 1][p], acc[c][p], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int COUT, bool VEC, int EPI, int NCT, int PG0, int NPG>
+__device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0, int n, int y0,
+                                         int x0, int tid) {
+  using C = ConvCfg<COUT>;
+  const int lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  // Bias is fetched now and added in the epilogue (nothing waits for it before the MFMAs).
+  f32x4 bias[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) bias[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[c][r] = a.bias[(ct0 + c) * 16 + lq * 4 + r];
+  }
+  f32x4 acc[NCT][NPG];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int p = 0; p < NPG; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Staging<COUT> st;
+  load_chunk<COUT, VEC>(a, 0, n, y0, x0, tid, st);
+  store_chunk<COUT, VEC>(smem, tid, st);
+  __syncthreads();
+
+  for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+    float* cur = smem + (chunk & 1) * C::STAGE_FLOATS;
+    float* nxt = smem + ((chunk & 1) ^ 1) * C::STAGE_FLOATS;
+    const bool more = chunk + 1 < a.n_chunks;
+    if (more) load_chunk<COUT, VEC>(a, chunk + 1, n, y0, x0, tid, st);
+    mfma_chunk<COUT, NCT, PG0, NPG>(cur, ct0, lane, acc);
+    if (more) store_chunk<COUT, VEC>(nxt, tid, st);
+    __syncthreads();
+  }
+
+  // Epilogue.  Lane (lr, lq) holds, in acc[c][p][r], output channel (ct0+c)*16 + lq*4 + r of
+  // pixel (y0 + pg/3, x0 + (pg%3)*16 + lr).
+  if constexpr (EPI == kEpiShuffle || EPI == kEpiShuffleBase) {
+    // PixelShuffle(4): out[n, C, 4y+i, 4x+j] = conv[n, 16C + 4i + j, y, x]; here C = ct0+c,
+    // i = lq, j = r -> one aligned 16-byte store per lane (models/LarvaNet.py:261,265-266).
+    const int HH = 4 * a.H, WW = 4 * a.W;
+    f32x4 basev[NCT][NPG];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
+        const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
+        if constexpr (EPI == kEpiShuffleBase) basev[c][p] = *reinterpret_cast<const f32x4*>(a.base + idx);
+      }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int y = y0 + prow, x = x0 + pcol * 16 + lr;
+        const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
+        f32x4 v = acc[c][p] + bias[c];
+        if constexpr (EPI == kEpiShuffleBase) v += basev[c][p];
+        if (y < a.H && x < a.W) *reinterpret_cast<f32x4*>(a.out + idx) = v;
+      }
+  } else {
+    const size_t plane = (size_t)a.H * a.W;
+    constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1) ? 1 : (EPI == kEpiRes2 ? 2 : 0);
+    f32x4 aux[NAUX > 0 ? NAUX : 1][NCT][NPG];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
+        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.W + x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (EPI == kEpiMask) aux[0][c][p][r] = a.mask[idx0 + r * plane];
+          if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) aux[0][c][p][r] = a.res0[idx0 + r * plane];
+          if constexpr (EPI == kEpiRes2) aux[1][c][p][r] = a.res1[idx0 + r * plane];
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int y = y0 + prow, x = x0 + pcol * 16 + lr;
+        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.W + x;
+        const f32x4 v = acc[c][p] + bias[c];
+        if (y < a.H && x < a.W) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float o = v[r];
+            if constexpr (EPI == kEpiRelu) o = fmaxf(o, 0.f);
+            if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
+            if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
+            if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
+            a.out[idx0 + r * plane] = o;
+          }
+        }
+      }
+  }
+}
+
+template <int COUT, bool VEC, int EPI>
+__global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = tile % a.tiles_x;
+  const int t2 = tile / a.tiles_x;
+  const int ty = t2 % a.tiles_y;
+  const int n = t2 / a.tiles_y;
+  const int x0 = tx * kTileCols, y0 = ty * kTileRows;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // 9 pixel groups x CT cout groups, dealt to the 4 waves (one per SIMD) as evenly as a
+  // rectangular (cout groups) x (pixel groups) ownership allows.
+  if constexpr (COUT == 48) {  // 27 -> 7,7,7,6
+    if (wave < 3) run_role<COUT, VEC, EPI, 1, 0, 7>(a, smem, wave, n, y0, x0, tid);
+    else run_role<COUT, VEC, EPI, 3, 7, 2>(a, smem, 0, n, y0, x0, tid);
+  } else if constexpr (COUT == 32) {  // 18 -> 5,5,4,4
+    if (wave < 2) run_role<COUT, VEC, EPI, 1, 0, 5>(a, smem, wave, n, y0, x0, tid);
+    else run_role<COUT, VEC, EPI, 1, 5, 4>(a, smem, wave - 2, n, y0, x0, tid);
+  } else {  // COUT == 64: 36 -> 9,9,9,9
+    static_assert(COUT == 64, "unsupported channel count");
+    run_role<COUT, VEC, EPI, 1, 0, 9>(a, smem, wave, n, y0, x0, tid);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing: [Cout][Cin][3][3] (PyTorch layout, models/LarvaNet.py:210) ->
+//   fwd  [Cin/16][9][16][CS(Cout)]   wpk[chunk][tap][k][co]  = W[co][chunk*16+k][tap]
+//   bwd  [Cout/16][9][16][CS(Cin)]   wpk[chunk][tap][k][ci]  = W[chunk*16+k][ci][8-tap]
+// (dgrad is the same convolution with the channel roles swapped and the taps point-mirrored).
+// `w_cin_total`/`w_cin_off` select a channel slice of a wider weight (merge conv of LarvaNetV2);
+// channels at or beyond w_cin_total pack as zero (the 3-channel head conv padded to 16).
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ fwd,
+                                    float* __restrict__ bwd, int Cout, int Cin, int w_cin_total,
+                                    int w_cin_off) {
+  const int csf = cout_stride(Cout), csb = cout_stride(Cin);
+  const int nf = (Cin / 16) * 9 * 16 * csf;
+  const int nb = (Cout / 16) * 9 * 16 * csb;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += gridDim.x * blockDim.x) {
+    if (i < nf) {
+      if (!fwd) continue;
+      const int co = i % csf;
+      int t = i / csf;
+      const int k = t % 16; t /= 16;
+      const int tap = t % 9;
+      const int chunk = t / 9;
+      float v = 0.f;
+      const int cin_abs = w_cin_off + chunk * 16 + k;
+      if (co < Cout && cin_abs < w_cin_total) v = w[((size_t)co * w_cin_total + cin_abs) * 9 + tap];
+      fwd[i] = v;
+    } else {
+      if (!bwd) continue;
+      const int j = i - nf;
+      const int ci = j % csb;
+      int t = j / csb;
+      const int k = t % 16; t /= 16;
+      const int tap = t % 9;
+      const int chunk = t / 9;
+      float v = 0.f;
+      if (ci < Cin && w_cin_off + ci < w_cin_total)
+        v = w[((size_t)(chunk * 16 + k) * w_cin_total + w_cin_off + ci) * 9 + (8 - tap)];
+      bwd[j] = v;
+    }
+  }
+}
+
+template <int COUT, bool VEC, int EPI>
+static hipError_t launch_conv_e(const ConvArgs& a, hipStream_t stream) {
+  using C = ConvCfg<COUT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<COUT, VEC, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = a.N * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
+  return hipGetLastError();
+}
+
+template <int COUT, bool VEC>
+static hipError_t launch_conv_v(const ConvArgs& a, int epi, hipStream_t stream) {
+  switch (epi) {
+    case kEpiPlain: return launch_conv_e<COUT, VEC, kEpiPlain>(a, stream);
+    case kEpiRelu: return launch_conv_e<COUT, VEC, kEpiRelu>(a, stream);
+    case kEpiMask: return launch_conv_e<COUT, VEC, kEpiMask>(a, stream);
+    case kEpiRes1: return launch_conv_e<COUT, VEC, kEpiRes1>(a, stream);
+    case kEpiRes2: return launch_conv_e<COUT, VEC, kEpiRes2>(a, stream);
+    case kEpiShuffle: return launch_conv_e<COUT, VEC, kEpiShuffle>(a, stream);
+    case kEpiShuffleBase: return launch_conv_e<COUT, VEC, kEpiShuffleBase>(a, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int COUT>
+static hipError_t launch_conv(const ConvArgs& a, int epi, hipStream_t stream) {
+  return a.vec_ok ? launch_conv_v<COUT, true>(a, epi, stream) : launch_conv_v<COUT, false>(a, epi, stream);
+}
+
+}  // namespace larva
+
+using namespace larva;
+
+extern "C" {
+
+// Number of floats of one packed weight image for a conv with `cin` input channels (multiple of
+// 16) and `cout` output channels (32, 48 or 64).
+long long larva_packed_weight_floats(int cout, int cin) {
+  return (long long)(cin / 16) * 9 * 16 * cout_stride(cout);
+}
+
+int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout, int cin,
+                       int w_cin_total, int w_cin_off, void* stream) {
+  if (cout % 16 || cin % 16 || cout <= 0 || cin <= 0) return (int)hipErrorInvalidValue;
+  const int total = (cin / 16) * 9 * 16 * cout_stride(cout) + (cout / 16) * 9 * 16 * cout_stride(cin);
+  const int blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                     wpk_fwd, wpk_bwd, cout, cin, w_cin_total, w_cin_off);
+  return (int)hipGetLastError();
+}
+
+// Fused 3x3 convolution.  `src` is an array of `n_src` device pointers (channel concatenation,
+// each tensor [N][cin_per_src][H][W]); `wpk` a packed weight image from larva_pack_weights for
+// (cout, n_src*cin_per_src).  Epilogue, in this order: relu -> mask -> +res0 -> +res1 -> store
+// (mode 0, [N][cout][H][W]) or pixel-shuffle(4) store with optional +base (mode 1,
+// [N][cout/16][4H][4W]).  Stream-ordered, never allocates or synchronises.
+int larva_conv3x3_fwd(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                      const float* bias, const float* res0, const float* res1, const float* mask,
+                      const float* base, float* out, int N, int cout, int H, int W, int relu,
+                      int mode, void* stream) {
+  if (n_src < 1 || n_src > kMaxSrc || cin_per_src % 16 || N <= 0 || H <= 0 || W <= 0)
+    return (int)hipErrorInvalidValue;
+  if (mode != 0 && mode != 1) return (int)hipErrorInvalidValue;
+  ConvArgs a{};
+  bool aligned = (W % 4 == 0);
+  for (int i = 0; i < n_src; ++i) {
+    if (!src[i]) return (int)hipErrorInvalidValue;
+    a.src[i] = src[i];
+    aligned = aligned && ((reinterpret_cast<uintptr_t>(src[i]) & 15) == 0);
+  }
+  if (!wpk || !out) return (int)hipErrorInvalidValue;
+  a.wpk = wpk; a.bias = bias; a.res0 = res0; a.res1 = res1; a.mask = mask; a.base = base;
+  a.out = out;
+  a.cin_per_src = cin_per_src;
+  a.n_chunks = n_src * cin_per_src / 16;
+  a.N = N; a.H = H; a.W = W;
+  a.tiles_x = (W + kTileCols - 1) / kTileCols;
+  a.tiles_y = (H + kTileRows - 1) / kTileRows;
+  a.relu = relu; a.mode = mode; a.vec_ok = aligned ? 1 : 0;
+  // Map the requested fusion onto a compiled epilogue (relu -> mask -> +res0 -> +res1).
+  int epi;
+  if (mode == 1) {
+    if (relu || mask || res0 || res1) return (int)hipErrorInvalidValue;
+    epi = base ? kEpiShuffleBase : kEpiShuffle;
+  } else {
+    if (base) return (int)hipErrorInvalidValue;
+    const int code = (relu ? 1 : 0) | (mask ? 2 : 0) | (res0 ? 4 : 0) | (res1 ? 8 : 0);
+    switch (code) {
+      case 0: epi = kEpiPlain; break;
+      case 1: epi = kEpiRelu; break;
+      case 2: epi = kEpiMask; break;
+      case 4: epi = kEpiRes1; break;
+      case 12: epi = kEpiRes2; break;
+      default: return (int)hipErrorInvalidValue;
+    }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  switch (cout) {
+    case 32: return (int)launch_conv<32>(a, epi, s);
+    case 48: return (int)launch_conv<48>(a, epi, s);
+    case 64: return (int)launch_conv<64>(a, epi, s);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+}  // extern "C"

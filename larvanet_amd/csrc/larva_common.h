@@ -1,0 +1,43 @@
+// Shared definitions for the gfx950 (MI355X / CDNA4) LarvaNet kernels.
+//
+// Geometry used by every 3x3 kernel in this directory:
+//   * a workgroup (256 threads = 4 wave64, one wave per SIMD) owns one OUTPUT TILE of
+//     3 rows x 48 columns of one image = 9 "pixel groups" of 16 consecutive pixels of a row;
+//   * the matching INPUT HALO TILE is 5 rows x 50 columns per channel, staged in LDS as
+//     [channel][5][LDS_RS] with the first wanted column (x0-1) at index 3 so that column x0
+//     sits on a 16-byte boundary;
+//   * channels are processed in chunks of 16 (= 4 k-steps of v_mfma_f32_16x16x4_f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace larva {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTileRows = 3;
+constexpr int kTileCols = 48;
+constexpr int kHaloRows = kTileRows + 2;
+constexpr int kPixGroups = kTileRows * (kTileCols / 16);  // 9
+constexpr int kChunk = 16;                                 // channels per K chunk
+constexpr int kMaxSrc = 8;                                 // channel-concatenated input tensors
+
+// LDS row stride of a staged halo row (floats): idx 3 = x0-1, idx 4..51 = x0..x0+47, idx 52 = x0+48.
+constexpr int kRS = 56;
+
+__host__ __device__ constexpr int cout_stride(int cout) {
+  // Row stride (floats) of one [k][cout] weight row in LDS: must be == 16 (mod 32) so the two
+  // 16-lane halves of a 32-lane ds_read_b32 group land on disjoint banks.
+  return (cout % 32 == 16) ? cout : cout + 16;
+}
+
+// XCD-aware, bijective block remap (8 XCDs, blocks dealt round-robin): gives every XCD a
+// contiguous run of tiles so that vertically adjacent tiles (which share halo rows) and the
+// same tile of the next layer hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (b >> 3);
+}
+
+}  // namespace larva

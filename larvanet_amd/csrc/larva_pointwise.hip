@@ -1,0 +1,260 @@
+// HBM-bound companions of the conv kernels (gfx950): bicubic x4 base image, L1 loss forward /
+// backward, pixel-unshuffle of the exit gradient, fused AdamW.  All are plain streaming
+// kernels: 16-byte accesses per lane, grid capped at 2048 blocks, no LDS.
+#include "larva_common.h"
+
+namespace larva {
+
+// ---------------------------------------------------------------------------------------------
+// Bicubic x4, align_corners=False (models/LarvaNet.py:283-285 -> F.interpolate(mode='bicubic')).
+// src = (dst + 0.5) / 4 - 0.5; taps at floor(src)-1..+2 with index clamping; Keys kernel
+// A = -0.75; row pass first, then the column weights (the order of ATen's separable CPU path).
+// One thread produces the 4 horizontally adjacent outputs of one LR pixel in one HR row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.0f;
+  w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+  w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+  const float x2 = 1.0f - t;
+  w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  const float x3 = x2 + 1.0f;
+  w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+__global__ void bicubic4_kernel(const float* __restrict__ in, float* __restrict__ out, int planes,
+                                int H, int W) {
+  const int HH = 4 * H;
+  const long long total = (long long)planes * HH * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const long long t2 = i / W;
+    const int Y = (int)(t2 % HH);
+    const int p = (int)(t2 / HH);
+    const float* src = in + (size_t)p * H * W;
+    const float sy = 0.25f * ((float)Y + 0.5f) - 0.5f;
+    const float fy = floorf(sy);
+    const int iy = (int)fy;
+    float wy[4];
+    cubic_coeffs(sy - fy, wy);
+    // columns x-2 .. x+2 of the 4 source rows
+    float v[4][5];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int yy = min(max(iy - 1 + r, 0), H - 1);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) v[r][c] = src[(size_t)yy * W + min(max(x - 2 + c, 0), W - 1)];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int X = 4 * x + jj;
+      const float sx = 0.25f * ((float)X + 0.5f) - 0.5f;
+      const float fx = floorf(sx);
+      const int ix = (int)fx;  // x-1 for jj < 2, x for jj >= 2
+      float wx[4];
+      cubic_coeffs(sx - fx, wx);
+      const int c0 = ix - 1 - (x - 2);  // 0 or 1
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float rowv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rowv += wx[c] * (c0 == 0 ? v[r][c] : v[r][c + 1]);
+        acc += wy[r] * rowv;
+      }
+      o[jj] = acc;
+    }
+    *reinterpret_cast<f32x4*>(out + ((size_t)p * HH + Y) * (4 * W) + 4 * x) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L1 loss (nn.L1Loss(), models/LarvaNet.py:85,108): sum |a - b| -> per-block partials -> one
+// block adds them in index order (reproducible) and writes sum / numel.
+// ---------------------------------------------------------------------------------------------
+constexpr int kL1Blocks = 1024;
+
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a,
+                                                         const float* __restrict__ b,
+                                                         long long numel, float* __restrict__ partial) {
+  float s = 0.f;
+  const long long n4 = numel >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 va = reinterpret_cast<const f32x4*>(a)[i];
+    const f32x4 vb = reinterpret_cast<const f32x4*>(b)[i];
+    s += fabsf(va[0] - vb[0]) + fabsf(va[1] - vb[1]) + fabsf(va[2] - vb[2]) + fabsf(va[3] - vb[3]);
+  }
+  if (blockIdx.x == 0) {
+    for (long long i = (n4 << 2) + threadIdx.x; i < numel; i += 256) s += fabsf(a[i] - b[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ __launch_bounds__(256) void l1_finish_kernel(const float* __restrict__ partial, int n,
+                                                        float inv_numel, float* __restrict__ loss) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = ((ws[0] + ws[1]) + (ws[2] + ws[3])) * inv_numel;
+}
+
+// d/da mean|a-b| * gout = sign(a-b) * gout / numel, sign(0) = 0 (ATen's l1 backward).
+__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                              const float* __restrict__ gout, float inv_numel, long long numel,
+                              float* __restrict__ ga) {
+  const float g = gout[0] * inv_numel;
+  const long long n4 = numel >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 va = reinterpret_cast<const f32x4*>(a)[i];
+    const f32x4 vb = reinterpret_cast<const f32x4*>(b)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = va[e] - vb[e];
+      o[e] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    }
+    reinterpret_cast<f32x4*>(ga)[i] = o;
+  }
+  if (blockIdx.x == 0) {
+    for (long long i = (n4 << 2) + threadIdx.x; i < numel; i += blockDim.x) {
+      const float d = a[i] - b[i];
+      ga[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inverse of PixelShuffle(4) (the backward of models/LarvaNet.py:261):
+//   out[n][16c + 4i + j][y][x] = in[n][c][4y+i][4x+j]
+// ---------------------------------------------------------------------------------------------
+__global__ void pixel_unshuffle4_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                        int planes /* N*C_hr */, int H, int W) {
+  const int HH = 4 * H;
+  const long long total = (long long)planes * HH * W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % W);
+    const long long t2 = idx / W;
+    const int Y = (int)(t2 % HH);
+    const int p = (int)(t2 / HH);
+    const int y = Y >> 2, i = Y & 3;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)p * HH + Y) * (4 * W) + 4 * x);
+    float* o = out + (((size_t)p * 16 + 4 * i) * H + y) * W + x;
+    const size_t plane = (size_t)H * W;
+    o[0] = v[0];
+    o[plane] = v[1];
+    o[2 * plane] = v[2];
+    o[3 * plane] = v[3];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdamW over one flat parameter buffer (torch.optim.AdamW semantics, models/LarvaNet.py:86-88:
+// decoupled weight decay, bias-corrected moments, eps added after the sqrt).  `step_lr` holds
+// {step count as float, lr} on the device so that a captured graph can be replayed.
+// ---------------------------------------------------------------------------------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, const float* __restrict__ step_lr, float beta1,
+                             float beta2, float eps, float wd, float gscale, long long n) {
+  const float step = step_lr[0], lr = step_lr[1];
+  const float bc1 = 1.f - powf(beta1, step);
+  const float bc2 = 1.f - powf(beta2, step);
+  const float step_size = lr / bc1;
+  const float bc2_sqrt = sqrtf(bc2);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float grad = g[i] * gscale;
+    float param = p[i];
+    param *= 1.f - lr * wd;
+    const float mi = m[i] + (grad - m[i]) * (1.f - beta1);  // lerp, as torch does
+    const float vi = v[i] * beta2 + (1.f - beta2) * grad * grad;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    param -= step_size * (mi / denom);
+    p[i] = param;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+static inline int grid_for(long long work, int block) {
+  long long g = (work + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace larva
+
+using namespace larva;
+
+extern "C" {
+
+int larva_bicubic4_fwd(const float* in, float* out, int N, int C, int H, int W, void* stream) {
+  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+  const long long work = (long long)N * C * 4 * H * W;
+  hipLaunchKernelGGL(bicubic4_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     N * C, H, W);
+  return (int)hipGetLastError();
+}
+
+int larva_l1_workspace_floats(void) { return kL1Blocks; }
+
+// loss[0] = mean |a - b|; `partial` is a workspace of larva_l1_workspace_floats() floats.
+int larva_l1_fwd(const float* a, const float* b, long long numel, float* partial, float* loss,
+                 void* stream) {
+  if (!a || !b || !partial || !loss || numel <= 0) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return (int)hipErrorInvalidValue;
+  int blocks = grid_for(numel / 4, 256);
+  if (blocks > kL1Blocks) blocks = kL1Blocks;
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, numel, partial);
+  hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks,
+                     1.0f / (float)numel, loss);
+  return (int)hipGetLastError();
+}
+
+// ga = sign(a - b) * gout[0] / numel   (gout is a device scalar: the upstream gradient).
+int larva_l1_bwd(const float* a, const float* b, const float* gout, long long numel, float* ga,
+                 void* stream) {
+  if (!a || !b || !gout || !ga || numel <= 0) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(ga)) & 15)
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(numel / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     gout, 1.0f / (float)numel, numel, ga);
+  return (int)hipGetLastError();
+}
+
+// in [N][C][4H][4W] -> out [N][16C][H][W]
+int larva_pixel_unshuffle4(const float* in, float* out, int N, int C, int H, int W, void* stream) {
+  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+  const long long work = (long long)N * C * 4 * H * W;
+  hipLaunchKernelGGL(pixel_unshuffle4_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, N * C, H, W);
+  return (int)hipGetLastError();
+}
+
+int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* step_lr, float beta1,
+                     float beta2, float eps, float weight_decay, float grad_scale, long long n,
+                     void* stream) {
+  if (!p || !g || !m || !v || !step_lr || n <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     step_lr, beta1, beta2, eps, weight_decay, grad_scale, n);
+  return (int)hipGetLastError();
+}
+
+const char* larva_error_string(int code) { return hipGetErrorString((hipError_t)code); }
+
+int larva_abi_version(void) { return 1; }
+
+}  // extern "C"

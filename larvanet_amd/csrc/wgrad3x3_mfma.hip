@@ -1,0 +1,386 @@
+// Weight / bias gradient of the 3x3 convolutions (the autograd backward of nn.Conv2d at
+// models/LarvaNet.py:210-212, 227, 256-258 and models/LarvaNetV2.py:318-323) for gfx950:
+//
+//   dW[co][ci][ky][kx] = sum_{n,y,x} dy[n][co][y][x] * x[n][ci][y+ky-1][x+kx-1]
+//   db[co]             = sum_{n,y,x} dy[n][co][y][x]
+//
+// as a split-K GEMM on v_mfma_f32_16x16x4_f32: M = co, N = (ci, tap), K = pixels.  A workgroup
+// walks a contiguous run of 3x48-pixel tiles; per tile it stages dy (3 rows) and x (5 halo rows)
+// in LDS, and every wave keeps the accumulators of ALL co groups x its share of the (ci group,
+// tap) operands in registers across the whole run, so a partial image is written exactly once
+// per workgroup.  A second, batched kernel sums the per-workgroup partial images in a fixed
+// order (bitwise reproducible, no float atomics) and writes the PyTorch-layout gradient.
+//
+// Several layers are processed by ONE launch (blockIdx.y = job): in the backward pass no
+// weight gradient is on the critical path, so the caller queues them and fills the chip with
+// few, long-running workgroups instead of 256 short ones per layer.
+//
+// Roofline: fp32 MFMA, 2*9*Cin*Cout FLOP per pixel (same as the forward conv).
+#include "larva_common.h"
+
+namespace larva {
+
+constexpr int kMaxJobs = 16;
+
+struct WgradJob {
+  const float* dy;   // [N][COUT][H][W]
+  const float* x;    // [N][CIN][H][W]
+  float* partial;    // [splits][ NB*CT*256 + COUT ]
+};
+
+struct WgradBatch {
+  WgradJob job[kMaxJobs];
+  int N, H, W;
+  int tiles_x, tiles_y;
+  int vec_ok;
+};
+
+template <int COUT, int CIN>
+struct WgCfg {
+  static constexpr int CT = COUT / 16;
+  static constexpr int NB = (CIN / 16) * 9;  // B operands: (ci group, tap)
+  static constexpr int NBW = (NB + 3) / 4;   // per wave (last waves may own one fewer)
+  // Channel strides == 2*odd (mod 32): 16 channels x 2 adjacent pixels hit 32 distinct banks.
+  static constexpr int PSD = 146;            // dy: 3 rows x 48
+  static constexpr int PSX = 278;            // x : 5 rows x kRS (tail of the last row unused)
+  static constexpr int DY_FLOATS = COUT * PSD;
+  static constexpr int X_FLOATS = CIN * PSX + 8;
+  static constexpr size_t LDS_BYTES = (DY_FLOATS + X_FLOATS) * sizeof(float);
+  static constexpr int DY_SLOTS = COUT * kTileRows * (kTileCols / 4);
+  static constexpr int X_SLOTS = CIN * kHaloRows * (kRS / 4);
+  static constexpr int DY_ITERS = (DY_SLOTS + 255) / 256;
+  static constexpr int X_ITERS = (X_SLOTS + 255) / 256;
+  static constexpr int PARTIAL_FLOATS = NB * CT * 256 + COUT;
+};
+
+template <int COUT, int CIN>
+struct WgStaging {
+  f32x4 dy[WgCfg<COUT, CIN>::DY_ITERS];
+  f32x4 x[WgCfg<COUT, CIN>::X_ITERS];
+  uint32_t ok_dy, ok_x;
+};
+
+template <int COUT, int CIN, bool VEC>
+__device__ __forceinline__ void wg_load(const WgradBatch& b, const WgradJob& j, int tile, int tid,
+                                        WgStaging<COUT, CIN>& st) {
+  using C = WgCfg<COUT, CIN>;
+  const int tx = tile % b.tiles_x;
+  const int t2 = tile / b.tiles_x;
+  const int ty = t2 % b.tiles_y;
+  const int n = t2 / b.tiles_y;
+  const int x0 = tx * kTileCols, y0 = ty * kTileRows;
+  const size_t plane = (size_t)b.H * b.W;
+  uint32_t ok_dy = 0, ok_x = 0;
+  const float* dyimg = j.dy + (size_t)n * COUT * plane;
+#pragma unroll
+  for (int i = 0; i < C::DY_ITERS; ++i) {
+    int s = tid + i * 256;
+    const bool live = s < C::DY_SLOTS;
+    s = live ? s : 0;
+    const int co = s / (kTileRows * 12);
+    const int rem = s - co * (kTileRows * 12);
+    const int r = rem / 12;
+    const int q = rem - r * 12;
+    const int gy = y0 + r, gx = x0 + 4 * q;
+    const bool row_ok = live && gy < b.H;
+    const float* row = dyimg + (size_t)co * plane + (size_t)min(gy, b.H - 1) * b.W;
+    f32x4 v;
+    if constexpr (VEC) {
+      v = *reinterpret_cast<const f32x4*>(row + min(gx, b.W - 4));
+      ok_dy |= ((row_ok && gx < b.W) ? 1u : 0u) << i;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (row_ok && gx + e < b.W) ? row[min(gx + e, b.W - 1)] : 0.f;
+    }
+    st.dy[i] = v;
+  }
+  const float* ximg = j.x + (size_t)n * CIN * plane;
+#pragma unroll
+  for (int i = 0; i < C::X_ITERS; ++i) {
+    int s = tid + i * 256;
+    const bool live = s < C::X_SLOTS;
+    s = live ? s : 0;
+    const int ci = s / (kHaloRows * 14);
+    const int rem = s - ci * (kHaloRows * 14);
+    const int r = rem / 14;
+    const int q = rem - r * 14;
+    const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+    const bool row_ok = live && gy >= 0 && gy < b.H;
+    const float* row = ximg + (size_t)ci * plane + (size_t)min(max(gy, 0), b.H - 1) * b.W;
+    f32x4 v;
+    if constexpr (VEC) {
+      v = *reinterpret_cast<const f32x4*>(row + min(max(gx, 0), b.W - 4));
+      ok_x |= ((row_ok && gx >= 0 && gx < b.W) ? 1u : 0u) << i;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = gx + e;
+        v[e] = (row_ok && x >= 0 && x < b.W) ? row[min(max(x, 0), b.W - 1)] : 0.f;
+      }
+    }
+    st.x[i] = v;
+  }
+  st.ok_dy = ok_dy;
+  st.ok_x = ok_x;
+}
+
+__device__ __forceinline__ void lds_store4(float* p, f32x4 v) {
+  // Channel bases are only 8-byte aligned (odd strides/2), so two 8-byte stores.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
+  *reinterpret_cast<f32x2*>(p + 2) = f32x2{v[2], v[3]};
+}
+
+template <int COUT, int CIN, bool VEC>
+__device__ __forceinline__ void wg_store(float* s_dy, float* s_x, int tid,
+                                         const WgStaging<COUT, CIN>& st) {
+  using C = WgCfg<COUT, CIN>;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < C::DY_ITERS; ++i) {
+    const int s = tid + i * 256;
+    if (i * 256 + 255 < C::DY_SLOTS || s < C::DY_SLOTS) {
+      const int co = s / (kTileRows * 12);
+      const int rem = s - co * (kTileRows * 12);
+      const int r = rem / 12;
+      const int q = rem - r * 12;
+      f32x4 v = st.dy[i];
+      if constexpr (VEC) v = ((st.ok_dy >> i) & 1u) ? v : zero;
+      lds_store4(s_dy + co * C::PSD + r * kTileCols + 4 * q, v);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < C::X_ITERS; ++i) {
+    const int s = tid + i * 256;
+    if (i * 256 + 255 < C::X_SLOTS || s < C::X_SLOTS) {
+      const int ci = s / (kHaloRows * 14);
+      const int rem = s - ci * (kHaloRows * 14);
+      const int r = rem / 14;
+      const int q = rem - r * 14;
+      f32x4 v = st.x[i];
+      if constexpr (VEC) v = ((st.ok_x >> i) & 1u) ? v : zero;
+      lds_store4(s_x + ci * C::PSX + r * kRS + 4 * q, v);
+    }
+  }
+}
+
+// k-step `ks` of a tile covers pixels (row = ks / 12, cols 4*(ks%12) .. +3).
+template <int COUT, int CIN, int B0, int NBW>
+__device__ __forceinline__ void wg_read(const float* a_base, const float* b_base, int ks,
+                                        float (&av)[COUT / 16], float (&bv)[NBW]) {
+  using C = WgCfg<COUT, CIN>;
+  const int row = ks / 12, col = 4 * (ks % 12);
+#pragma unroll
+  for (int c = 0; c < C::CT; ++c) av[c] = a_base[c * 16 * C::PSD + row * kTileCols + col];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    const int bi = B0 + j, cit = bi / 9, tap = bi % 9, ky = tap / 3, kx = tap % 3;
+    bv[j] = b_base[cit * 16 * C::PSX + (row + ky) * kRS + col + kx];
+  }
+}
+
+template <int COUT, int CIN, bool VEC, int B0, int NBW>
+__device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, float* smem,
+                                        int split, int splits, int tid, bool bias_wave) {
+  using C = WgCfg<COUT, CIN>;
+  const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  float* s_dy = smem;
+  float* s_x = smem + C::DY_FLOATS;
+  const float* a_base = s_dy + lr * C::PSD + lq;
+  const float* b_base = s_x + lr * C::PSX + lq + 3;
+
+  f32x4 acc[C::CT][NBW];
+#pragma unroll
+  for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) acc[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[C::CT];
+#pragma unroll
+  for (int c = 0; c < C::CT; ++c) bsum[c] = 0.f;
+
+  const int total = b.N * b.tiles_x * b.tiles_y;
+  const int t_begin = (int)(((long long)total * split) / splits);
+  const int t_end = (int)(((long long)total * (split + 1)) / splits);
+
+  // The next tile's global loads ride in registers under the MFMA block of the current one;
+  // at 64x64 channels accumulators + staging exceed the register file, so that shape loads
+  // its tile synchronously instead.
+  constexpr bool kPrefetch = (COUT * CIN <= 48 * 48);
+  WgStaging<COUT, CIN> st;
+  if (kPrefetch && t_begin < t_end) wg_load<COUT, CIN, VEC>(b, j, t_begin, tid, st);
+  for (int t = t_begin; t < t_end; ++t) {
+    if (!kPrefetch) wg_load<COUT, CIN, VEC>(b, j, t, tid, st);
+    __syncthreads();  // every wave is done reading the previous tile
+    wg_store<COUT, CIN, VEC>(s_dy, s_x, tid, st);
+    __syncthreads();
+    if (kPrefetch && t + 1 < t_end) wg_load<COUT, CIN, VEC>(b, j, t + 1, tid, st);
+
+    float av[2][C::CT], bv[2][NBW];
+    wg_read<COUT, CIN, B0, NBW>(a_base, b_base, 0, av[0], bv[0]);
+#pragma unroll
+    for (int ks = 0; ks < 36; ++ks) {
+      if (ks + 1 < 36) wg_read<COUT, CIN, B0, NBW>(a_base, b_base, ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+        for (int k = 0; k < NBW; ++k)
+          acc[c][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][c], bv[ks & 1][k], acc[c][k], 0, 0, 0);
+      if (bias_wave) {
+#pragma unroll
+        for (int c = 0; c < C::CT; ++c) bsum[c] += av[ks & 1][c];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // Partial image: [b][ct][lane][4] = the accumulator registers as they stand (1 KiB per tile
+  // per store instruction, fully coalesced).  acc[c][k][r] = dW[co = 16c + 4lq + r][ci = 16*cit + lr][tap].
+  float* part = j.partial + (size_t)split * C::PARTIAL_FLOATS;
+#pragma unroll
+  for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+    for (int k = 0; k < NBW; ++k)
+      *reinterpret_cast<f32x4*>(part + (((B0 + k) * C::CT + c) * 64 + lane) * 4) = acc[c][k];
+  if (bias_wave) {
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c) {
+      float v = bsum[c];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 16) part[C::NB * C::CT * 256 + c * 16 + lane] = v;
+    }
+  }
+}
+
+template <int COUT, int CIN, bool VEC>
+__global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(WgradBatch b) {
+  using C = WgCfg<COUT, CIN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WgradJob& j = b.job[blockIdx.y];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x, splits = gridDim.x;
+  // (ci group, tap) operands dealt to the 4 waves: NB = 9 -> 3,2,2,2; 18 -> 5,5,4,4;
+  // 27 -> 7,7,7,6; 36 -> 9,9,9,9.
+  constexpr int NB = C::NB;
+  constexpr int W0 = (NB + 3) / 4, W1 = (NB + 2) / 4, W2 = (NB + 1) / 4, W3 = NB / 4;
+  if (wave == 0) wg_role<COUT, CIN, VEC, 0, W0>(b, j, smem, split, splits, tid, true);
+  else if (wave == 1) wg_role<COUT, CIN, VEC, W0, W1>(b, j, smem, split, splits, tid, false);
+  else if (wave == 2) wg_role<COUT, CIN, VEC, W0 + W1, W2>(b, j, smem, split, splits, tid, false);
+  else wg_role<COUT, CIN, VEC, W0 + W1 + W2, W3>(b, j, smem, split, splits, tid, false);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fixed-order reduction of the partial images into PyTorch-layout gradients.
+// ---------------------------------------------------------------------------------------------
+struct ReduceJob {
+  const float* partial;  // [splits][PARTIAL_FLOATS]
+  float* dw;             // [cout][w_cin_total][3][3]
+  float* db;             // [cout] or null
+  int cin_off;           // first input channel of this job inside dw
+  int cin_valid;         // channels of this job that exist in dw (3 for the head, else CIN)
+  int w_cin_total;
+};
+
+struct ReduceBatch {
+  ReduceJob job[kMaxJobs];
+  int splits;
+  int cout, cin;  // kernel shape of every job in the batch
+};
+
+__global__ void wgrad_reduce_kernel(ReduceBatch rb) {
+  const ReduceJob& j = rb.job[blockIdx.y];
+  const int ct_n = rb.cout / 16, nb = (rb.cin / 16) * 9;
+  const int n_w = nb * ct_n * 256;
+  const int pf = n_w + rb.cout;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pf) return;
+  float s = 0.f;
+  for (int k = 0; k < rb.splits; ++k) s += j.partial[(size_t)k * pf + i];
+  if (i < n_w) {
+    const int r = i & 3, lane = (i >> 2) & 63;
+    const int t = i >> 8;
+    const int c = t % ct_n, bi = t / ct_n;
+    const int cit = bi / 9, tap = bi % 9;
+    const int co = c * 16 + (lane >> 4) * 4 + r;
+    const int ci = cit * 16 + (lane & 15);
+    if (ci < j.cin_valid) j.dw[((size_t)co * j.w_cin_total + j.cin_off + ci) * 9 + tap] = s;
+  } else if (j.db) {
+    j.db[i - n_w] = s;
+  }
+}
+
+template <int COUT, int CIN>
+static hipError_t launch_wgrad(const WgradBatch& b, int njobs, int splits, hipStream_t stream) {
+  using C = WgCfg<COUT, CIN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (b.vec_ok)
+    hipLaunchKernelGGL((wgrad3x3_kernel<COUT, CIN, true>), dim3(splits, njobs), dim3(256), C::LDS_BYTES, stream, b);
+  else
+    hipLaunchKernelGGL((wgrad3x3_kernel<COUT, CIN, false>), dim3(splits, njobs), dim3(256), C::LDS_BYTES, stream, b);
+  return hipGetLastError();
+}
+
+}  // namespace larva
+
+using namespace larva;
+
+extern "C" {
+
+// Floats of partial-image workspace one job needs for `splits` workgroups.
+long long larva_wgrad_partial_floats(int cout, int cin, int splits) {
+  return (long long)splits * ((long long)(cin / 16) * 9 * (cout / 16) * 256 + cout);
+}
+
+// Weight + bias gradients of `njobs` (<= 16) same-shape 3x3 convolutions in two launches.
+// Job i: dy[i] [N][cout][H][W], x[i] [N][cin][H][W] -> partial[i] (workspace of
+// larva_wgrad_partial_floats floats) -> dw[i] [cout][w_cin_total[i]][3][3] at input-channel
+// offset cin_off[i] (only the first cin_valid[i] channels are written; the rest of `cin` is
+// zero padding of x), db[i] [cout] (may be null).  Gradients are OVERWRITTEN, not accumulated.
+int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* const* partial,
+                        float* const* dw, float* const* db, const int* cin_off,
+                        const int* cin_valid, const int* w_cin_total, int njobs, int splits,
+                        int N, int cout, int cin, int H, int W, void* stream) {
+  if (njobs < 1 || njobs > kMaxJobs || splits < 1 || N <= 0 || H <= 0 || W <= 0)
+    return (int)hipErrorInvalidValue;
+  WgradBatch b{};
+  ReduceBatch rb{};
+  bool aligned = (W % 4 == 0);
+  for (int i = 0; i < njobs; ++i) {
+    if (!dy[i] || !x[i] || !partial[i] || !dw[i]) return (int)hipErrorInvalidValue;
+    b.job[i] = WgradJob{dy[i], x[i], partial[i]};
+    aligned = aligned && ((reinterpret_cast<uintptr_t>(dy[i]) & 15) == 0) &&
+              ((reinterpret_cast<uintptr_t>(x[i]) & 15) == 0);
+    rb.job[i] = ReduceJob{partial[i], dw[i], db ? db[i] : nullptr, cin_off[i], cin_valid[i], w_cin_total[i]};
+  }
+  b.N = N; b.H = H; b.W = W;
+  b.tiles_x = (W + kTileCols - 1) / kTileCols;
+  b.tiles_y = (H + kTileRows - 1) / kTileRows;
+  b.vec_ok = aligned ? 1 : 0;
+  const int total = N * b.tiles_x * b.tiles_y;
+  if (splits > total) splits = total;
+  rb.splits = splits; rb.cout = cout; rb.cin = cin;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if (cout == 48 && cin == 48) e = launch_wgrad<48, 48>(b, njobs, splits, s);
+  else if (cout == 48 && cin == 16) e = launch_wgrad<48, 16>(b, njobs, splits, s);
+  else if (cout == 32 && cin == 32) e = launch_wgrad<32, 32>(b, njobs, splits, s);
+  else if (cout == 64 && cin == 64) e = launch_wgrad<64, 64>(b, njobs, splits, s);
+  else return (int)hipErrorInvalidValue;
+  if (e != hipSuccess) return (int)e;
+  const int pf = (cin / 16) * 9 * (cout / 16) * 256 + cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((pf + 255) / 256, njobs), dim3(256), 0, s, rb);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+"""ctypes binding of liblarva_hip.so (the C ABI declared in include/larva_hip.h).
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblarva_hip.so")
+
+_c_float_p = ctypes.c_void_p  # device pointers travel as integers
+_c_pp = ctypes.POINTER(ctypes.c_void_p)
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); mirrors include/larva_hip.h one to one
+SIGNATURES = {
+    "larva_abi_version": (ctypes.c_int, []),
+    "larva_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "larva_packed_weight_floats": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int]),
+    "larva_pack_weights": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_conv3x3_fwd": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
+                                         _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_wgrad_partial_floats": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "larva_conv3x3_wgrad": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_bicubic4_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_void_p]),
+    "larva_l1_workspace_floats": (ctypes.c_int, []),
+    "larva_l1_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong, _c_float_p, _c_float_p,
+                                    ctypes.c_void_p]),
+    "larva_l1_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_longlong, _c_float_p,
+                                    ctypes.c_void_p]),
+    "larva_pixel_unshuffle4": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_adamw_step": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle. Raises RuntimeError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "larvanet_amd: %s is missing. Build it with `python -m larvanet_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        lib = load()
+        msg = lib.larva_error_string(code)
+        raise RuntimeError("larvanet_amd: %s failed: hip error %d (%s)" %
+                           (what, code, msg.decode() if msg else "?"))
+
+
+def ptr_array(ptrs):
+    """Array of device pointers (ints / None) for a `const float* const*` argument."""
+    arr = (ctypes.c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr
+
+
+def int_array(vals):
+    return (ctypes.c_int * len(vals))(*vals)

@@ -1,0 +1,192 @@
+"""Tensor-level wrappers over the C ABI (hip_lib): torch supplies device memory and the stream,
+every byte of arithmetic happens in liblarva_hip.so.  Each wrapper validates what the kernel and
+its grid assume (device, dtype, contiguity, shapes) before launching.
+"""
+import torch
+
+from . import hip_lib
+
+_SUPPORTED_COUT = (32, 48, 64)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("larvanet_amd: %s must be a tensor on a HIP device (no CPU path exists)" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("larvanet_amd: %s must be float32, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("larvanet_amd: %s must be contiguous" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError("larvanet_amd: %s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t.data_ptr()
+
+
+def _opt(t, name, shape):
+    return None if t is None else _chk(t, name, shape)
+
+
+def packed_weight_floats(cout, cin):
+    return int(hip_lib.load().larva_packed_weight_floats(cout, cin))
+
+
+def pack_weights(w, cin_off=0, cin=None, cin_pad=None, want_bwd=True):
+    """w: [cout][cin_total][3][3] -> (wpk_fwd, wpk_bwd) packed images for the conv kernel.
+
+    Packs the input-channel slice [cin_off, cin_off+cin) (default: to the end).  cin_pad pads
+    with zero channels up to that kernel channel count (head conv: 3 -> 16); padding is only
+    meaningful when the slice ends at cin_total."""
+    lib = hip_lib.load()
+    _chk(w, "w")
+    if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+        raise RuntimeError("larvanet_amd: only [cout][cin][3][3] weights are supported")
+    cout, cin_total = int(w.shape[0]), int(w.shape[1])
+    cin = cin_total - cin_off if cin is None else cin
+    if cin_off < 0 or cin < 1 or cin_off + cin > cin_total:
+        raise RuntimeError("larvanet_amd: weight slice out of range")
+    cin_k = cin if cin_pad is None else cin_pad
+    if cin_k > cin and cin_off + cin != cin_total:
+        raise RuntimeError("larvanet_amd: zero padding needs a slice that ends at cin_total")
+    if cin_k % 16 or cout % 16 or cin_k < cin:
+        raise RuntimeError("larvanet_amd: channel counts must be multiples of 16 (cout=%d cin=%d)" % (cout, cin_k))
+    fwd = torch.empty(packed_weight_floats(cout, cin_k), device=w.device, dtype=torch.float32)
+    bwd = torch.empty(packed_weight_floats(cin_k, cout), device=w.device, dtype=torch.float32) if want_bwd else None
+    code = lib.larva_pack_weights(w.data_ptr(), fwd.data_ptr(), bwd.data_ptr() if want_bwd else None,
+                                  cout, cin_k, cin_total, cin_off, _stream())
+    hip_lib.check(code, "larva_pack_weights")
+    return fwd, bwd
+
+
+def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=None,
+            shuffle=False, base=None, out=None):
+    """Fused 3x3 conv over the channel concatenation of `srcs` (list of [N][c][H][W]).
+
+    shuffle=False: returns [N][cout][H][W]; shuffle=True: returns PixelShuffle(4) layout
+    [N][cout/16][4H][4W] (+ base)."""
+    lib = hip_lib.load()
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    if not 1 <= len(srcs) <= 8:
+        raise RuntimeError("larvanet_amd: 1..8 source tensors")
+    if cout not in _SUPPORTED_COUT:
+        raise RuntimeError("larvanet_amd: cout must be one of %s" % (_SUPPORTED_COUT,))
+    N, cps, H, W = (int(v) for v in srcs[0].shape)
+    if cps % 16:
+        raise RuntimeError("larvanet_amd: input channels per tensor must be a multiple of 16")
+    ptrs = [_chk(s, "src[%d]" % i, (N, cps, H, W)) for i, s in enumerate(srcs)]
+    cin = cps * len(srcs)
+    _chk(wpk, "wpk", (packed_weight_floats(cout, cin),))
+    full = (N, cout, H, W)
+    hr = (N, cout // 16, 4 * H, 4 * W)
+    if out is None:
+        out = torch.empty(hr if shuffle else full, device=srcs[0].device, dtype=torch.float32)
+    _chk(out, "out", hr if shuffle else full)
+    code = lib.larva_conv3x3_fwd(
+        hip_lib.ptr_array(ptrs), len(srcs), cps, wpk.data_ptr(), _opt(bias, "bias", (cout,)),
+        _opt(res0, "res0", full), _opt(res1, "res1", full), _opt(mask, "mask", full),
+        _opt(base, "base", hr), out.data_ptr(), N, cout, H, W, 1 if relu else 0, 1 if shuffle else 0, _stream())
+    hip_lib.check(code, "larva_conv3x3_fwd")
+    return out
+
+
+def wgrad_partial_floats(cout, cin, splits):
+    return int(hip_lib.load().larva_wgrad_partial_floats(cout, cin, splits))
+
+
+def conv3x3_wgrad(jobs, cout, cin, splits):
+    """jobs: list (<= 16) of dicts {dy, x, dw, db (or None), cin_off, cin_valid}; dw/db are
+    overwritten.  All jobs share (N, cout, cin, H, W)."""
+    lib = hip_lib.load()
+    if not 1 <= len(jobs) <= 16:
+        raise RuntimeError("larvanet_amd: 1..16 wgrad jobs per call")
+    N, _, H, W = (int(v) for v in jobs[0]["dy"].shape)
+    dys, xs, parts, dws, dbs, offs, valids, totals, keep = [], [], [], [], [], [], [], [], []
+    nfl = wgrad_partial_floats(cout, cin, splits)
+    for j in jobs:
+        dys.append(_chk(j["dy"], "dy", (N, cout, H, W)))
+        xs.append(_chk(j["x"], "x", (N, cin, H, W)))
+        dw = j["dw"]
+        _chk(dw, "dw")
+        if dw.dim() != 4 or int(dw.shape[0]) != cout or tuple(dw.shape[2:]) != (3, 3):
+            raise RuntimeError("larvanet_amd: dw must be [cout][cin_total][3][3]")
+        total = int(dw.shape[1])
+        off = int(j.get("cin_off", 0))
+        valid = int(j.get("cin_valid", cin))
+        if off < 0 or valid < 1 or valid > cin or off + valid > total:
+            raise RuntimeError("larvanet_amd: wgrad channel slice out of range")
+        part = j.get("partial")
+        if part is None:
+            part = torch.empty(nfl, device=dw.device, dtype=torch.float32)
+        _chk(part, "partial", (nfl,))
+        keep.append(part)
+        parts.append(part.data_ptr())
+        dws.append(dw.data_ptr())
+        dbs.append(_opt(j.get("db"), "db", (cout,)))
+        offs.append(off)
+        valids.append(valid)
+        totals.append(total)
+    code = lib.larva_conv3x3_wgrad(
+        hip_lib.ptr_array(dys), hip_lib.ptr_array(xs), hip_lib.ptr_array(parts), hip_lib.ptr_array(dws),
+        hip_lib.ptr_array(dbs), hip_lib.int_array(offs), hip_lib.int_array(valids), hip_lib.int_array(totals),
+        len(jobs), splits, N, cout, cin, H, W, _stream())
+    hip_lib.check(code, "larva_conv3x3_wgrad")
+    return keep
+
+
+def bicubic4(x):
+    lib = hip_lib.load()
+    N, C, H, W = (int(v) for v in x.shape)
+    _chk(x, "x")
+    out = torch.empty((N, C, 4 * H, 4 * W), device=x.device, dtype=torch.float32)
+    hip_lib.check(lib.larva_bicubic4_fwd(x.data_ptr(), out.data_ptr(), N, C, H, W, _stream()), "larva_bicubic4_fwd")
+    return out
+
+
+def l1_fwd(a, b):
+    """mean |a - b| as a 0-d device tensor."""
+    lib = hip_lib.load()
+    _chk(a, "a")
+    _chk(b, "b", a.shape)
+    ws = torch.empty(int(lib.larva_l1_workspace_floats()), device=a.device, dtype=torch.float32)
+    loss = torch.empty((), device=a.device, dtype=torch.float32)
+    hip_lib.check(lib.larva_l1_fwd(a.data_ptr(), b.data_ptr(), a.numel(), ws.data_ptr(), loss.data_ptr(), _stream()),
+                  "larva_l1_fwd")
+    return loss
+
+
+def l1_bwd(a, b, gout):
+    lib = hip_lib.load()
+    _chk(a, "a")
+    _chk(b, "b", a.shape)
+    _chk(gout, "gout", ())
+    ga = torch.empty_like(a)
+    hip_lib.check(lib.larva_l1_bwd(a.data_ptr(), b.data_ptr(), gout.data_ptr(), a.numel(), ga.data_ptr(), _stream()),
+                  "larva_l1_bwd")
+    return ga
+
+
+def pixel_unshuffle4(g):
+    lib = hip_lib.load()
+    _chk(g, "g")
+    N, C, HH, WW = (int(v) for v in g.shape)
+    if HH % 4 or WW % 4:
+        raise RuntimeError("larvanet_amd: pixel_unshuffle4 needs spatial dims divisible by 4")
+    H, W = HH // 4, WW // 4
+    out = torch.empty((N, 16 * C, H, W), device=g.device, dtype=torch.float32)
+    hip_lib.check(lib.larva_pixel_unshuffle4(g.data_ptr(), out.data_ptr(), N, C, H, W, _stream()),
+                  "larva_pixel_unshuffle4")
+    return out
+
+
+def adamw_step(p, g, m, v, step_lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    lib = hip_lib.load()
+    n = p.numel()
+    for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, name, (n,))
+    _chk(step_lr, "step_lr", (2,))
+    hip_lib.check(lib.larva_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), step_lr.data_ptr(),
+                                       beta1, beta2, eps, weight_decay, grad_scale, n, _stream()),
+                  "larva_adamw_step")

@@ -1,0 +1,326 @@
+"""LarvaNet x4 for MI355X: drop-in for the reference plugin models/LarvaNet.py.
+
+Same plugin surface (create_model(), parse_args/prepare/train_step_larva/upscale/save/restore/...),
+same sub-module names and state_dict keys (head.feature_extraction.*, body_{i}.res_blocks.{j}.body.{0,2}.*,
+body_{i}.leg.recon_block.{0,2}.*), same initialisation draw order -- but every convolution,
+the pixel-shuffle heads, the bicubic base image, the L1 loss and their backward passes run in
+the hand-written gfx950 kernels of liblarva_hip.so.  The nn.Conv2d objects below are parameter
+containers only; their own forward is never called.
+
+Reference call sites are cited as models/LarvaNet.py:<line> (reference tree).
+"""
+import argparse
+import copy
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import dist as ldist
+from .. import kernels as K
+from ..autograd import BodyFn, HeadFn, L1LossFn, LegFn, PackedConv
+from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
+from .base import BaseModel
+
+NUM_FILTERS = 48  # = 3 * 4**2: PixelShuffle(4) of the leg output must give RGB (models/LarvaNet.py:226,261)
+
+
+def create_model():
+    return LarvaNet()
+
+
+def init_conv(conv, scale=0.1):
+    """Reference init (models/LarvaNet.py:22-31): kaiming normal (fan_in, a=0) * scale, zero bias."""
+    nn.init.kaiming_normal_(conv.weight, a=0, mode="fan_in")
+    conv.weight.data *= scale
+    if conv.bias is not None:
+        conv.bias.data.zero_()
+
+
+def _conv(cin, cout):
+    return nn.Conv2d(in_channels=cin, out_channels=cout, kernel_size=3, stride=1, padding=1)
+
+
+def _require_hip(t):
+    if not t.is_cuda:
+        raise RuntimeError("larvanet_amd: the network only runs on a HIP device (MI355X); "
+                           "got a %s tensor and there is no CPU fallback" % t.device)
+
+
+class L1Loss(nn.Module):
+    """nn.L1Loss() replacement (models/LarvaNet.py:85) backed by the fused HIP reduction."""
+
+    def forward(self, output, target):
+        _require_hip(output)
+        return L1LossFn.apply(output, target)
+
+
+class ResidualBlock(nn.Module):
+    """models/LarvaNet.py:205-220"""
+
+    def __init__(self, num_channels):
+        super().__init__()
+        self.body = nn.Sequential(_conv(num_channels, num_channels), nn.ReLU(inplace=True),
+                                  _conv(num_channels, num_channels))
+        init_conv(self.body[0])
+        init_conv(self.body[2])
+
+    def forward(self, x):
+        raise RuntimeError("ResidualBlock is executed by its LarvaBody (fused launch sequence)")
+
+
+class LarvaHead(nn.Module):
+    """models/LarvaNet.py:223-233"""
+
+    def __init__(self):
+        super().__init__()
+        self.feature_extraction = _conv(3, NUM_FILTERS)
+        init_conv(self.feature_extraction)
+        self._pc = PackedConv(self.feature_extraction.weight, self.feature_extraction.bias, cin_pad=16)
+
+    def forward(self, x):
+        _require_hip(x)
+        c = self.feature_extraction
+        return HeadFn.apply(x.contiguous(), c.weight, c.bias, self._pc)
+
+
+class LarvaLeg(nn.Module):
+    """models/LarvaNet.py:251-267"""
+
+    def __init__(self):
+        super().__init__()
+        self.recon_block = nn.Sequential(_conv(NUM_FILTERS, NUM_FILTERS), nn.ReLU(inplace=True),
+                                         _conv(NUM_FILTERS, NUM_FILTERS))
+        init_conv(self.recon_block[0])
+        init_conv(self.recon_block[2])
+        self.upsample = nn.PixelShuffle(4)  # kept for introspection; fused into the conv store
+        self._pcs = [PackedConv(self.recon_block[0].weight, self.recon_block[0].bias),
+                     PackedConv(self.recon_block[2].weight, self.recon_block[2].bias)]
+
+    def forward(self, fea, base):
+        _require_hip(fea)
+        c1, c2 = self.recon_block[0], self.recon_block[2]
+        return LegFn.apply(fea.contiguous(), base.contiguous(), self._pcs, c1.weight, c1.bias, c2.weight, c2.bias)
+
+
+class LarvaBody(nn.Module):
+    """models/LarvaNet.py:236-248"""
+
+    def __init__(self, num_blocks):
+        super().__init__()
+        self.res_blocks = nn.Sequential(*[ResidualBlock(NUM_FILTERS) for _ in range(num_blocks)])
+        self.leg = LarvaLeg()
+        self._pcs = []
+        for blk in self.res_blocks:
+            self._pcs += [PackedConv(blk.body[0].weight, blk.body[0].bias),
+                          PackedConv(blk.body[2].weight, blk.body[2].bias)]
+
+    def forward(self, x):
+        _require_hip(x)
+        params = []
+        for blk in self.res_blocks:
+            params += [blk.body[0].weight, blk.body[0].bias, blk.body[2].weight, blk.body[2].bias]
+        if not params:
+            return x + x
+        return BodyFn.apply(x.contiguous(), self._pcs, *params)
+
+
+def parse_num_blocks(args):
+    blocks = [int(v) for v in str(args.num_blocks).split(",")]
+    if len(blocks) != args.num_modules:
+        # the reference raises GeneratorExit here (models/LarvaNet.py:277-278)
+        raise GeneratorExit("Argument num_blocks should have the same number of elements as num_modules.")
+    return blocks
+
+
+class LarvaNetModule(nn.Module):
+    """models/LarvaNet.py:270-293"""
+
+    def __init__(self, args):
+        super().__init__()
+        self.len = args.num_modules
+        self.interpolate = args.interpolate
+        self.head = LarvaHead()
+        for i, nb in enumerate(parse_num_blocks(args)):
+            setattr(self, "body_%d" % i, LarvaBody(num_blocks=nb))
+
+    def base(self, x):
+        """F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False) (models/LarvaNet.py:283-285)."""
+        _require_hip(x)
+        if self.interpolate != "bicubic":
+            raise RuntimeError("larvanet_amd: only --interpolate=bicubic has a HIP kernel")
+        with torch.no_grad():
+            return K.bicubic4(x.detach().contiguous())
+
+    def forward(self, x):
+        fea = self.head(x)
+        for i in range(self.len):
+            fea = getattr(self, "body_%d" % i)(fea)
+        base = self.base(x)
+        return getattr(self, "body_%d" % (self.len - 1)).leg(fea, base)
+
+
+class LarvaNet(BaseModel):
+    """Plugin wrapper; control flow of models/LarvaNet.py:42-202."""
+
+    module_class = LarvaNetModule
+
+    def __init__(self):
+        super().__init__()
+        self.volume_per_step = 0
+
+    # ------------------------------------------------------------------ flags
+    def _add_args(self, parser):
+        parser.add_argument("--num_modules", type=int, default=2, help="Number of cascaded bodies (exits).")
+        # the reference declares type=str with an int default, which cannot be split (models/LarvaNet.py:51,276)
+        parser.add_argument("--num_blocks", type=str, default="16,16", help="Residual blocks per body, comma separated.")
+        parser.add_argument("--interpolate", type=str, default="bicubic", help="Interpolation of the base image.")
+        parser.add_argument("--val_volume", type=float, default=30e9, help="Input volume between validations.")
+        parser.add_argument("--lr", type=float, default=4e-4, help="Initial learning rate.")
+        parser.add_argument("--lr_decay", type=float, default=0.5, help="Learning rate decay factor.")
+        parser.add_argument("--lr_step", type=int, default=20000, help="Learning rate decay step (unused, kept for CLI parity).")
+        parser.add_argument("--threshold", type=float, default=0.001, help="Plateau threshold (absolute, dB).")
+        parser.add_argument("--min_lr", type=float, default=1e-8, help="Minimum learning rate.")
+        parser.add_argument("--patience", type=int, default=3, help="Plateau patience.")
+        parser.add_argument("--cooldown", type=int, default=6, help="Plateau cooldown.")
+
+    def parse_args(self, args):
+        parser = argparse.ArgumentParser()
+        self._add_args(parser)
+        self.args, remaining_args = parser.parse_known_args(args=args)
+        return copy.deepcopy(self.args), remaining_args
+
+    # ------------------------------------------------------------------ build
+    def _make_scheduler(self):
+        return torch.optim.lr_scheduler.ReduceLROnPlateau(
+            self.optim, mode="max", factor=self.args.lr_decay, patience=self.args.patience,
+            cooldown=self.args.cooldown, threshold=self.args.threshold, threshold_mode="abs",
+            min_lr=self.args.min_lr)
+
+    def prepare(self, is_training, scales, global_step=0):
+        self.global_step = global_step
+        self.total_volume = 0.0
+        self.temp_volume = 0
+        self.scale_list = scales
+        for scale in self.scale_list:
+            if scale not in (2, 3, 4):
+                raise ValueError("Unsupported scale is provided.")
+        if len(self.scale_list) != 1:
+            raise ValueError("Only one scale should be provided.")
+        self.scale = self.scale_list[0]
+
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+            else torch.device("cpu")
+        self.model = self.module_class(args=self.args).to(self.device)
+        ldist.broadcast_parameters(self.model)  # no-op unless torch.distributed is initialised
+
+        if is_training:
+            self.loss_fn = L1Loss()
+            params = [p for p in self.model.parameters() if p.requires_grad]
+            self.optim = torch.optim.AdamW(params, lr=self.args.lr, fused=self.device.type == "cuda")
+            self.scheduler = self._make_scheduler()
+
+    # ------------------------------------------------------------------ training
+    def _exit_losses(self, input_tensor, truth_tensor):
+        """Forward through every exit (models/LarvaNet.py:102-109). Returns (loss, last output)."""
+        net = self.model
+        fea = net.head(input_tensor)
+        base = net.base(input_tensor)
+        loss = 0
+        out = None
+        for i in range(self.args.num_modules):
+            body = getattr(net, "body_%d" % i)
+            fea = body(fea)
+            out = body.leg(fea, base)
+            loss = loss + self.loss_fn(out, truth_tensor)
+        return loss / self.args.num_modules, out
+
+    def train_step_larva(self, args, val_dataloader, input_tensor, truth_tensor, summary=None):
+        self.global_step += 1
+        self.temp_volume += self.volume_per_step
+
+        loss, out = self._exit_losses(input_tensor, truth_tensor)
+
+        self.optim.zero_grad()
+        loss.backward()
+        ldist.allreduce_gradients(self.model)  # mean over ranks; no-op for a single process
+        self.optim.step()
+
+        if self.global_step == 1:
+            self.validate_for_train(args, val_dataloader)
+
+        if self.temp_volume >= self.args.val_volume:
+            self.total_volume += self.temp_volume
+            self.temp_volume = 0
+            self.validate_for_train(args, val_dataloader)
+            if ldist.is_main():
+                self.save(base_path=args.train_path)
+                print(f"saved a model checkpoint at volume {self.total_volume/1e9:.0f}G")
+            if summary is not None:
+                self._write_summary(summary, loss, input_tensor, out, truth_tensor)
+
+        return loss.item()
+
+    def _write_summary(self, summary, loss, input_tensor, out, truth_tensor):
+        summary.add_scalar("loss", loss, self.global_step)
+        summary.add_scalar("lr", self.get_lr(), self.global_step)
+        tensors = {"input": input_tensor, "output": out.detach(), "truth": truth_tensor}
+        for name, t in tensors.items():
+            t8 = t.clamp(0, 255).byte()
+            for i in range(min(4, len(t8))):
+                summary.add_image("%s/%d" % (name, i), t8[i], self.global_step)
+
+    def validate_for_train(self, args, dataloader):
+        """Mean RGB PSNR over the validation set drives ReduceLROnPlateau (models/LarvaNet.py:141-161).
+        Under data parallelism rank r scores images r, r+world, ... and the sum is all-reduced so
+        that every rank steps its scheduler with the same value."""
+        print("begin validation")
+        num_images = dataloader.get_num_images()
+        psnr_sum = 0.0
+        with torch.no_grad():
+            for image_index in range(ldist.rank(), num_images, ldist.world_size()):
+                input_image, truth_image, _ = dataloader.get_image_pair(image_index=image_index, scale=4)
+                output_image = image_to_uint8(self.upscale(input_list=[input_image], scale=4)[0])
+                truth_image = fit_truth_image_size(output_image=output_image, truth_image=image_to_uint8(truth_image))
+                psnr_sum += image_psnr(output_image=output_image, truth_image=truth_image)
+        average_psnr = ldist.allreduce_scalar_sum(psnr_sum, self.device) / max(num_images, 1)
+        print(f"step {self.global_step}, volume {self.total_volume/1e9:.0f}G,"
+              f" psnr={average_psnr:.8f}, lr = {self.get_lr():.8f}")
+        self.scheduler.step(average_psnr)
+        return average_psnr
+
+    # ------------------------------------------------------------------ inference
+    def _to_input_tensor(self, input_list):
+        arr = np.ascontiguousarray(np.stack([np.asarray(a, dtype=np.float32) for a in input_list]))
+        return torch.from_numpy(arr).to(self.device)
+
+    def upscale(self, input_list, scale):
+        """list of CHW numpy images -> (N, 3, 4H, 4W) float32 numpy (models/LarvaNet.py:163-171)."""
+        with torch.no_grad():
+            return self.model(self._to_input_tensor(input_list)).detach().cpu().numpy()
+
+    def test(self, input_list):
+        return self.model(self._to_input_tensor(input_list))
+
+    def fwd_runtime(self, input_tensor):
+        return self.model(input_tensor)
+
+    # ------------------------------------------------------------------ checkpoints
+    def save(self, base_path):
+        """Bare state_dict with the reference's key names (models/LarvaNet.py:183-185)."""
+        save_path = os.path.join(base_path, "model_step%d_vol%.0fG.pth" % (self.global_step, self.total_volume / 1e9))
+        torch.save({k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}, save_path)
+        return save_path
+
+    def restore(self, ckpt_path, target=None):
+        self.model.load_state_dict(torch.load(ckpt_path, map_location=self.device))
+
+    def get_model(self):
+        return self.model
+
+    def get_next_train_scale(self):
+        return self.scale_list[np.random.randint(len(self.scale_list))]
+
+    def get_lr(self):
+        return self.optim.param_groups[0]["lr"]

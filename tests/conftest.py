@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return load
+
+
+@pytest.fixture(scope="session")
+def hip_device():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("a test marked gpu ran without a HIP device")
+    from larvanet_amd import hip_lib
+    hip_lib.load()  # fails loudly if the extension was not built
+    return torch.device("cuda", 0)

@@ -1,0 +1,226 @@
+"""Generates tests/golden/*.npz by IMPORTING the reference (read-only at /root/reference) in the
+build container.  The reference cannot travel to the GPU box; these small input/output vectors
+can.  Run:  python tests/golden/make_golden.py
+
+Accommodations needed to import the reference here (both ordinary Python errors, see SURVEY.md
+section 8c): an empty stand-in module for `cv2` (imported by validate.py:14, never called on this
+path), and prepare(is_training=False) + hand-attached loss/optimizer/scheduler because
+ReduceLROnPlateau(verbose=...) no longer exists in torch 2.10 (models/LarvaNet.py:90-92).
+"""
+import hashlib
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()
+
+
+def sd_to_np(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def make_ref_model(name, argv, seed):
+    mod = importlib.import_module("models." + name)
+    model = mod.create_model()
+    model.parse_args(argv)
+    torch.manual_seed(seed)
+    model.prepare(is_training=False, scales=[4])
+    return model
+
+
+def attach_training(model):
+    import torch.nn as nn
+    import torch.optim as optim
+    model.loss_fn = nn.L1Loss()
+    model.optim = optim.AdamW(filter(lambda p: p.requires_grad, model.model.parameters()), lr=model.args.lr)
+    model.scheduler = optim.lr_scheduler.ReduceLROnPlateau(
+        model.optim, mode="max", factor=model.args.lr_decay, patience=model.args.patience,
+        cooldown=getattr(model.args, "cooldown", 0), threshold=model.args.threshold, threshold_mode="abs",
+        min_lr=model.args.min_lr)
+
+
+class FakeValLoader:
+    """Two tiny synthetic validation pairs (uint8-valued), enough for validate_for_train."""
+
+    def __init__(self, seed):
+        rng = np.random.RandomState(seed)
+        self.pairs = []
+        for (h, w) in ((10, 12), (9, 14)):
+            lr = rng.randint(0, 256, size=(3, h, w)).astype(np.float32)
+            hr = rng.randint(0, 256, size=(3, 4 * h + 1, 4 * w + 2)).astype(np.float32)  # larger: exercises the crop
+            self.pairs.append((lr, hr))
+
+    def get_num_images(self):
+        return len(self.pairs)
+
+    def get_image_pair(self, image_index, scale):
+        lr, hr = self.pairs[image_index]
+        return lr, hr, "img%d" % image_index
+
+
+def main():
+    sys.path.insert(0, REF)
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    torch.set_num_threads(4)
+    torch.use_deterministic_algorithms(False)
+
+    # ---------------- F1/F2: M2B2 weights, staged outputs on a 2x3x12x12 input ----------------
+    model = make_ref_model("LarvaNet", ["--num_modules=2", "--num_blocks=2,2"], seed=0)
+    net = model.model
+    sd = sd_to_np(net.state_dict())
+    g = torch.Generator().manual_seed(100)
+    x = torch.rand(2, 3, 12, 12, generator=g) * 255
+    stages = {}
+
+    def hook(name):
+        def fn(_m, _i, o):
+            stages[name] = o.detach().numpy().copy()
+        return fn
+
+    handles = [net.head.register_forward_hook(hook("head")),
+               net.body_0.register_forward_hook(hook("body_0")),
+               net.body_1.register_forward_hook(hook("body_1")),
+               net.body_0.res_blocks[0].register_forward_hook(hook("body_0.res_blocks.0")),
+               net.body_0.res_blocks[0].body[1].register_forward_hook(hook("body_0.res_blocks.0.relu")),
+               net.body_0.leg.recon_block.register_forward_hook(hook("body_0.leg.recon_block"))]
+    with torch.no_grad():
+        fea = net.head(x)
+        base = net.base(x)
+        outs = []
+        for i in range(2):
+            fea = getattr(net, "body_%d" % i)(fea)
+            outs.append(getattr(net, "body_%d" % i).leg(fea, base).numpy().copy())
+        final = net(x).numpy().copy()
+    for h in handles:
+        h.remove()
+    np.savez(os.path.join(OUT, "f1_m2b2_forward.npz"), x=x.numpy(), base=base.numpy(), exit_0=outs[0],
+             exit_1=outs[1], final=final, **{"stage." + k: v for k, v in stages.items()},
+             **{"sd." + k: v for k, v in sd.items()})
+
+    # ---------------- F3: PixelShuffle(4) integer KAT (bit-exact index layout) ----------------
+    ps_in = torch.arange(2 * 48 * 3 * 5, dtype=torch.int32).reshape(2, 48, 3, 5)
+    ps_out = torch.nn.PixelShuffle(4)(ps_in)
+    np.savez(os.path.join(OUT, "f3_pixel_shuffle.npz"), inp=ps_in.numpy(), out=ps_out.numpy())
+
+    # ---------------- F4: bicubic x4 incl. borders ----------------
+    g = torch.Generator().manual_seed(101)
+    bx = torch.rand(1, 3, 9, 11, generator=g) * 255
+    np.savez(os.path.join(OUT, "f4_bicubic.npz"), inp=bx.numpy(), out=net.base(bx).numpy())
+
+    # ---------------- F5: the reference's own train_step_larva, 3 steps ----------------
+    model = make_ref_model("LarvaNet", ["--num_modules=2", "--num_blocks=2,2"], seed=0)
+    attach_training(model)
+    model.volume_per_step = 12 * 12 * 2 * 3
+    g = torch.Generator().manual_seed(102)
+    tx = torch.rand(2, 3, 12, 12, generator=g) * 255
+    tt = torch.rand(2, 3, 48, 48, generator=g) * 255
+    val = FakeValLoader(7)
+    args = types.SimpleNamespace(train_path="/tmp")
+    losses, grads1, lrs = [], None, []
+    for step in range(3):
+        losses.append(model.train_step_larva(args, val, tx, tt, None))
+        lrs.append(model.get_lr())
+        if step == 0:
+            grads1 = {k: p.grad.detach().numpy().copy() for k, p in model.model.named_parameters()}
+    after = sd_to_np(model.model.state_dict())
+    flat_after = np.concatenate([after[k].ravel() for k in sorted(after)])
+    np.savez(os.path.join(OUT, "f5_train_steps.npz"), x=tx.numpy(), truth=tt.numpy(),
+             losses=np.array(losses, np.float64), lrs=np.array(lrs, np.float64),
+             after3_sample=flat_after[::61].copy(), after3_sha=np.array(sha(flat_after)),
+             global_step=np.array(model.global_step), temp_volume=np.array(model.temp_volume),
+             **{"grad1." + k: v for k, v in grads1.items()})
+
+    # ---------------- F6: canonical M4B4 forward on 16x3x48x48 (sampled) ----------------
+    model = make_ref_model("LarvaNet", ["--num_modules=4", "--num_blocks=4,4,4,4"], seed=0)
+    sd4 = sd_to_np(model.model.state_dict())
+    flat4 = np.concatenate([sd4[k].ravel() for k in sorted(sd4)])
+    g = torch.Generator().manual_seed(0)
+    cx = torch.rand(16, 3, 48, 48, generator=g) * 255
+    with torch.no_grad():
+        cy = model.model(cx).numpy()
+    idx = np.random.RandomState(5).choice(cy.size, 4096, replace=False)
+    np.savez(os.path.join(OUT, "f6_m4b4_canonical.npz"), sd_sha=np.array(sha(flat4)),
+             sd_sample=flat4[::997].copy(), n_params=np.array(flat4.size), out_sha=np.array(sha(cy)),
+             sample_idx=idx, sample_val=cy.ravel()[idx], out_mean=np.array(cy.mean(dtype=np.float64)))
+
+    # ---------------- F7: validate.py helpers ----------------
+    validate = importlib.import_module("validate")
+    img = np.array([[[-3.2, 0.5, 1.5, 2.5], [254.5, 255.5, 300.0, 127.49999]],
+                    [[0.49999997, 3.5, 4.5, 99.5], [1e-7, -0.5, 255.49998, 128.5]],
+                    [[10.2, 20.7, 30.5, 31.5], [32.5, 33.5, 250.5, 251.5]]], np.float32)
+    u8 = validate._image_to_uint8(img)
+    rng = np.random.RandomState(3)
+    o_img = rng.randint(0, 256, size=(3, 8, 10)).astype(np.uint8)
+    t_img = np.clip(o_img.astype(np.int32) + rng.randint(-9, 10, size=o_img.shape), 0, 255).astype(np.uint8)
+    t_big = rng.randint(0, 256, size=(3, 11, 13)).astype(np.uint8)
+    t_big[:, :8, :10] = t_img
+    fitted = validate._fit_truth_image_size(output_image=o_img, truth_image=t_big)
+    psnr = validate._image_psnr(output_image=o_img, truth_image=fitted)
+    np.savez(os.path.join(OUT, "f7_validate_helpers.npz"), img=img, u8=u8, o_img=o_img, t_big=t_big,
+             fitted=fitted, psnr=np.array(float(psnr), np.float64))
+
+    # ---------------- F8: LarvaNetV2 (tail) forward + one train step ----------------
+    model2 = make_ref_model("LarvaNetV2", ["--num_modules=2", "--num_blocks=2,2"], seed=0)
+    sd2 = sd_to_np(model2.model.state_dict())
+    same_trunk = all(np.array_equal(sd2[k], sd[k]) for k in sd)
+    g = torch.Generator().manual_seed(103)
+    vx = torch.rand(2, 3, 12, 12, generator=g) * 255
+    vt = torch.rand(2, 3, 48, 48, generator=g) * 255
+    with torch.no_grad():
+        v_out = model2.model(vx).numpy().copy()
+    attach_training(model2)
+    model2.volume_per_step = 0
+    model2.steps_per_epoch = 10 ** 9 if hasattr(model2, "steps_per_epoch") else None
+    v_loss = model2.train_step_larva(types.SimpleNamespace(train_path="/tmp"), FakeValLoader(7), vx, vt, None)
+    v_grads = {k: p.grad.detach().numpy().copy() for k, p in model2.model.named_parameters() if k.startswith("tail.")}
+    trunk_gsum = {k: float(p.grad.double().abs().sum()) for k, p in model2.model.named_parameters()
+                  if not k.startswith("tail.")}
+    np.savez(os.path.join(OUT, "f8_v2_tail.npz"), x=vx.numpy(), truth=vt.numpy(), out=v_out,
+             loss=np.array(float(v_loss), np.float64), same_trunk=np.array(same_trunk),
+             trunk_keys=np.array(sorted(trunk_gsum)), trunk_gabs=np.array([trunk_gsum[k] for k in sorted(trunk_gsum)]),
+             **{"sd." + k: v for k, v in sd2.items() if k.startswith("tail.")},
+             **{"grad." + k: v for k, v in v_grads.items()})
+
+    # ---------------- F9: chop-forward split / stitch on an odd-sized image ----------------
+    image_utils = importlib.import_module("utils.image_utils")
+
+    class NearestModel:
+        def upscale(self, input_list, scale):
+            a = np.asarray(input_list, np.float32)
+            return a.repeat(scale, axis=2).repeat(scale, axis=3) + 0.25
+
+    rng = np.random.RandomState(11)
+    cimg = rng.randint(0, 256, size=(3, 21, 27)).astype(np.float32)
+    splits = image_utils._split_image(cimg, chop=True, overlap_size=6)
+    chopped = image_utils.upscale_with_chop_forward(model=NearestModel(), input_image=cimg, scale=4, overlap_size=6)
+    np.savez(os.path.join(OUT, "f9_chop_forward.npz"), img=cimg, out=chopped,
+             split_shapes=np.array([s.shape for s in splits]), **{"split%d" % i: s for i, s in enumerate(splits)})
+
+    # ---------------- F10: LarvaNet.upscale + PSNR protocol on a small image ----------------
+    model = make_ref_model("LarvaNet", ["--num_modules=2", "--num_blocks=2,2"], seed=0)
+    rng = np.random.RandomState(21)
+    lr_img = rng.randint(0, 256, size=(3, 20, 26)).astype(np.float32)
+    hr_img = rng.randint(0, 256, size=(3, 80, 104)).astype(np.float32)
+    with torch.no_grad():
+        up = model.upscale(input_list=[lr_img], scale=4)[0]
+    o8 = validate._image_to_uint8(up)
+    t8 = validate._fit_truth_image_size(output_image=o8, truth_image=validate._image_to_uint8(hr_img))
+    np.savez(os.path.join(OUT, "f10_upscale_psnr.npz"), lr=lr_img, hr=hr_img, up=up,
+             psnr=np.array(float(validate._image_psnr(output_image=o8, truth_image=t8)), np.float64))
+
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print("%-28s %8.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,194 @@
+"""The oracle (oracle/) against the vectors captured from the imported reference (tests/golden/).
+CPU only.  This is what pins the oracle; the GPU tests then compare the HIP path with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import larva_ref as R
+from oracle import larva_torch as T
+
+
+def _sd(npz, prefix="sd."):
+    return {k[len(prefix):]: npz[k] for k in npz.files if k.startswith(prefix)}
+
+
+def _tsd(npz, prefix="sd."):
+    return {k: torch.from_numpy(v) for k, v in _sd(npz, prefix).items()}
+
+
+def test_c_restatement_stages_f1(golden):
+    g = golden("f1_m2b2_forward.npz")
+    sd, x = _sd(g), g["x"]
+    head = R.head(sd, x)
+    np.testing.assert_allclose(head, g["stage.head"], rtol=1e-5, atol=2e-4)
+    h = R.relu(R.conv3x3(g["stage.head"], sd["body_0.res_blocks.0.body.0.weight"], sd["body_0.res_blocks.0.body.0.bias"]))
+    np.testing.assert_allclose(h, g["stage.body_0.res_blocks.0.relu"], rtol=1e-5, atol=2e-4)
+    blk = R.residual_block(sd, "body_0.res_blocks.0", g["stage.head"])
+    np.testing.assert_allclose(blk, g["stage.body_0.res_blocks.0"], rtol=1e-5, atol=2e-4)
+    b0 = R.body(sd, 0, g["stage.head"], 2)
+    np.testing.assert_allclose(b0, g["stage.body_0"], rtol=1e-5, atol=5e-4)
+    b1 = R.body(sd, 1, g["stage.body_0"], 2)
+    np.testing.assert_allclose(b1, g["stage.body_1"], rtol=1e-5, atol=5e-4)
+    base = R.bicubic_up(x, 4)
+    np.testing.assert_allclose(base, g["base"], rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(R.leg(sd, "body_0.leg", g["stage.body_0"], g["base"]), g["exit_0"], rtol=1e-5, atol=5e-4)
+    np.testing.assert_allclose(R.forward(sd, x, [2, 2]), g["final"], rtol=1e-5, atol=2e-3)
+    assert np.array_equal(g["exit_1"], g["final"])  # forward() == last exit (models/LarvaNet.py:287-293)
+
+
+def test_torch_restatement_f1_and_init(golden):
+    g = golden("f1_m2b2_forward.npz")
+    sd, x = _tsd(g), torch.from_numpy(g["x"])
+    with torch.no_grad():
+        outs, feats, base = T.forward_exits(sd, x, [2, 2])
+        np.testing.assert_allclose(outs[0].numpy(), g["exit_0"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(outs[1].numpy(), g["exit_1"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(feats[1].numpy(), g["stage.body_1"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(T.forward(sd, x, [2, 2]).numpy(), g["final"], rtol=0, atol=1e-4)
+    init = T.init_state_dict([2, 2], seed=0)
+    assert sorted(init) == sorted(sd)
+    for k in sd:
+        assert torch.equal(init[k], sd[k]), k  # same draw order as the reference modules
+
+
+def test_pixel_shuffle_bit_exact_f3(golden):
+    g = golden("f3_pixel_shuffle.npz")
+    out = R.pixel_shuffle(g["inp"], 4)
+    assert out.dtype == np.int32 and np.array_equal(out, g["out"])
+    assert np.array_equal(R.pixel_unshuffle(g["out"], 4), g["inp"])
+
+
+def test_bicubic_f4(golden):
+    g = golden("f4_bicubic.npz")
+    np.testing.assert_allclose(R.bicubic_up(g["inp"], 4), g["out"], rtol=1e-5, atol=2e-4)
+    # closed-form phase weights quoted in SURVEY 8(a7)
+    one = np.zeros((1, 1, 9, 9), np.float32)
+    one[0, 0, 4, 4] = 1.0
+    up = R.bicubic_up(one, 4)
+    col = up[0, 0, 16, 4 * 4 - 8:4 * 4 + 12:4]  # phase 0 row, taps of column phase 0 at successive LR offsets
+    assert np.isclose(up[0, 0, 16, 16], 0.74951172 * 0.74951172, atol=1e-6), col
+
+
+def test_train_steps_f5(golden):
+    g = golden("f5_train_steps.npz")
+    f1 = golden("f1_m2b2_forward.npz")
+    sd = _tsd(f1)  # same seed-0 M2B2 weights
+    x, truth = torch.from_numpy(g["x"]), torch.from_numpy(g["truth"])
+    # loss by the C restatement (forward only)
+    loss_c = R.multi_exit_loss(_sd(f1), g["x"], g["truth"], [2, 2])
+    assert abs(loss_c - g["losses"][0]) < 1e-4 * abs(g["losses"][0])
+    losses, _ = T.train_steps({k: v.clone() for k, v in sd.items()}, x, truth, [2, 2], steps=1)
+    sd3 = {k: v.clone() for k, v in sd.items()}
+    losses3, _ = T.train_steps(sd3, x, truth, [2, 2], steps=3)
+    np.testing.assert_allclose(losses3, g["losses"], rtol=1e-5)
+    # gradients of step 1
+    _, grads = T.train_steps({k: v.clone() for k, v in sd.items()}, x, truth, [2, 2], steps=1)
+    for k, v in grads.items():
+        ref = g["grad1." + k]
+        np.testing.assert_allclose(v.numpy(), ref, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    flat = np.concatenate([sd3[k].numpy().ravel() for k in sorted(sd3)])
+    np.testing.assert_allclose(flat[::61], g["after3_sample"], rtol=1e-4, atol=1e-6)
+    assert int(g["global_step"]) == 3 and int(g["temp_volume"]) == 3 * 12 * 12 * 2 * 3
+
+
+def test_c_restatement_grads_f5(golden):
+    """dgrad / wgrad / l1-grad of the C restatement chained by hand through the last leg."""
+    g = golden("f5_train_steps.npz")
+    f1 = golden("f1_m2b2_forward.npz")
+    sd = _sd(f1)
+    outs, feats, base = R.forward_exits(sd, g["x"], [2, 2])
+    M = 2
+    # d loss / d exit_1 = sign(out - truth) / (numel * M)
+    dout = R.l1_grad(outs[1], g["truth"], 1.0 / M)
+    dy2 = R.pixel_unshuffle(dout, 4)
+    h = R.relu(R.conv3x3(feats[1], sd["body_1.leg.recon_block.0.weight"], sd["body_1.leg.recon_block.0.bias"]))
+    dw2, db2 = R.conv3x3_wgrad(dy2, h)
+    np.testing.assert_allclose(dw2, g["grad1.body_1.leg.recon_block.2.weight"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(db2, g["grad1.body_1.leg.recon_block.2.bias"], rtol=2e-4, atol=2e-6)
+    dh = R.conv3x3_dgrad(dy2, sd["body_1.leg.recon_block.2.weight"]) * (h > 0)
+    dw1, db1 = R.conv3x3_wgrad(dh, feats[1])
+    np.testing.assert_allclose(dw1, g["grad1.body_1.leg.recon_block.0.weight"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(db1, g["grad1.body_1.leg.recon_block.0.bias"], rtol=2e-4, atol=2e-6)
+
+
+def test_adamw_restatement():
+    rng = np.random.RandomState(0)
+    p = rng.randn(1000).astype(np.float32)
+    gr = rng.randn(1000).astype(np.float32)
+    tp = torch.from_numpy(p.copy()).requires_grad_(True)
+    opt = torch.optim.AdamW([tp], lr=4e-4)
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    pc = p.copy()
+    for step in (1, 2, 3):
+        tp.grad = torch.from_numpy(gr * step)
+        opt.step()
+        pc, m, v = R.adamw(pc, gr * step, m, v, step)
+    np.testing.assert_allclose(pc, tp.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_canonical_forward_f6(golden):
+    g = golden("f6_m4b4_canonical.npz")
+    sd = T.init_state_dict([4, 4, 4, 4], seed=0)
+    flat = np.concatenate([sd[k].numpy().ravel() for k in sorted(sd)])
+    assert flat.size == int(g["n_params"]) == 832704
+    np.testing.assert_array_equal(flat[::997], g["sd_sample"])
+    x = torch.rand(16, 3, 48, 48, generator=torch.Generator().manual_seed(0)) * 255
+    with torch.no_grad():
+        y = T.forward(sd, x, [4, 4, 4, 4]).numpy()
+    np.testing.assert_allclose(y.ravel()[g["sample_idx"]], g["sample_val"], rtol=0, atol=2e-3)
+
+
+def test_validate_helpers_f7(golden):
+    g = golden("f7_validate_helpers.npz")
+    assert np.array_equal(R.image_to_uint8(g["img"]), g["u8"])
+    fitted = R.fit_truth_image_size(g["o_img"], g["t_big"])
+    assert np.array_equal(fitted, g["fitted"])
+    assert abs(R.image_psnr(g["o_img"], g["t_big"]) - float(g["psnr"])) < 1e-4
+    from larvanet_amd import metrics
+    assert np.array_equal(metrics.image_to_uint8(g["img"]), g["u8"])
+    assert abs(float(metrics.image_psnr(g["o_img"], metrics.fit_truth_image_size(g["o_img"], g["t_big"]))) - float(g["psnr"])) < 1e-5
+
+
+def test_v2_tail_f8(golden):
+    g = golden("f8_v2_tail.npz")
+    f1 = golden("f1_m2b2_forward.npz")
+    assert bool(g["same_trunk"])
+    sd = _tsd(f1)
+    sd.update(_tsd(g))
+    x, truth = torch.from_numpy(g["x"]), torch.from_numpy(g["truth"])
+    with torch.no_grad():
+        np.testing.assert_allclose(T.forward_v2(sd, x, [2, 2]).numpy(), g["out"], rtol=0, atol=1e-4)
+    nsd = {k: v.numpy() for k, v in sd.items()}
+    np.testing.assert_allclose(R.forward_v2(nsd, g["x"], [2, 2]), g["out"], rtol=1e-5, atol=2e-3)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss = T.multi_exit_loss(params, x, truth, [2, 2], v2=True)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    for k in params:
+        if k.startswith("tail."):
+            np.testing.assert_allclose(params[k].grad.numpy(), g["grad." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    init = T.init_state_dict([2, 2], v2=True, seed=0)
+    for k in sd:
+        assert torch.equal(init[k], sd[k]), k
+
+
+def test_chop_forward_f9(golden):
+    g = golden("f9_chop_forward.npz")
+    parts = R.split_image(g["img"], 6)
+    assert [p.shape for p in parts] == [tuple(s) for s in g["split_shapes"]]
+    for i, p in enumerate(parts):
+        assert np.array_equal(p, g["split%d" % i])
+    ups = [p.repeat(4, axis=1).repeat(4, axis=2) + 0.25 for p in parts]
+    assert np.array_equal(R.combine_images(ups, g["img"].shape, 4, 6), g["out"])
+
+
+def test_upscale_psnr_f10(golden):
+    g = golden("f10_upscale_psnr.npz")
+    f1 = golden("f1_m2b2_forward.npz")
+    sd = _tsd(f1)
+    with torch.no_grad():
+        up = T.forward(sd, torch.from_numpy(g["lr"])[None], [2, 2])[0].numpy()
+    np.testing.assert_allclose(up, g["up"], rtol=0, atol=2e-4)
+    o8 = R.image_to_uint8(up)
+    assert abs(R.image_psnr(o8, R.image_to_uint8(g["hr"])) - float(g["psnr"])) < 1e-3
