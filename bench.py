@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: HR Mpixels/s of the LarvaNet x4 multi-exit TRAINING step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A step = one pass of the hot path over one synthetic batch per GPU: head conv, 4 bodies x 4
+residual blocks, 4 pixel-shuffle exits, 4 L1 losses, full backward (dgrad + wgrad + bias grads),
+gradient all-reduce over RCCL when N > 1, AdamW -- i.e. train_step_larva (models/LarvaNet.py:98-114
+of the reference) at the BASELINE configuration: 16 x 3 x 48 x 48 fp32 patches per GPU -> 16 x 3 x
+192 x 192, `--num_modules=4 --num_blocks=4,4,4,4`, 48 channels (the only channel count the
+reference can express).  value = N * 16 * 192 * 192 / t_step (pixels counted once).
+
+The JSON line also carries
+  roofline      fp32-MFMA roofline of the dominant kernel (fused conv3x3+ReLU, 48->48, 16x48x48),
+                timed live with events on the launch stream
+  cpu_baseline  the same training step in the torch CPU restatement (oracle/, kind "port") on the
+                host cores of this box, bounded sample
+  infer         inference-forward throughput (LarvaNetModule.forward) as extra information
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+BATCH, PATCH, SCALE, CH = 16, 48, 4, 48
+BLOCKS = [4, 4, 4, 4]
+HR_PIX_PER_BATCH = BATCH * (PATCH * SCALE) ** 2          # 589 824
+CONV_FLOP = 2 * 9 * CH * CH * BATCH * PATCH * PATCH      # 1.5288 GFLOP per 48->48 layer
+FP32_MFMA_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: Peak FP32 (matrix)
+
+
+class TinyValLoader:
+    """train_step_larva validates once at global_step == 1 (models/LarvaNet.py:116-117); that
+    happens inside the warm-up steps.  One small synthetic pair is enough."""
+
+    def get_num_images(self):
+        return 1
+
+    def get_image_pair(self, image_index, scale):
+        rng = np.random.RandomState(3)
+        return (rng.randint(0, 256, (3, 24, 24)).astype(np.float32),
+                rng.randint(0, 256, (3, 96, 96)).astype(np.float32), "synthetic")
+
+
+def barrier_sync(dist_on):
+    import torch.distributed as td
+    if dist_on:
+        td.barrier()
+    torch.cuda.synchronize()
+
+
+def time_dominant_kernel(dev, iters=30):
+    """Average duration of the fused conv3x3+ReLU kernel at 16x48x48x48, one event pair per launch
+    on the launch stream (torch's current stream is the stream the C ABI launches on)."""
+    from larvanet_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 20).to(dev)
+    w = (torch.randn(CH, CH, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.zeros(CH, device=dev)
+    fwd, _ = K.pack_weights(w)
+    out = torch.empty_like(x)
+    for _ in range(5):
+        K.conv3x3(x, fwd, CH, bias=b, relu=True, out=out)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in evs:
+        s.record()
+        K.conv3x3(x, fwd, CH, bias=b, relu=True, out=out)
+        e.record()
+    torch.cuda.synchronize()
+    ms = sorted(s.elapsed_time(e) for s, e in evs)
+    return float(np.mean(ms)), float(ms[len(ms) // 2])
+
+
+def cpu_baseline(budget_s=15.0):
+    """The reference CPU path (torch CPU operators, all host cores) on the same workload."""
+    from oracle import larva_torch as T
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = T.init_state_dict(BLOCKS, seed=0)
+    x = torch.rand(BATCH, 3, PATCH, PATCH, generator=torch.Generator().manual_seed(0)) * 255
+    truth = torch.rand(BATCH, 3, PATCH * SCALE, PATCH * SCALE, generator=torch.Generator().manual_seed(1)) * 255
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=4e-4)
+
+    def step():
+        loss = T.multi_exit_loss(params, x, truth, BLOCKS)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    step()  # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 50):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": HR_PIX_PER_BATCH / med / 1e6, "unit": "HR Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps (median %.1f ms) of the same M4B4 batch-16 workload, torch %s CPU ops, %d threads"
+                      % (len(times), med * 1e3, torch.__version__, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-loss", action="store_true",
+                    help="return loss.item() every step like the reference (host sync per step)")
+    a = ap.parse_args()
+
+    from larvanet_amd import dist as ldist
+    rank, world = ldist.init_from_env()
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % a.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import importlib
+    model = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
+    model.parse_args(["--num_modules=4", "--num_blocks=4,4,4,4"])
+    torch.manual_seed(0)
+    model.volume_per_step = PATCH * PATCH * BATCH * 3 * world
+    model.prepare(is_training=True, scales=[SCALE])
+    model.sync_loss = bool(a.sync_loss)
+
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = (torch.rand(BATCH, 3, PATCH, PATCH, generator=g) * 255).to(dev)
+    truth = (torch.rand(BATCH, 3, PATCH * SCALE, PATCH * SCALE, generator=g) * 255).to(dev)
+    args = types.SimpleNamespace(train_path="/tmp")
+    val = TinyValLoader()
+
+    for _ in range(max(a.warmup, 1)):
+        model.train_step_larva(args, val, x, truth)
+    barrier_sync(world > 1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = model.train_step_larva(args, val, x, truth)
+    barrier_sync(world > 1)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as td
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = world * HR_PIX_PER_BATCH / (ms_per_step * 1e-3) / 1e6
+
+    if rank != 0:
+        return
+
+    # inference forward (extra information)
+    with torch.no_grad():
+        for _ in range(5):
+            model.model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            model.model(x)
+        torch.cuda.synchronize()
+        infer_ms = (time.perf_counter() - t0) / 20 * 1e3
+
+    k_mean_ms, k_med_ms = time_dominant_kernel(dev)
+    achieved = CONV_FLOP / (k_mean_ms * 1e-3) / 1e12
+    line = {
+        "metric": "HR Mpixels/s (LarvaNet x4 multi-exit train step, 48x48 LR patches)",
+        "value": value, "unit": "HR Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LarvaNet x4 train_step_larva, num_modules=4 num_blocks=4,4,4,4, 48 channels "
+                               "(BASELINE config 2 at the reference's only channel count), batch 16 x 3x48x48 "
+                               "-> 3x192x192 per GPU, fp32",
+                   "global_batch": BATCH * world, "parallelism": "dp%d" % world,
+                   "loss_sync_per_step": bool(a.sync_loss), "final_loss": float(loss)},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "conv3x3_mfma_kernel<48,vec,relu> 16x48x48x48", "flop_per_launch": CONV_FLOP,
+                     "avg_ms": k_mean_ms, "median_ms": k_med_ms},
+        "infer": {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
+                  "unit": "HR Mpixels/s"},
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

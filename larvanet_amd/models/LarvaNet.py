@@ -169,6 +169,7 @@ class LarvaNet(BaseModel):
     def __init__(self):
         super().__init__()
         self.volume_per_step = 0
+        self.sync_loss = True
 
     # ------------------------------------------------------------------ flags
     def _add_args(self, parser):
@@ -260,7 +261,9 @@ class LarvaNet(BaseModel):
             if summary is not None:
                 self._write_summary(summary, loss, input_tensor, out, truth_tensor)
 
-        return loss.item()
+        # the reference returns loss.item() (a host sync every step, models/LarvaNet.py:139);
+        # sync_loss=False hands back the 0-d device tensor instead so the host can run ahead
+        return loss.item() if self.sync_loss else loss.detach()
 
     def _write_summary(self, summary, loss, input_tensor, out, truth_tensor):
         summary.add_scalar("loss", loss, self.global_step)

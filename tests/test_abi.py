@@ -1,0 +1,55 @@
+"""The C-ABI library loads on a machine without a GPU and exports exactly what include/larva_hip.h
+declares (no compute calls here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "larva_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(larva_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared()
+    for must in ("larva_conv3x3_fwd", "larva_conv3x3_wgrad", "larva_pack_weights", "larva_bicubic4_fwd",
+                 "larva_l1_fwd", "larva_l1_bwd", "larva_pixel_unshuffle4", "larva_adamw_step"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from larvanet_amd import hip_lib
+    if not os.path.exists(hip_lib.LIB_PATH):
+        from larvanet_amd.build import build_extension
+        build_extension(verbose=False)
+    lib = hip_lib.load()
+    declared = _declared()
+    assert sorted(hip_lib.SIGNATURES) == declared  # binding table and header agree
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.larva_abi_version() == 1
+    # pure host-side size helpers need no device
+    assert lib.larva_packed_weight_floats(48, 48) == 3 * 9 * 16 * 48
+    assert lib.larva_packed_weight_floats(64, 64) == 4 * 9 * 16 * 80
+    assert lib.larva_wgrad_partial_floats(48, 48, 2) == 2 * (27 * 3 * 256 + 48)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from larvanet_amd import hip_lib
+    monkeypatch.setattr(hip_lib, "_lib", None)
+    monkeypatch.setattr(hip_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        hip_lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "larvanet_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(d, f)

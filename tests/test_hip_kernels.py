@@ -1,0 +1,292 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against the oracle, on a real MI355X.
+
+Tolerances: conv outputs are sums of K = 9*Cin products of O(100)-scale activations with
+O(0.01) weights; fp32 MFMA is an exact fma chain, so the only difference from the double-
+accumulating C oracle is fp32 summation order: |err| <= ~K * 2^-24 * sum|a*b|.  We assert a
+relative-to-scale bound of 2e-5 (measured errors are ~1e-6).  Index layouts (pixel shuffle /
+unshuffle) are asserted bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_err(got, ref):
+    scale = max(1.0, float(np.abs(ref).max()))
+    return float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) / scale
+
+
+def _report(name, got, ref, tol):
+    err = _rel_err(got, ref)
+    if not err <= tol:
+        bad = np.argwhere(np.abs(got - ref) > tol * max(1.0, float(np.abs(ref).max())))
+        raise AssertionError("%s: max rel-to-scale err %.3e > %.1e; %d bad; first bad idx %s got %r ref %r" % (
+            name, err, tol, len(bad), bad[:4].tolist(),
+            [float(got[tuple(b)]) for b in bad[:4]], [float(ref[tuple(b)]) for b in bad[:4]]))
+
+
+def _rand(rng, shape, scale):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+def _dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 48, 9, 48), (1, 48, 7, 50), (1, 48, 5, 13), (2, 32, 6, 48), (1, 64, 6, 52),
+                                     (1, 48, 3, 100)])
+@pytest.mark.parametrize("epi", ["plain", "relu", "res1", "res2", "mask"])
+def test_conv3x3_epilogues(hip_device, N, C, H, W, epi):
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(N * 100003 + C * 1009 + H * 101 + W * 7 + len(epi))
+    x = _rand(rng, (N, C, H, W), 20.0)
+    w = _rand(rng, (C, C, 3, 3), 0.05)
+    b = _rand(rng, (C,), 1.0)
+    r0 = _rand(rng, (N, C, H, W), 20.0)
+    r1 = _rand(rng, (N, C, H, W), 20.0)
+    m = _rand(rng, (N, C, H, W), 1.0)
+    ref = R.conv3x3(x, w, b)
+    kw = {}
+    if epi == "relu":
+        ref = np.maximum(ref, 0)
+        kw["relu"] = True
+    elif epi == "res1":
+        ref = ref + r0
+        kw["res0"] = _dev(r0, hip_device)
+    elif epi == "res2":
+        ref = (ref + r0) + r1
+        kw["res0"], kw["res1"] = _dev(r0, hip_device), _dev(r1, hip_device)
+    elif epi == "mask":
+        ref = np.where(m > 0, ref, 0).astype(np.float32)
+        kw["mask"] = _dev(m, hip_device)
+    wd = _dev(w, hip_device)
+    fwd, bwd = K.pack_weights(wd)
+    out = K.conv3x3(_dev(x, hip_device), fwd, C, bias=_dev(b, hip_device), **kw)
+    torch.cuda.synchronize()
+    _report("conv3x3[%s]" % epi, out.cpu().numpy(), ref, 2e-5)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 6, 48), (1, 5, 20), (1, 4, 49)])
+@pytest.mark.parametrize("with_base", [True, False])
+def test_conv3x3_pixel_shuffle_tail(hip_device, N, H, W, with_base):
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(N * 1000 + H * 10 + W)
+    x = _rand(rng, (N, 48, H, W), 20.0)
+    w = _rand(rng, (48, 48, 3, 3), 0.05)
+    b = _rand(rng, (48,), 1.0)
+    base = _rand(rng, (N, 3, 4 * H, 4 * W), 50.0)
+    ref = R.pixel_shuffle(R.conv3x3(x, w, b), 4)
+    if with_base:
+        ref = ref + base
+    fwd, _ = K.pack_weights(_dev(w, hip_device))
+    out = K.conv3x3(_dev(x, hip_device), fwd, 48, bias=_dev(b, hip_device), shuffle=True,
+                    base=_dev(base, hip_device) if with_base else None)
+    torch.cuda.synchronize()
+    _report("tail", out.cpu().numpy(), ref, 2e-5)
+
+
+def test_pixel_shuffle_store_is_bit_exact_index_map(hip_device, golden):
+    """Identity-like conv (centre tap = 1 on the diagonal) turns the tail kernel into a pure
+    PixelShuffle(4): the integer fixture F3 from the reference must come out bit for bit."""
+    from larvanet_amd import kernels as K
+    g = golden("f3_pixel_shuffle.npz")
+    inp = g["inp"].astype(np.float32)  # integers < 2^24: exact in fp32
+    w = np.zeros((48, 48, 3, 3), np.float32)
+    for c in range(48):
+        w[c, c, 1, 1] = 1.0
+    fwd, _ = K.pack_weights(_dev(w, hip_device))
+    out = K.conv3x3(_dev(inp, hip_device), fwd, 48, shuffle=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().astype(np.int32), g["out"])
+    back = K.pixel_unshuffle4(out)
+    torch.cuda.synchronize()
+    assert np.array_equal(back.cpu().numpy().astype(np.int32), g["inp"])
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 48, 9, 48), (1, 48, 5, 13), (1, 32, 6, 48), (1, 64, 6, 52)])
+def test_conv3x3_dgrad(hip_device, N, C, H, W):
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(N + C + H + W)
+    dy = _rand(rng, (N, C, H, W), 1e-3)
+    w = _rand(rng, (C, C, 3, 3), 0.05)
+    ref = R.conv3x3_dgrad(dy, w)
+    _, bwd = K.pack_weights(_dev(w, hip_device))
+    out = K.conv3x3(_dev(dy, hip_device), bwd, C)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    err = float(np.abs(got - ref).max()) / float(np.abs(ref).max())
+    assert err < 2e-5, err
+
+
+def test_multi_source_concat_conv(hip_device):
+    """torch.cat(features, 1) + merge_conv (models/LarvaNetV2.py:328-330) without the concat."""
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(9)
+    feats = [_rand(rng, (2, 48, 6, 48), 20.0) for _ in range(3)]
+    w = _rand(rng, (48, 144, 3, 3), 0.03)
+    b = _rand(rng, (48,), 1.0)
+    ref = R.conv3x3(np.concatenate(feats, 1), w, b)
+    fwd, _ = K.pack_weights(_dev(w, hip_device), want_bwd=False)
+    out = K.conv3x3([_dev(f, hip_device) for f in feats], fwd, 48, bias=_dev(b, hip_device))
+    torch.cuda.synchronize()
+    _report("merge", out.cpu().numpy(), ref, 2e-5)
+    # per-source dgrad slices
+    dy = _rand(rng, (2, 48, 6, 48), 1e-3)
+    full = R.conv3x3_dgrad(dy, w)
+    for i in range(3):
+        _, bwd = K.pack_weights(_dev(w, hip_device), cin_off=48 * i, cin=48)
+        d = K.conv3x3(_dev(dy, hip_device), bwd, 48)
+        torch.cuda.synchronize()
+        r = full[:, 48 * i:48 * i + 48]
+        assert float(np.abs(d.cpu().numpy() - r).max()) / float(np.abs(r).max()) < 2e-5
+
+
+@pytest.mark.parametrize("N,Cout,Cin,H,W,splits", [(2, 48, 48, 9, 48, 4), (1, 48, 48, 5, 13, 1), (3, 48, 48, 7, 50, 7),
+                                                   (2, 32, 32, 6, 48, 3), (1, 64, 64, 6, 52, 2), (2, 48, 16, 6, 48, 4)])
+def test_conv3x3_wgrad(hip_device, N, Cout, Cin, H, W, splits):
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(N * 7 + Cout + Cin + H + W)
+    dy = _rand(rng, (N, Cout, H, W), 1e-3)
+    x = _rand(rng, (N, Cin, H, W), 20.0)
+    cin_valid = 3 if Cin == 16 else Cin
+    if Cin == 16:
+        x[:, 3:] = 0
+    dw_ref, db_ref = R.conv3x3_wgrad(dy, x[:, :cin_valid])
+    dw = torch.full((Cout, cin_valid, 3, 3), float("nan"), device=hip_device)
+    db = torch.full((Cout,), float("nan"), device=hip_device)
+    K.conv3x3_wgrad([{"dy": _dev(dy, hip_device), "x": _dev(x, hip_device), "dw": dw, "db": db,
+                      "cin_off": 0, "cin_valid": cin_valid}], Cout, Cin, splits)
+    torch.cuda.synchronize()
+    _report("dw", dw.cpu().numpy(), dw_ref, 3e-5)
+    _report("db", db.cpu().numpy(), db_ref, 3e-5)
+
+
+def test_wgrad_batched_jobs_and_slices(hip_device):
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(77)
+    jobs, refs = [], []
+    dw_wide = torch.zeros((48, 96, 3, 3), device=hip_device)
+    for i in range(3):
+        dy = _rand(rng, (2, 48, 6, 48), 1e-3)
+        x = _rand(rng, (2, 48, 6, 48), 20.0)
+        refs.append(R.conv3x3_wgrad(dy, x))
+        if i < 2:  # two jobs write channel slices of one wide gradient (merge conv)
+            jobs.append({"dy": _dev(dy, hip_device), "x": _dev(x, hip_device), "dw": dw_wide,
+                         "db": torch.empty(48, device=hip_device), "cin_off": 48 * i, "cin_valid": 48})
+        else:
+            jobs.append({"dy": _dev(dy, hip_device), "x": _dev(x, hip_device),
+                         "dw": torch.empty((48, 48, 3, 3), device=hip_device), "db": torch.empty(48, device=hip_device)})
+    K.conv3x3_wgrad(jobs, 48, 48, 5)
+    torch.cuda.synchronize()
+    wide = dw_wide.cpu().numpy()
+    _report("slice0", wide[:, :48], refs[0][0], 3e-5)
+    _report("slice1", wide[:, 48:], refs[1][0], 3e-5)
+    _report("job2", jobs[2]["dw"].cpu().numpy(), refs[2][0], 3e-5)
+    _report("job2.db", jobs[2]["db"].cpu().numpy(), refs[2][1], 3e-5)
+
+
+def test_wgrad_is_deterministic(hip_device):
+    from larvanet_amd import kernels as K
+    rng = np.random.default_rng(5)
+    dy = _dev(_rand(rng, (4, 48, 12, 48), 1e-3), hip_device)
+    x = _dev(_rand(rng, (4, 48, 12, 48), 20.0), hip_device)
+    outs = []
+    for _ in range(2):
+        dw = torch.empty((48, 48, 3, 3), device=hip_device)
+        K.conv3x3_wgrad([{"dy": dy, "x": x, "dw": dw, "db": None}], 48, 48, 16)
+        torch.cuda.synchronize()
+        outs.append(dw.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_bicubic4(hip_device, golden):
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    g = golden("f4_bicubic.npz")
+    out = K.bicubic4(_dev(g["inp"], hip_device))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-5, atol=3e-4)
+    rng = np.random.default_rng(3)
+    x = (rng.random((2, 3, 17, 23)) * 255).astype(np.float32)
+    out = K.bicubic4(_dev(x, hip_device))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), R.bicubic_up(x, 4), rtol=1e-5, atol=3e-4)
+
+
+@pytest.mark.parametrize("numel_shape", [(2, 3, 16, 20), (1, 3, 7, 9), (16, 3, 192, 192)])
+def test_l1_forward_backward(hip_device, numel_shape):
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(11)
+    a = (rng.random(numel_shape) * 255).astype(np.float32)
+    b = (rng.random(numel_shape) * 255).astype(np.float32)
+    b.ravel()[::7] = a.ravel()[::7]  # exact ties: sign(0) = 0
+    ad, bd = _dev(a, hip_device), _dev(b, hip_device)
+    loss = K.l1_fwd(ad, bd)
+    g = torch.tensor(0.25, device=hip_device)
+    ga = K.l1_bwd(ad, bd, g)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - R.l1_mean(a, b)) < 2e-6 * R.l1_mean(a, b) + 1e-6
+    assert np.array_equal(ga.cpu().numpy(), R.l1_grad(a, b, 0.25))
+
+
+def test_adamw_flat(hip_device):
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(2)
+    n = 100003
+    p = rng.standard_normal(n).astype(np.float32) * 0.05
+    g = rng.standard_normal(n).astype(np.float32) * 1e-3
+    pd, md, vd = _dev(p, hip_device), torch.zeros(n, device=hip_device), torch.zeros(n, device=hip_device)
+    pr, mr, vr = p.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for step in (1, 2, 3):
+        sl = torch.tensor([float(step), 4e-4], device=hip_device)
+        K.adamw_step(pd, _dev(g * step, hip_device), md, vd, sl, 0.9, 0.999, 1e-8, 0.01)
+        pr, mr, vr = R.adamw(pr, g * step, mr, vr, step)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(vd.cpu().numpy(), vr, rtol=2e-6, atol=1e-12)
+
+
+def test_canonical_layer_properties(hip_device):
+    """BASELINE size (16x48x48x48): linearity in the input and agreement with the torch CPU
+    operator on a sample -- size-independent checks where the C oracle would take too long."""
+    from larvanet_amd import kernels as K
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(0)
+    x1 = torch.randn(16, 48, 48, 48, generator=gen) * 20
+    x2 = torch.randn(16, 48, 48, 48, generator=gen) * 20
+    w = torch.randn(48, 48, 3, 3, generator=gen) * 0.05
+    fwd, _ = K.pack_weights(w.to(hip_device))
+    y1 = K.conv3x3(x1.to(hip_device), fwd, 48)
+    y2 = K.conv3x3(x2.to(hip_device), fwd, 48)
+    y12 = K.conv3x3((x1 + x2).to(hip_device), fwd, 48)
+    torch.cuda.synchronize()
+    lin = float((y12 - (y1 + y2)).abs().max()) / float(y12.abs().max())
+    assert lin < 1e-5, lin
+    ref = F.conv2d(x1, w, padding=1)
+    err = float((y1.cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1e-5, err
+
+
+def test_invalid_arguments_are_rejected(hip_device):
+    from larvanet_amd import kernels as K
+    x = torch.zeros(1, 48, 4, 4, device=hip_device)
+    w = torch.zeros(48, 48, 3, 3, device=hip_device)
+    fwd, _ = K.pack_weights(w)
+    with pytest.raises(RuntimeError):
+        K.conv3x3(x.cpu(), fwd, 48)  # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        K.conv3x3(x, fwd, 40)  # unsupported channel count
+    with pytest.raises(RuntimeError):
+        K.conv3x3(x, fwd, 48, relu=True, res0=x)  # fusion that is not compiled
+    with pytest.raises(RuntimeError):
+        K.conv3x3(x[:, :, :, ::2], fwd, 48)  # non-contiguous
