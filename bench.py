@@ -82,14 +82,34 @@ def time_dominant_kernel(dev, iters=30):
     return float(np.mean(ms)), float(ms[len(ms) // 2])
 
 
-def cpu_baseline(budget_s=15.0):
-    """The reference CPU path (torch CPU operators, all host cores) on the same workload."""
-    from oracle import larva_torch as T
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (a GPU
+    box hands each job a share of a large host; 256 threads on a 16-CPU share thrash)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    cores = min(cores, max(1, q // period))
+        except Exception:
+            continue
+    return min(cores, int(os.environ.get("LARVA_CPU_BASELINE_THREADS", "32")))
+
+
+def cpu_baseline(budget_s=15.0):
+    """The reference CPU path (torch CPU operators, all host cores) on the same workload."""
+    from oracle import larva_torch as T
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = T.init_state_dict(BLOCKS, seed=0)
     x = torch.rand(BATCH, 3, PATCH, PATCH, generator=torch.Generator().manual_seed(0)) * 255

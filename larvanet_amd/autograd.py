@@ -31,11 +31,15 @@ class PackedConv:
     def invalidate(self):
         self._key = None
 
-    def get(self):
-        """-> list of (wpk_fwd, wpk_bwd) per slice (a single entry when slices is None)."""
+    def refresh(self):
+        """Called by the owning module's forward (outside autograd.Function, where the grad
+        mode is visible).  While training, the weights change every step and in-place optimizer
+        kernels do not reliably bump Tensor._version, so the images are rebuilt on every
+        grad-enabled forward; for inference they are cached until the storage or version moves
+        (load_state_dict / restore also call invalidate())."""
         w = self.weight
         key = (w.data_ptr(), w._version, str(w.device))
-        if key != self._key:
+        if key != self._key or (torch.is_grad_enabled() and w.requires_grad):
             with torch.no_grad():
                 if self.slices is None:
                     self._packs = [K.pack_weights(w.detach(), cin_pad=self.cin_pad, want_bwd=self.cin_pad is None)]
@@ -43,6 +47,12 @@ class PackedConv:
                     whole = K.pack_weights(w.detach(), want_bwd=False)[0]
                     self._packs = [(whole, None)] + [K.pack_weights(w.detach(), cin_off=o, cin=c) for (o, c) in self.slices]
             self._key = key
+        return self
+
+    def get(self):
+        """-> list of (wpk_fwd, wpk_bwd) per slice (a single entry when slices is None)."""
+        if self._packs is None:
+            self.refresh()
         return self._packs
 
 

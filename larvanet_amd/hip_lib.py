@@ -53,6 +53,9 @@ def load():
         raise RuntimeError(
             "larvanet_amd: %s is missing. Build it with `python -m larvanet_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback." % LIB_PATH)
+    # torch must own the process's HIP runtime: loading this library first would bring in a
+    # second libamdhip64 that later finds "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header and library disagree

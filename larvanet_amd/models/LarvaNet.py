@@ -82,6 +82,7 @@ class LarvaHead(nn.Module):
     def forward(self, x):
         _require_hip(x)
         c = self.feature_extraction
+        self._pc.refresh()
         return HeadFn.apply(x.contiguous(), c.weight, c.bias, self._pc)
 
 
@@ -101,6 +102,8 @@ class LarvaLeg(nn.Module):
     def forward(self, fea, base):
         _require_hip(fea)
         c1, c2 = self.recon_block[0], self.recon_block[2]
+        for pc in self._pcs:
+            pc.refresh()
         return LegFn.apply(fea.contiguous(), base.contiguous(), self._pcs, c1.weight, c1.bias, c2.weight, c2.bias)
 
 
@@ -123,6 +126,8 @@ class LarvaBody(nn.Module):
             params += [blk.body[0].weight, blk.body[0].bias, blk.body[2].weight, blk.body[2].bias]
         if not params:
             return x + x
+        for pc in self._pcs:
+            pc.refresh()
         return BodyFn.apply(x.contiguous(), self._pcs, *params)
 
 
@@ -144,6 +149,12 @@ class LarvaNetModule(nn.Module):
         self.head = LarvaHead()
         for i, nb in enumerate(parse_num_blocks(args)):
             setattr(self, "body_%d" % i, LarvaBody(num_blocks=nb))
+
+    def invalidate_packed_weights(self):
+        """Forget the kernel-layout weight images (call after changing weights behind torch's back)."""
+        for m in self.modules():
+            for pc in ([m._pc] if hasattr(m, "_pc") else []) + list(getattr(m, "_pcs", [])):
+                pc.invalidate()
 
     def base(self, x):
         """F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False) (models/LarvaNet.py:283-285)."""
@@ -318,6 +329,7 @@ class LarvaNet(BaseModel):
 
     def restore(self, ckpt_path, target=None):
         self.model.load_state_dict(torch.load(ckpt_path, map_location=self.device))
+        self.model.invalidate_packed_weights()
 
     def get_model(self):
         return self.model
