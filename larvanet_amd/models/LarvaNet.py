@@ -181,6 +181,7 @@ class LarvaNet(BaseModel):
         super().__init__()
         self.volume_per_step = 0
         self.sync_loss = True
+        self.use_hip_graph = os.environ.get("LARVA_HIP_GRAPH", "1") != "0"
 
     # ------------------------------------------------------------------ flags
     def _add_args(self, parser):
@@ -248,16 +249,52 @@ class LarvaNet(BaseModel):
             loss = loss + self.loss_fn(out, truth_tensor)
         return loss / self.args.num_modules, out
 
+    # hipGraph path: one step issues ~330 short kernels; launched one by one from Python the GPU
+    # idles between them, so forward + backward are captured once per batch shape and replayed.
+    def _graph_key(self, input_tensor, truth_tensor):
+        return (tuple(input_tensor.shape), tuple(truth_tensor.shape), str(input_tensor.device))
+
+    def _capture_step(self, input_tensor, truth_tensor):
+        self._static_in = input_tensor.clone()
+        self._static_truth = truth_tensor.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up outside capture (lazy kernel attributes, allocator pools)
+                self.optim.zero_grad(set_to_none=True)
+                loss, _ = self._exit_losses(self._static_in, self._static_truth)
+                loss.backward()
+        torch.cuda.current_stream().wait_stream(side)
+        self.optim.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss, out = self._exit_losses(self._static_in, self._static_truth)
+            loss.backward()
+        self._graph, self._graph_loss, self._graph_out = graph, loss, out
+        self._graph_shape = self._graph_key(input_tensor, truth_tensor)
+
+    def _forward_backward(self, input_tensor, truth_tensor):
+        """loss and gradients of one batch (models/LarvaNet.py:101-113)."""
+        if self.use_hip_graph and input_tensor.is_cuda:
+            if getattr(self, "_graph_shape", None) != self._graph_key(input_tensor, truth_tensor):
+                self._capture_step(input_tensor, truth_tensor)
+            self._static_in.copy_(input_tensor)
+            self._static_truth.copy_(truth_tensor)
+            self._graph.replay()  # gradients are overwritten in place: no zero_grad needed
+            return self._graph_loss, self._graph_out
+        loss, out = self._exit_losses(input_tensor, truth_tensor)
+        self.optim.zero_grad()
+        loss.backward()
+        return loss, out
+
     def train_step_larva(self, args, val_dataloader, input_tensor, truth_tensor, summary=None):
         self.global_step += 1
         self.temp_volume += self.volume_per_step
 
-        loss, out = self._exit_losses(input_tensor, truth_tensor)
-
-        self.optim.zero_grad()
-        loss.backward()
+        loss, out = self._forward_backward(input_tensor, truth_tensor)
         ldist.allreduce_gradients(self.model)  # mean over ranks; no-op for a single process
         self.optim.step()
+        self.model.invalidate_packed_weights()  # the kernel-layout weight images are now stale
 
         if self.global_step == 1:
             self.validate_for_train(args, val_dataloader)

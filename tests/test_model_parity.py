@@ -128,3 +128,20 @@ def test_save_restore_roundtrip(hip_device, tmp_path):
     m2.restore(path)
     x = np.random.RandomState(0).randint(0, 256, size=(3, 9, 11)).astype(np.float32)
     assert np.array_equal(m.upscale([x], 4), m2.upscale([x], 4))
+
+
+def test_hip_graph_replay_matches_eager_launches(hip_device):
+    """The captured forward+backward must be the same arithmetic as launching kernel by kernel."""
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand(2, 3, 12, 16, generator=g) * 255).to(hip_device)
+    t = (torch.rand(2, 3, 48, 64, generator=g) * 255).to(hip_device)
+    args = types.SimpleNamespace(train_path="/tmp")
+    results = []
+    for use_graph in (False, True):
+        m = _model("LarvaNet", ["--num_modules=2", "--num_blocks=2,1"], training=True, seed=5)
+        m.use_hip_graph = use_graph
+        losses = [m.train_step_larva(args, FakeValLoader(7), x, t) for _ in range(4)]
+        results.append((losses, {k: v.cpu().numpy().copy() for k, v in m.model.state_dict().items()}))
+    assert results[0][0] == results[1][0]
+    for k in results[0][1]:
+        assert np.array_equal(results[0][1][k], results[1][1][k]), k
