@@ -84,3 +84,12 @@ def seed_for_rank(base_seed):
     """Distinct patch streams per rank (the reference draws from the un-seeded global numpy RNG,
     dataloaders/div2k_train_loader.py:63,79-80,87,92: identical streams under naive replication)."""
     return int(base_seed) + 1000 * rank()
+
+
+def gather_objects(obj):
+    """All ranks' python objects, in rank order, on every rank."""
+    if world_size() == 1:
+        return [obj]
+    out = [None] * world_size()
+    td.all_gather_object(out, obj)
+    return out

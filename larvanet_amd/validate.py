@@ -1,0 +1,99 @@
+"""Validation driver: counterpart of the reference's validate.py (full-image upscale, uint8
+round/clip, RGB PSNR, per-image wall time).  Under torchrun image i goes to rank i mod world and
+the per-image PSNR / duration are gathered (images are independent units).
+
+    python -m larvanet_amd.validate --model=LarvaNet --num_modules=4 --num_blocks=4,4,4,4 \\
+        --restore_path=model.pth --val_input_path=... --val_truth_path=... [--chop_forward] [--save_path=out]
+"""
+import argparse
+import importlib
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import dist as ldist
+from . import image_utils
+from .metrics import fit_truth_image_size, image_psnr, image_to_uint8
+
+
+def save_png(image_chw_uint8, path):
+    from PIL import Image
+    Image.fromarray(np.transpose(image_chw_uint8, [1, 2, 0])).save(path)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--dataloader", type=str, default="div2k_val_loader")
+    p.add_argument("--model", type=str, default="LarvaNet")
+    p.add_argument("--scales", type=str, default="4")
+    p.add_argument("--cuda_device", type=str, default=None)
+    p.add_argument("--restore_path", type=str, default=None,
+                   help="checkpoint (bare state_dict); omitted = freshly initialised weights")
+    p.add_argument("--restore_target", type=str)
+    p.add_argument("--restore_global_step", type=int, default=0)
+    p.add_argument("--save_path", type=str)
+    p.add_argument("--chop_forward", action="store_true")
+    p.add_argument("--chop_overlap_size", type=int, default=20)
+    return p
+
+
+def main(argv=None):
+    args, remaining = build_parser().parse_known_args(argv)
+    if args.cuda_device is not None and "LOCAL_RANK" not in os.environ:
+        os.environ["HIP_VISIBLE_DEVICES"] = args.cuda_device
+    rank, world = ldist.init_from_env()
+    scales = [int(s) for s in args.scales.split(",")]
+
+    print("prepare data loader - %s" % args.dataloader)
+    loader = importlib.import_module("larvanet_amd.dataloaders." + args.dataloader).create_loader()
+    _, remaining = loader.parse_args(remaining)
+    loader.prepare(scales=scales)
+
+    print("prepare model - %s" % args.model)
+    model = importlib.import_module("larvanet_amd.models." + args.model).create_model()
+    _, remaining = model.parse_args(remaining)
+    model.prepare(is_training=False, scales=scales, global_step=args.restore_global_step)
+    if remaining:
+        print("WARNING: found unhandled arguments: %s" % remaining)
+    if args.restore_path is not None:
+        model.restore(ckpt_path=args.restore_path, target=args.restore_target)
+        print("restored the model")
+
+    print("begin validation")
+    results = {}
+    num_images = loader.get_num_images()
+    for scale in scales:
+        mine = []
+        with torch.no_grad():
+            for index in range(rank, num_images, world):
+                lr, hr, name = loader.get_image_pair(image_index=index, scale=scale)
+                t0 = time.perf_counter()
+                if args.chop_forward:
+                    out = image_utils.upscale_with_chop_forward(model=model, input_image=lr, scale=scale,
+                                                                overlap_size=args.chop_overlap_size)
+                else:
+                    out = model.upscale(input_list=[lr], scale=scale)[0]
+                duration = time.perf_counter() - t0
+                out8 = image_to_uint8(out)
+                if args.save_path is not None:
+                    os.makedirs(os.path.join(args.save_path, "x%d" % scale), exist_ok=True)
+                    save_png(out8, os.path.join(args.save_path, "x%d" % scale, name + ".png"))
+                truth8 = fit_truth_image_size(output_image=out8, truth_image=image_to_uint8(hr))
+                psnr = float(image_psnr(output_image=out8, truth_image=truth8))
+                mine.append((index, psnr, duration))
+                print("x%d, %d/%d, psnr=%.2f, duration=%.4f" % (scale, index + 1, num_images, psnr, duration))
+        rows = ldist.gather_objects(mine)
+        rows = sorted(r for part in rows for r in part)
+        results[scale] = {"psnr": float(np.mean([r[1] for r in rows])) if rows else float("nan"),
+                          "duration": float(np.mean([r[2] for r in rows])) if rows else float("nan"),
+                          "per_image": rows}
+        if rank == 0:
+            print("x%d, psnr=%.2f, duration=%.4f" % (scale, results[scale]["psnr"], results[scale]["duration"]))
+    print("finished")
+    return results
+
+
+if __name__ == "__main__":
+    main()

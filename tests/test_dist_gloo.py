@@ -1,0 +1,89 @@
+"""The data-parallel host logic on 2 CPU processes over gloo: flat-bucket gradient mean, weight
+broadcast, PSNR all-reduce, per-rank patch streams, validation sharding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import torch.distributed as td
+    from larvanet_amd import dist as ldist
+    r, w = ldist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and ldist.is_main() == (rank == 0)
+    torch.manual_seed(100 + rank)  # ranks start from different weights
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 2, 3))
+    ldist.broadcast_parameters(net)
+    w0 = torch.cat([p.detach().flatten() for p in net.parameters()])
+    for i, p in enumerate(net.parameters()):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    ldist.allreduce_gradients(net)
+    grads = [float(p.grad.flatten()[0]) for p in net.parameters()]
+    psnr_sum = ldist.allreduce_scalar_sum(10.0 + rank, torch.device("cpu"))
+    gathered = ldist.gather_objects([(rank, rank * 2.0)])
+
+    # validation sharding: rank r scores images r, r+world, ...; every rank steps its scheduler with the same mean
+    from larvanet_amd.models import LarvaNet as L
+    m = L.create_model()
+    m.parse_args(["--num_modules=1", "--num_blocks=1"])
+    m.prepare(is_training=True, scales=[4])
+    seen = []
+
+    def fake_upscale(input_list, scale):
+        seen.append(int(input_list[0][0, 0, 0]))
+        return np.repeat(np.repeat(np.asarray(input_list, np.float32), 4, axis=2), 4, axis=3)
+
+    m.upscale = fake_upscale
+
+    class Val:
+        def get_num_images(self):
+            return 5
+
+        def get_image_pair(self, image_index, scale):
+            lr = np.full((3, 4, 4), image_index, np.float32)
+            hr = np.full((3, 16, 16), image_index + 1 + image_index % 2, np.float32)
+            return lr, hr, str(image_index)
+
+    avg = m.validate_for_train(None, Val())
+    from larvanet_amd.dataloaders import synthetic_loader
+    ld = synthetic_loader.create_loader()
+    ld.parse_args(["--synthetic_images=4", "--synthetic_lr_size=24"])
+    ld.prepare([4])
+    first_patch = ld.get_patch_batch(1, 4, 12)[0][0]
+    q.put((rank, w0.numpy(), grads, psnr_sum, gathered, seen, float(avg), float(np.asarray(first_patch).sum())))
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, w0, g0, s0, ga0, seen0, avg0, patch0), (r1, w1, g1, s1, ga1, seen1, avg1, patch1) = out
+    assert np.array_equal(w0, w1)                       # broadcast from rank 0
+    assert g0 == g1 == [1.5 * (i + 1) for i in range(4)]  # mean of (1, 2) x (i+1)
+    assert s0 == s1 == 21.0
+    assert ga0 == ga1 == [[(0, 0.0)], [(1, 2.0)]]
+    assert seen0 == [0, 2, 4] and seen1 == [1, 3]        # image i -> rank i mod world
+    assert avg0 == avg1                                  # identical scheduler input on every rank
+    assert patch0 != patch1                              # per-rank patch streams

@@ -1,0 +1,31 @@
+"""End-to-end drivers on the GPU: a few training steps with validation + checkpoint, then the
+validation driver (plain and chop-forward) on that checkpoint."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_then_validate(hip_device, tmp_path, capsys):
+    from larvanet_amd import train_larva, validate
+    vol = 12 * 12 * 4 * 3
+    model = train_larva.main([
+        "--model=LarvaNet", "--dataloader=synthetic_loader", "--val_dataloader=synthetic_loader",
+        "--train_path", str(tmp_path), "--max_steps=5", "--batch_size=4", "--input_patch_size=12",
+        "--num_modules=2", "--num_blocks=1,1", "--synthetic_images=3", "--synthetic_lr_size=20",
+        "--val_volume=%d" % (2 * vol)])
+    out = capsys.readouterr().out
+    assert model.global_step == 5
+    assert out.count("begin validation") == 3  # step 1, then every 2 steps of volume (steps 2 and 4)
+    ckpts = sorted(glob.glob(os.path.join(str(tmp_path), "model_step*_vol*.pth")))
+    assert len(ckpts) == 2 and os.path.basename(ckpts[0]).startswith("model_step2_")
+    common = ["--model=LarvaNet", "--dataloader=synthetic_loader", "--num_modules=2", "--num_blocks=1,1",
+              "--synthetic_images=3", "--synthetic_lr_size=20", "--synthetic_uint8", "--restore_path", ckpts[-1]]
+    plain = validate.main(common + ["--save_path", str(tmp_path / "sr")])
+    assert np.isfinite(plain[4]["psnr"]) and len(plain[4]["per_image"]) == 3
+    assert len(glob.glob(os.path.join(str(tmp_path), "sr", "x4", "*.png"))) == 3
+    chop = validate.main(common + ["--chop_forward", "--chop_overlap_size=8"])
+    assert np.isfinite(chop[4]["psnr"]) and abs(chop[4]["psnr"] - plain[4]["psnr"]) < 1.0

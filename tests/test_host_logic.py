@@ -1,0 +1,184 @@
+"""Host-side logic of the plugin surface, loaders and drivers (CPU only, no kernels run)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+
+def _make(name, argv, training=True):
+    import importlib
+    m = importlib.import_module("larvanet_amd.models." + name).create_model()
+    parsed, rest = m.parse_args(argv)
+    return m, parsed, rest
+
+
+def test_parse_args_chaining_returns_copy_and_leftovers():
+    m, parsed, rest = _make("LarvaNet", ["--num_modules=4", "--num_blocks=4,4,4,4", "--foo=1", "--lr=1e-3"])
+    assert rest == ["--foo=1"] and parsed.lr == 1e-3 and parsed.num_modules == 4
+    parsed.lr = 5.0
+    assert m.args.lr == 1e-3  # deep copy, like the reference (models/LarvaNet.py:65-66)
+    assert m.args.val_volume == 30e9 and m.args.cooldown == 6 and m.args.min_lr == 1e-8
+    m2, p2, _ = _make("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,1"])
+    assert p2.val_volume == 3e9 and p2.lr == 1e-4 and p2.min_lr == 1e-7 and not hasattr(p2, "cooldown")
+
+
+def test_prepare_validates_scales_and_block_list():
+    m, _, _ = _make("LarvaNet", ["--num_modules=2", "--num_blocks=2,2"])
+    with pytest.raises(ValueError):
+        m.prepare(is_training=False, scales=[5])
+    with pytest.raises(ValueError):
+        m.prepare(is_training=False, scales=[2, 4])
+    bad, _, _ = _make("LarvaNet", ["--num_modules=3", "--num_blocks=2,2"])
+    with pytest.raises(GeneratorExit):
+        bad.prepare(is_training=False, scales=[4])
+
+
+def test_state_dict_keys_are_the_reference_wire_format():
+    m, _, _ = _make("LarvaNet", ["--num_modules=4", "--num_blocks=4,4,4,4"])
+    m.prepare(is_training=True, scales=[4])
+    sd = m.model.state_dict()
+    assert len(sd) == 82 and sum(v.numel() for v in sd.values()) == 832704
+    assert "head.feature_extraction.weight" in sd and "body_3.res_blocks.3.body.2.bias" in sd
+    assert "body_0.leg.recon_block.0.weight" in sd and tuple(sd["head.feature_extraction.weight"].shape) == (48, 3, 3, 3)
+    assert isinstance(m.optim, torch.optim.AdamW) and m.get_lr() == 4e-4
+    assert m.optim.defaults["weight_decay"] == 0.01 and m.optim.defaults["betas"] == (0.9, 0.999)
+    assert m.get_next_train_scale() == 4 and m.get_model() is m.model
+    v2, _, _ = _make("LarvaNetV2", ["--num_modules=4", "--num_blocks=4,4,4,4"])
+    v2.prepare(is_training=False, scales=[4])
+    sd2 = v2.model.state_dict()
+    assert len(sd2) == 88 and sum(v.numel() for v in sd2.values()) == 957264
+    assert tuple(sd2["tail.merge_conv.weight"].shape) == (48, 192, 3, 3)
+
+
+def test_scheduler_is_plateau_on_max_psnr():
+    m, _, _ = _make("LarvaNet", ["--num_modules=1", "--num_blocks=1", "--patience=0", "--cooldown=0"])
+    m.prepare(is_training=True, scales=[4])
+    m.scheduler.step(30.0)
+    m.scheduler.step(30.0005)  # below the absolute threshold of 1e-3 dB: counts as no improvement
+    assert m.get_lr() == pytest.approx(2e-4)
+
+
+def test_cpu_forward_fails_loudly():
+    m, _, _ = _make("LarvaNet", ["--num_modules=1", "--num_blocks=1"])
+    m.prepare(is_training=False, scales=[4])
+    if m.device.type == "cpu":
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.upscale([np.zeros((3, 8, 8), np.float32)], 4)
+
+
+def test_metrics_and_chop_forward_match_reference_vectors(golden):
+    from larvanet_amd import image_utils, metrics
+    g = golden("f7_validate_helpers.npz")
+    assert np.array_equal(metrics.image_to_uint8(g["img"]), g["u8"])
+    g9 = golden("f9_chop_forward.npz")
+    parts = image_utils.split_quadrants(g9["img"], 6)
+    for i, p in enumerate(parts):
+        assert np.array_equal(p, g9["split%d" % i])
+
+    class Nearest:
+        def upscale(self, input_list, scale):
+            a = np.asarray(input_list, np.float32)
+            return a.repeat(scale, axis=2).repeat(scale, axis=3) + 0.25
+
+    assert np.array_equal(image_utils.upscale_with_chop_forward(Nearest(), g9["img"], 4, 6), g9["out"])
+
+
+def _write_div2k(tmp_path, n=3):
+    from PIL import Image
+    from larvanet_amd.dataloaders.synthetic_loader import make_pair
+    hr_dir = tmp_path / "HR"
+    lr_dir = tmp_path / "LR" / "X4"
+    hr_dir.mkdir(parents=True)
+    lr_dir.mkdir(parents=True)
+    for i in range(n):
+        lr, hr = make_pair(i, 20 + i, 24, 4, False)
+        Image.fromarray(hr.transpose(1, 2, 0)).save(hr_dir / ("%04d.png" % i))
+        Image.fromarray(lr.transpose(1, 2, 0)).save(lr_dir / ("%04dx4.png" % i))
+    return str(tmp_path / "LR"), str(hr_dir)
+
+
+def test_div2k_loader_patch_geometry(tmp_path):
+    from larvanet_amd.dataloaders import div2k_train_loader, div2k_val_loader
+    lr_root, hr_root = _write_div2k(tmp_path)
+    ld = div2k_train_loader.create_loader()
+    _, rest = ld.parse_args(["--data_input_path", lr_root, "--data_truth_path", hr_root, "--data_seed=3", "--x=1"])
+    assert rest == ["--x=1"]
+    ld.prepare([4])
+    assert ld.get_num_images() == 3 and not ld.is_threaded
+    lr, hr, name = ld.get_image_pair(1, 4)
+    assert lr.dtype == np.float32 and lr.shape == (3, 21, 24) and hr.shape == (3, 84, 96) and name == "0001"
+    ins, outs = ld.get_patch_batch(batch_size=5, scale=4, input_patch_size=8)
+    assert len(ins) == 5 and all(a.shape == (3, 8, 8) for a in ins) and all(b.shape == (3, 32, 32) for b in outs)
+    # the HR patch is the x4 region of the LR patch under the same rotation/flip: its 4x4 box
+    # mean equals the LR patch (the synthetic LR is the rounded box filter of HR)
+    for a, b in zip(ins, outs):
+        box = np.asarray(b).reshape(3, 8, 4, 8, 4).mean(axis=(2, 4))
+        assert np.abs(box - np.asarray(a)).max() <= 0.5 + 1e-4
+    # same seed -> same stream; different rank seed -> different stream
+    ld2 = div2k_train_loader.create_loader()
+    ld2.parse_args(["--data_input_path", lr_root, "--data_truth_path", hr_root, "--data_seed=3"])
+    ld2.prepare([4])
+    ins2, _ = ld2.get_patch_batch(batch_size=5, scale=4, input_patch_size=8)
+    assert all(np.array_equal(a, b) for a, b in zip(ins, ins2))
+    val = div2k_val_loader.create_loader()
+    val.parse_args(["--val_input_path", lr_root, "--val_truth_path", hr_root])
+    val.prepare([4])
+    vlr, vhr, _ = val.get_image_pair(0, 4)
+    assert vlr.dtype == np.uint8 and vhr.dtype == np.uint8
+
+
+def test_combined_loader_threads(tmp_path):
+    from larvanet_amd.dataloaders import combined_loader
+    lr_root, hr_root = _write_div2k(tmp_path)
+    ld = combined_loader.create_loader()
+    ld.parse_args(["--data_input_path", lr_root, "--data_truth_path", hr_root, "--data_cached",
+                   "--data_num_queue_runners=2", "--data_seed=1"])
+    ld.prepare([4])
+    assert ld.is_threaded and ld.get_queue_data(4) is None
+    ld.start_training_queue_runner(batch_size=3, input_patch_size=8)
+    for _ in range(4):
+        ins, outs = ld.get_queue_data(scale=4)
+        assert len(ins) == 3 and ins[0].shape == (3, 8, 8) and outs[0].shape == (3, 32, 32)
+    ld.stop_queue_runners()
+    assert ld.get_queue_data(4) is None
+
+
+def test_synthetic_loader_rank_streams_differ(monkeypatch):
+    from larvanet_amd import dist as ldist
+    from larvanet_amd.dataloaders import synthetic_loader
+    batches = []
+    for r in (0, 1):
+        monkeypatch.setattr(ldist, "rank", lambda r=r: r)
+        ld = synthetic_loader.create_loader()
+        ld.parse_args(["--synthetic_images=4", "--synthetic_lr_size=24"])
+        ld.prepare([4])
+        batches.append(ld.get_patch_batch(4, 4, 12)[0])
+    assert not all(np.array_equal(a, b) for a, b in zip(*batches))
+
+
+def test_train_driver_argument_chain_on_cpu(tmp_path, monkeypatch, capsys):
+    """Everything of train_larva.main() up to the first step, with the model's device work stubbed
+    out: flags are chained driver -> loader -> val loader -> model, arguments.json is written,
+    volume_per_step uses the global batch."""
+    from larvanet_amd import train_larva
+    from larvanet_amd.models import LarvaNet as L
+    calls = {}
+
+    def fake_step(self, args, val_dataloader, input_tensor, truth_tensor, summary=None):
+        self.global_step += 1
+        calls.setdefault("shapes", []).append((tuple(input_tensor.shape), tuple(truth_tensor.shape), input_tensor.dtype))
+        return 1.0
+
+    monkeypatch.setattr(L.LarvaNet, "train_step_larva", fake_step)
+    model = train_larva.main(["--model=LarvaNet", "--dataloader=synthetic_loader", "--val_dataloader=synthetic_loader",
+                              "--train_path", str(tmp_path), "--max_steps=2", "--batch_size=3", "--input_patch_size=12",
+                              "--num_modules=1", "--num_blocks=1", "--synthetic_images=2", "--synthetic_lr_size=24",
+                              "--bogus_flag=7"])
+    assert model.global_step == 2 and model.volume_per_step == 12 * 12 * 3 * 3
+    assert calls["shapes"][0] == ((3, 3, 12, 12), (3, 3, 48, 48), torch.float32)
+    saved = json.load(open(os.path.join(str(tmp_path), "arguments.json")))
+    assert saved["model"] == "LarvaNet" and saved["num_blocks"] == "1" and saved["batch_size"] == 3 and saved["world_size"] == 1
+    assert "WARNING: found unhandled arguments: ['--bogus_flag=7']" in capsys.readouterr().out

@@ -145,3 +145,41 @@ def test_hip_graph_replay_matches_eager_launches(hip_device):
     assert results[0][0] == results[1][0]
     for k in results[0][1]:
         assert np.array_equal(results[0][1][k], results[1][1][k]), k
+
+
+def test_v2_tail_f8(hip_device, golden):
+    """LarvaNetV2: merge conv over the un-materialised concatenation, tail exit, (M+1)-way loss."""
+    g = golden("f8_v2_tail.npz")
+    m = _model("LarvaNetV2", ["--num_modules=2", "--num_blocks=2,2"], training=True)
+    sd = m.model.state_dict()
+    for k in sd:  # seed-0 construction order matches the reference
+        if k.startswith("tail."):
+            assert np.array_equal(sd[k].cpu().numpy(), g["sd." + k]), k
+    x = torch.from_numpy(g["x"]).to(hip_device)
+    truth = torch.from_numpy(g["truth"]).to(hip_device)
+    with torch.no_grad():
+        out = m.model(x).cpu().numpy()
+    np.testing.assert_allclose(out, g["out"], rtol=0, atol=2e-3)
+    m.use_hip_graph = False
+    m.volume_per_step = 0
+    loss = m.train_step_larva(types.SimpleNamespace(train_path="/tmp"), FakeValLoader(7), x, truth)
+    assert abs(loss - float(g["loss"])) < 2e-5 * float(g["loss"])
+    grads = {k: p.grad.cpu().numpy() for k, p in m.model.named_parameters()}
+    for k in grads:
+        if k.startswith("tail."):
+            ref = g["grad." + k]
+            tol = 2e-4 * max(float(np.abs(ref).max()), 1e-6)
+            assert float(np.abs(grads[k] - ref).max()) <= tol, k
+    for k, ref_abs in zip(g["trunk_keys"], g["trunk_gabs"]):
+        got = float(np.abs(grads[str(k)].astype(np.float64)).sum())
+        assert abs(got - float(ref_abs)) <= 1e-3 * float(ref_abs) + 1e-7, (str(k), got, float(ref_abs))
+
+
+def test_v2_restore_takes_matching_keys_only(hip_device, tmp_path):
+    v1 = _model("LarvaNet", ["--num_modules=2", "--num_blocks=1,1"], training=True, seed=3)
+    path = v1.save(str(tmp_path))
+    v2 = _model("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,1"], seed=4)
+    tail_before = v2.model.tail.merge_conv.weight.detach().cpu().clone()
+    v2.restore(path)
+    assert torch.equal(v2.model.head.feature_extraction.weight.cpu(), v1.model.head.feature_extraction.weight.cpu())
+    assert torch.equal(v2.model.tail.merge_conv.weight.cpu(), tail_before)
