@@ -19,6 +19,16 @@
 // Roofline: fp32 MFMA (2*9*Cin*Cout FLOP per pixel; 41 472 at 48 channels) -- see DESIGN.md.
 #include "larva_common.h"
 
+// Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
+// bit 0 = skip the MFMA blocks, bit 1 = skip the global->LDS staging, bit 2 = skip the
+// epilogue's global traffic, bit 3 = return at kernel entry.
+#ifndef LARVA_DIAG
+#define LARVA_DIAG 0
+#endif
+#ifndef LARVA_DIAG_ONLY48
+#define LARVA_DIAG_ONLY48 0
+#endif
+
 namespace larva {
 
 struct ConvArgs {
@@ -228,20 +238,33 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     for (int p = 0; p < NPG; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   Staging<COUT> st;
-  load_chunk<COUT, VEC>(a, 0, n, y0, x0, tid, st);
-  store_chunk<COUT, VEC>(smem, tid, st);
+  if constexpr (!(LARVA_DIAG & 2)) {
+    load_chunk<COUT, VEC>(a, 0, n, y0, x0, tid, st);
+    store_chunk<COUT, VEC>(smem, tid, st);
+  }
   __syncthreads();
 
   for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
     float* cur = smem + (chunk & 1) * C::STAGE_FLOATS;
     float* nxt = smem + ((chunk & 1) ^ 1) * C::STAGE_FLOATS;
     const bool more = chunk + 1 < a.n_chunks;
-    if (more) load_chunk<COUT, VEC>(a, chunk + 1, n, y0, x0, tid, st);
-    mfma_chunk<COUT, NCT, PG0, NPG>(cur, ct0, lane, acc);
-    if (more) store_chunk<COUT, VEC>(nxt, tid, st);
+    if constexpr (!(LARVA_DIAG & 2)) {
+      if (more) load_chunk<COUT, VEC>(a, chunk + 1, n, y0, x0, tid, st);
+    }
+    if constexpr (!(LARVA_DIAG & 1)) mfma_chunk<COUT, NCT, PG0, NPG>(cur, ct0, lane, acc);
+    if constexpr (!(LARVA_DIAG & 2)) {
+      if (more) store_chunk<COUT, VEC>(nxt, tid, st);
+    }
     __syncthreads();
   }
 
+  if constexpr ((LARVA_DIAG & 4) != 0) {  // keep the accumulators alive, touch no global memory
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) asm volatile("" ::"v"(acc[c][p]));
+    return;
+  }
   // Epilogue.  Lane (lr, lq) holds, in acc[c][p][r], output channel (ct0+c)*16 + lq*4 + r of
   // pixel (y0 + pg/3, x0 + (pg%3)*16 + lr).
   if constexpr (EPI == kEpiShuffle || EPI == kEpiShuffleBase) {
@@ -313,6 +336,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
 template <int COUT, bool VEC, int EPI>
 __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if constexpr ((LARVA_DIAG & 8) != 0) return;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = tile % a.tiles_x;
   const int t2 = tile / a.tiles_x;
@@ -481,9 +505,11 @@ int larva_conv3x3_fwd(const float* const* src, int n_src, int cin_per_src, const
   }
   hipStream_t s = (hipStream_t)stream;
   switch (cout) {
+#if !LARVA_DIAG_ONLY48
     case 32: return (int)launch_conv<32>(a, epi, s);
-    case 48: return (int)launch_conv<48>(a, epi, s);
     case 64: return (int)launch_conv<64>(a, epi, s);
+#endif
+    case 48: return (int)launch_conv<48>(a, epi, s);
     default: return (int)hipErrorInvalidValue;
   }
 }
