@@ -37,6 +37,9 @@ BLOCKS = [4, 4, 4, 4]
 HR_PIX_PER_BATCH = BATCH * (PATCH * SCALE) ** 2          # 589 824
 CONV_FLOP = 2 * 9 * CH * CH * BATCH * PATCH * PATCH      # 1.5288 GFLOP per 48->48 layer
 FP32_MFMA_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: Peak FP32 (matrix)
+# HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per
+# the guide's gfx950 correction + WRITE_SIZE), see profiles/README.md; None until measured.
+HBM_TRAFFIC_PER_LAUNCH = None
 
 
 class TinyValLoader:
@@ -59,9 +62,11 @@ def barrier_sync(dist_on):
     torch.cuda.synchronize()
 
 
-def time_dominant_kernel(dev, iters=30):
-    """Average duration of the fused conv3x3+ReLU kernel at 16x48x48x48, one event pair per launch
-    on the launch stream (torch's current stream is the stream the C ABI launches on)."""
+def time_dominant_kernel(dev, iters=50):
+    """Duration of the fused conv3x3+ReLU kernel at 16x48x48x48 on the launch stream, two ways:
+    kernel-attached HIP events (hipExtLaunchKernelGGL start/stop = the kernel's own begin/end, what
+    rocprofv3 --kernel-trace reports) and a plain event pair around each launch (includes the
+    launch gap).  roofline.achieved uses the former."""
     from larvanet_amd import kernels as K
     g = torch.Generator().manual_seed(5)
     x = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 20).to(dev)
@@ -72,14 +77,26 @@ def time_dominant_kernel(dev, iters=30):
     for _ in range(5):
         K.conv3x3(x, fwd, CH, bias=b, relu=True, out=out)
     torch.cuda.synchronize()
+    k_mean, k_min = K.conv3x3_relu_timed(x, fwd, CH, b, out, iters)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for s, e in evs:
         s.record()
         K.conv3x3(x, fwd, CH, bias=b, relu=True, out=out)
         e.record()
     torch.cuda.synchronize()
-    ms = sorted(s.elapsed_time(e) for s, e in evs)
-    return float(np.mean(ms)), float(ms[len(ms) // 2])
+    pair = sorted(s.elapsed_time(e) for s, e in evs)
+    return k_mean, k_min, float(np.mean(pair))
+
+
+def roofline_block(dev):
+    k_mean_ms, k_min_ms, pair_ms = time_dominant_kernel(dev)
+    achieved = CONV_FLOP / (k_mean_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": HBM_TRAFFIC_PER_LAUNCH,
+            "kernel": "conv3x3_mfma_kernel<48, true, 1> (fused conv3x3+bias+ReLU), 16x48x48x48 fp32",
+            "flop_per_launch": CONV_FLOP, "avg_ms": k_mean_ms, "min_ms": k_min_ms,
+            "event_pair_ms_incl_launch_gap": pair_ms,
+            "algorithmic_bytes_per_launch": 2 * BATCH * CH * PATCH * PATCH * 4 + 4 * (9 * CH * CH + CH)}
 
 
 def host_cores():
@@ -143,6 +160,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only time the dominant kernel (short run for rocprofv3 --pmc passes)")
     ap.add_argument("--sync-loss", action="store_true",
                     help="return loss.item() every step like the reference (host sync per step)")
     a = ap.parse_args()
@@ -155,6 +174,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
     dev = torch.device("cuda", torch.cuda.current_device())
+    if a.roofline_only:
+        print(json.dumps({"roofline": roofline_block(dev)}))
+        return
 
     import importlib
     model = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
@@ -200,8 +222,6 @@ def main():
         torch.cuda.synchronize()
         infer_ms = (time.perf_counter() - t0) / 20 * 1e3
 
-    k_mean_ms, k_med_ms = time_dominant_kernel(dev)
-    achieved = CONV_FLOP / (k_mean_ms * 1e-3) / 1e12
     line = {
         "metric": "HR Mpixels/s (LarvaNet x4 multi-exit train step, 48x48 LR patches)",
         "value": value, "unit": "HR Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -211,11 +231,9 @@ def main():
                                "(BASELINE config 2 at the reference's only channel count), batch 16 x 3x48x48 "
                                "-> 3x192x192 per GPU, fp32",
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
-                   "loss_sync_per_step": bool(a.sync_loss), "final_loss": float(loss)},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                     "kernel": "conv3x3_mfma_kernel<48,vec,relu> 16x48x48x48", "flop_per_launch": CONV_FLOP,
-                     "avg_ms": k_mean_ms, "median_ms": k_med_ms},
+                   "loss_sync_per_step": bool(a.sync_loss), "hip_graph": bool(model.use_hip_graph),
+                   "final_loss": float(loss)},
+        "roofline": roofline_block(dev),
         "infer": {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
                   "unit": "HR Mpixels/s"},
     }

@@ -31,6 +31,11 @@ long long larva_packed_weight_floats(int cout, int cin);
 int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout, int cin,
                        int w_cin_total, int w_cin_off, void* stream);
 
+/* njobs (<= 64) packs in ONE launch; every argument is a host array of length njobs. */
+int larva_pack_weights_batch(const float* const* w, float* const* wpk_fwd, float* const* wpk_bwd,
+                             const int* cout, const int* cin, const int* w_cin_total,
+                             const int* w_cin_off, int njobs, void* stream);
+
 /* ---- fused 3x3 convolution (forward and input-gradient) -----------------------------------
  * Replaces nn.Conv2d(k=3,s=1,p=1) plus its elementwise neighbours:
  *   conv+ReLU                 models/LarvaNet.py:210-211, 256-257
@@ -49,6 +54,13 @@ int larva_conv3x3_fwd(const float* const* src, int n_src, int cin_per_src, const
                       const float* bias, const float* res0, const float* res1, const float* mask,
                       const float* base, float* out, int N, int cout, int H, int W, int relu,
                       int mode, void* stream);
+
+/* Measurement only: the same launch `iters` times with kernel-attached events
+ * (hipExtLaunchKernelGGL); mean/min kernel duration in ms.  Synchronises the stream. */
+int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                            const float* bias, const float* res0, const float* res1, const float* mask,
+                            const float* base, float* out, int N, int cout, int H, int W, int relu,
+                            int mode, void* stream, int iters, float* mean_ms, float* min_ms);
 
 /* ---- weight / bias gradient ---------------------------------------------------------------
  * Replaces autograd's conv weight/bias gradient for the call sites above (loss.backward(),

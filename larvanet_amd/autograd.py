@@ -18,35 +18,64 @@ _WGRAD_WORKGROUPS = 256
 
 
 class PackedConv:
-    """Packed (kernel-layout) images of one conv weight, rebuilt when the weight changes."""
+    """Kernel-layout images of one conv weight in persistent device buffers.
 
-    __slots__ = ("weight", "bias", "cin_pad", "slices", "_key", "_packs")
+    Staleness: in-place optimizer kernels (torch's fused AdamW) do not bump Tensor._version, so
+    while gradients are enabled the images are rebuilt for every forward -- by ONE batched launch
+    for the whole network (pack_all) when the owner calls it first, else per conv.  Without
+    gradients (inference) they are cached until the weight's storage/version moves or
+    invalidate() is called (restore / load_state_dict / optimizer step do)."""
+
+    __slots__ = ("weight", "bias", "cin_pad", "slices", "_key", "_packs", "_bufs", "_prepacked")
 
     def __init__(self, weight, bias, cin_pad=None, slices=None):
         self.weight, self.bias, self.cin_pad = weight, bias, cin_pad
         self.slices = slices  # list of (cin_off, cin) for a conv over concatenated inputs, or None
         self._key = None
         self._packs = None
+        self._bufs = None
+        self._prepacked = False
 
     def invalidate(self):
         self._key = None
+        self._prepacked = False
+
+    def _current_key(self):
+        w = self.weight
+        return (w.data_ptr(), w._version, str(w.device))
+
+    def jobs(self):
+        """Pack jobs (w, fwd_buf, bwd_buf, cout, cin_k, cin_off) writing into persistent buffers."""
+        w = self.weight
+        cout, cin_total = int(w.shape[0]), int(w.shape[1])
+        dev = w.device
+        if self._bufs is None or self._bufs[0] != (w.data_ptr(), str(dev)):
+            def buf(a, b):
+                return torch.empty(K.packed_weight_floats(a, b), device=dev, dtype=torch.float32)
+            if self.slices is None:
+                cin_k = cin_total if self.cin_pad is None else self.cin_pad
+                specs = [(buf(cout, cin_k), None if self.cin_pad is not None else buf(cin_k, cout), cin_k, 0)]
+            else:
+                specs = [(buf(cout, cin_total), None, cin_total, 0)]
+                specs += [(buf(cout, c), buf(c, cout), c, o) for (o, c) in self.slices]
+            self._bufs = ((w.data_ptr(), str(dev)), specs)
+        wd = w.detach()
+        return [(wd, f, b, cout, cin_k, off) for (f, b, cin_k, off) in self._bufs[1]]
+
+    def _mark_packed(self):
+        self._packs = [(f, b) for (f, b, _, _) in self._bufs[1]]
+        self._key = self._current_key()
 
     def refresh(self):
-        """Called by the owning module's forward (outside autograd.Function, where the grad
-        mode is visible).  While training, the weights change every step and in-place optimizer
-        kernels do not reliably bump Tensor._version, so the images are rebuilt on every
-        grad-enabled forward; for inference they are cached until the storage or version moves
-        (load_state_dict / restore also call invalidate())."""
-        w = self.weight
-        key = (w.data_ptr(), w._version, str(w.device))
-        if key != self._key or (torch.is_grad_enabled() and w.requires_grad):
+        """Called by the owning module's forward (outside autograd.Function, where the grad mode
+        is visible)."""
+        if self._prepacked:  # packed by pack_all() for exactly this use
+            self._prepacked = False
+            return self
+        if self._key != self._current_key() or (torch.is_grad_enabled() and self.weight.requires_grad):
             with torch.no_grad():
-                if self.slices is None:
-                    self._packs = [K.pack_weights(w.detach(), cin_pad=self.cin_pad, want_bwd=self.cin_pad is None)]
-                else:
-                    whole = K.pack_weights(w.detach(), want_bwd=False)[0]
-                    self._packs = [(whole, None)] + [K.pack_weights(w.detach(), cin_off=o, cin=c) for (o, c) in self.slices]
-            self._key = key
+                K.pack_weights_batch(self.jobs())
+            self._mark_packed()
         return self
 
     def get(self):
@@ -54,6 +83,19 @@ class PackedConv:
         if self._packs is None:
             self.refresh()
         return self._packs
+
+
+def pack_all(pcs):
+    """One launch (per 64 jobs) packing every conv of a network; each PackedConv then skips its
+    own repack at its next refresh()."""
+    jobs = []
+    for pc in pcs:
+        jobs += pc.jobs()
+    with torch.no_grad():
+        K.pack_weights_batch(jobs)
+    for pc in pcs:
+        pc._mark_packed()
+        pc._prepacked = True
 
 
 def _splits(njobs):

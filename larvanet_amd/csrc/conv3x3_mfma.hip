@@ -18,6 +18,7 @@
 //
 // Roofline: fp32 MFMA (2*9*Cin*Cout FLOP per pixel; 41 472 at 48 channels) -- see DESIGN.md.
 #include "larva_common.h"
+#include <hip/hip_ext.h>
 
 // Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
 // bit 0 = skip the MFMA blocks, bit 1 = skip the global->LDS staging, bit 2 = skip the
@@ -402,8 +403,62 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+constexpr int kMaxPackJobs = 64;
+
+struct PackJob {
+  const float* w;
+  float* fwd;
+  float* bwd;
+  int cout, cin, w_cin_total, w_cin_off;
+};
+
+struct PackBatch {
+  PackJob job[kMaxPackJobs];
+};
+
+// All layers of a network in one launch (blockIdx.y = layer): 41 packs per training step would
+// otherwise be 41 launch boundaries for 3 us of work each.
+__global__ void pack_weights_batch_kernel(PackBatch b) {
+  const PackJob& j = b.job[blockIdx.y];
+  const int csf = cout_stride(j.cout), csb = cout_stride(j.cin);
+  const int nf = (j.cin / 16) * 9 * 16 * csf;
+  const int nb = (j.cout / 16) * 9 * 16 * csb;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += gridDim.x * blockDim.x) {
+    if (i < nf) {
+      if (!j.fwd) continue;
+      const int co = i % csf;
+      int t = i / csf;
+      const int k = t % 16; t /= 16;
+      const int tap = t % 9;
+      const int chunk = t / 9;
+      const int cin_abs = j.w_cin_off + chunk * 16 + k;
+      float v = 0.f;
+      if (co < j.cout && cin_abs < j.w_cin_total) v = j.w[((size_t)co * j.w_cin_total + cin_abs) * 9 + tap];
+      j.fwd[i] = v;
+    } else {
+      if (!j.bwd) continue;
+      const int q = i - nf;
+      const int ci = q % csb;
+      int t = q / csb;
+      const int k = t % 16; t /= 16;
+      const int tap = t % 9;
+      const int chunk = t / 9;
+      float v = 0.f;
+      if (ci < j.cin && j.w_cin_off + ci < j.w_cin_total)
+        v = j.w[((size_t)(chunk * 16 + k) * j.w_cin_total + j.w_cin_off + ci) * 9 + (8 - tap)];
+      j.bwd[q] = v;
+    }
+  }
+}
+
+// Optional kernel-attached events (hipExtLaunchKernelGGL): start/stop carry the kernel's own
+// begin/end timestamps, i.e. the duration a profiler reports, without launch gaps.
+struct LaunchTiming {
+  hipEvent_t start, stop;
+};
+
 template <int COUT, bool VEC, int EPI>
-static hipError_t launch_conv_e(const ConvArgs& a, hipStream_t stream) {
+static hipError_t launch_conv_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
   using C = ConvCfg<COUT>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -413,27 +468,31 @@ static hipError_t launch_conv_e(const ConvArgs& a, hipStream_t stream) {
     attr_set = true;
   }
   const int grid = a.N * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
+  if (tm)
+    hipExtLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(256), C::LDS_BYTES, stream,
+                          tm->start, tm->stop, 0, a);
+  else
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(256), C::LDS_BYTES, stream, a);
   return hipGetLastError();
 }
 
 template <int COUT, bool VEC>
-static hipError_t launch_conv_v(const ConvArgs& a, int epi, hipStream_t stream) {
+static hipError_t launch_conv_v(const ConvArgs& a, int epi, hipStream_t stream, const LaunchTiming* tm) {
   switch (epi) {
-    case kEpiPlain: return launch_conv_e<COUT, VEC, kEpiPlain>(a, stream);
-    case kEpiRelu: return launch_conv_e<COUT, VEC, kEpiRelu>(a, stream);
-    case kEpiMask: return launch_conv_e<COUT, VEC, kEpiMask>(a, stream);
-    case kEpiRes1: return launch_conv_e<COUT, VEC, kEpiRes1>(a, stream);
-    case kEpiRes2: return launch_conv_e<COUT, VEC, kEpiRes2>(a, stream);
-    case kEpiShuffle: return launch_conv_e<COUT, VEC, kEpiShuffle>(a, stream);
-    case kEpiShuffleBase: return launch_conv_e<COUT, VEC, kEpiShuffleBase>(a, stream);
+    case kEpiPlain: return launch_conv_e<COUT, VEC, kEpiPlain>(a, stream, tm);
+    case kEpiRelu: return launch_conv_e<COUT, VEC, kEpiRelu>(a, stream, tm);
+    case kEpiMask: return launch_conv_e<COUT, VEC, kEpiMask>(a, stream, tm);
+    case kEpiRes1: return launch_conv_e<COUT, VEC, kEpiRes1>(a, stream, tm);
+    case kEpiRes2: return launch_conv_e<COUT, VEC, kEpiRes2>(a, stream, tm);
+    case kEpiShuffle: return launch_conv_e<COUT, VEC, kEpiShuffle>(a, stream, tm);
+    case kEpiShuffleBase: return launch_conv_e<COUT, VEC, kEpiShuffleBase>(a, stream, tm);
     default: return hipErrorInvalidValue;
   }
 }
 
 template <int COUT>
-static hipError_t launch_conv(const ConvArgs& a, int epi, hipStream_t stream) {
-  return a.vec_ok ? launch_conv_v<COUT, true>(a, epi, stream) : launch_conv_v<COUT, false>(a, epi, stream);
+static hipError_t launch_conv(const ConvArgs& a, int epi, hipStream_t stream, const LaunchTiming* tm) {
+  return a.vec_ok ? launch_conv_v<COUT, true>(a, epi, stream, tm) : launch_conv_v<COUT, false>(a, epi, stream, tm);
 }
 
 }  // namespace larva
@@ -446,6 +505,24 @@ extern "C" {
 // 16) and `cout` output channels (32, 48 or 64).
 long long larva_packed_weight_floats(int cout, int cin) {
   return (long long)(cin / 16) * 9 * 16 * cout_stride(cout);
+}
+
+// njobs (<= 64) larva_pack_weights calls in one launch; arrays are host arrays of length njobs.
+int larva_pack_weights_batch(const float* const* w, float* const* wpk_fwd, float* const* wpk_bwd,
+                             const int* cout, const int* cin, const int* w_cin_total,
+                             const int* w_cin_off, int njobs, void* stream) {
+  if (njobs < 1 || njobs > kMaxPackJobs) return (int)hipErrorInvalidValue;
+  PackBatch b{};
+  int max_total = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (!w[i] || cout[i] % 16 || cin[i] % 16 || cout[i] <= 0 || cin[i] <= 0) return (int)hipErrorInvalidValue;
+    b.job[i] = PackJob{w[i], wpk_fwd[i], wpk_bwd[i], cout[i], cin[i], w_cin_total[i], w_cin_off[i]};
+    const int total = (cin[i] / 16) * 9 * 16 * cout_stride(cout[i]) + (cout[i] / 16) * 9 * 16 * cout_stride(cin[i]);
+    max_total = total > max_total ? total : max_total;
+  }
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((max_total + 255) / 256, njobs), dim3(256), 0,
+                     (hipStream_t)stream, b);
+  return (int)hipGetLastError();
 }
 
 int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout, int cin,
@@ -463,10 +540,10 @@ int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout,
 // (cout, n_src*cin_per_src).  Epilogue, in this order: relu -> mask -> +res0 -> +res1 -> store
 // (mode 0, [N][cout][H][W]) or pixel-shuffle(4) store with optional +base (mode 1,
 // [N][cout/16][4H][4W]).  Stream-ordered, never allocates or synchronises.
-int larva_conv3x3_fwd(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                      const float* bias, const float* res0, const float* res1, const float* mask,
-                      const float* base, float* out, int N, int cout, int H, int W, int relu,
-                      int mode, void* stream) {
+static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                         const float* bias, const float* res0, const float* res1, const float* mask,
+                         const float* base, float* out, int N, int cout, int H, int W, int relu,
+                         int mode, void* stream, const LaunchTiming* tm) {
   if (n_src < 1 || n_src > kMaxSrc || cin_per_src % 16 || N <= 0 || H <= 0 || W <= 0)
     return (int)hipErrorInvalidValue;
   if (mode != 0 && mode != 1) return (int)hipErrorInvalidValue;
@@ -506,12 +583,54 @@ int larva_conv3x3_fwd(const float* const* src, int n_src, int cin_per_src, const
   hipStream_t s = (hipStream_t)stream;
   switch (cout) {
 #if !LARVA_DIAG_ONLY48
-    case 32: return (int)launch_conv<32>(a, epi, s);
-    case 64: return (int)launch_conv<64>(a, epi, s);
+    case 32: return (int)launch_conv<32>(a, epi, s, tm);
+    case 64: return (int)launch_conv<64>(a, epi, s, tm);
 #endif
-    case 48: return (int)launch_conv<48>(a, epi, s);
+    case 48: return (int)launch_conv<48>(a, epi, s, tm);
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+
+int larva_conv3x3_fwd(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                      const float* bias, const float* res0, const float* res1, const float* mask,
+                      const float* base, float* out, int N, int cout, int H, int W, int relu,
+                      int mode, void* stream) {
+  return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, relu,
+                       mode, stream, nullptr);
+}
+
+// Measurement only (synchronises; not capturable): runs the same launch `iters` times with
+// kernel-attached events and returns the mean and minimum kernel duration in milliseconds.
+int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                            const float* bias, const float* res0, const float* res1, const float* mask,
+                            const float* base, float* out, int N, int cout, int H, int W, int relu,
+                            int mode, void* stream, int iters, float* mean_ms, float* min_ms) {
+  if (iters < 1 || !mean_ms || !min_ms) return (int)hipErrorInvalidValue;
+  LaunchTiming tm{};
+  hipError_t e = hipEventCreate(&tm.start);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventCreate(&tm.stop);
+  if (e != hipSuccess) return (int)e;
+  double sum = 0.0;
+  float best = 1e30f;
+  int rc = 0;
+  for (int i = 0; i < iters && rc == 0; ++i) {
+    rc = conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, relu,
+                       mode, stream, &tm);
+    if (rc) break;
+    e = hipEventSynchronize(tm.stop);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, tm.start, tm.stop);
+    if (e != hipSuccess) { rc = (int)e; break; }
+    sum += ms;
+    best = ms < best ? ms : best;
+  }
+  (void)hipEventDestroy(tm.start);
+  (void)hipEventDestroy(tm.stop);
+  *mean_ms = (float)(sum / iters);
+  *min_ms = best;
+  return rc;
 }
 
 }  // extern "C"

@@ -289,25 +289,39 @@ struct ReduceBatch {
   int cout, cin;  // kernel shape of every job in the batch
 };
 
-__global__ void wgrad_reduce_kernel(ReduceBatch rb) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceBatch rb) {
   const ReduceJob& j = rb.job[blockIdx.y];
   const int ct_n = rb.cout / 16, nb = (rb.cin / 16) * 9;
   const int n_w = nb * ct_n * 256;
-  const int pf = n_w + rb.cout;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pf = n_w + rb.cout;  // multiple of 4
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= pf) return;
-  float s = 0.f;
-  for (int k = 0; k < rb.splits; ++k) s += j.partial[(size_t)k * pf + i];
+  // one 16-byte column of the [splits][pf] partial matrix per thread; 8 independent loads in flight
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const float* p = j.partial + i;
+  int k = 0;
+  for (; k + 8 <= rb.splits; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + u) * pf);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < rb.splits; ++k) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * pf);
   if (i < n_w) {
-    const int r = i & 3, lane = (i >> 2) & 63;
+    const int lane = (i >> 2) & 63;
     const int t = i >> 8;
     const int c = t % ct_n, bi = t / ct_n;
     const int cit = bi / 9, tap = bi % 9;
-    const int co = c * 16 + (lane >> 4) * 4 + r;
+    const int co0 = c * 16 + (lane >> 4) * 4;
     const int ci = cit * 16 + (lane & 15);
-    if (ci < j.cin_valid) j.dw[((size_t)co * j.w_cin_total + j.cin_off + ci) * 9 + tap] = s;
+    if (ci < j.cin_valid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) j.dw[((size_t)(co0 + r) * j.w_cin_total + j.cin_off + ci) * 9 + tap] = s[r];
+    }
   } else if (j.db) {
-    j.db[i - n_w] = s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) j.db[i - n_w + r] = s[r];
   }
 }
 
@@ -379,7 +393,7 @@ int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* co
   else return (int)hipErrorInvalidValue;
   if (e != hipSuccess) return (int)e;
   const int pf = (cin / 16) * 9 * (cout / 16) * 256 + cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((pf + 255) / 256, njobs), dim3(256), 0, s, rb);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((pf / 4 + 255) / 256, njobs), dim3(256), 0, s, rb);
   return (int)hipGetLastError();
 }
 

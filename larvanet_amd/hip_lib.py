@@ -19,10 +19,17 @@ SIGNATURES = {
     "larva_packed_weight_floats": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int]),
     "larva_pack_weights": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_pack_weights_batch": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p,
+                                                ctypes.c_int, ctypes.c_void_p]),
     "larva_conv3x3_fwd": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
                                          _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_conv3x3_fwd_timed": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
+                                               _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "larva_wgrad_partial_floats": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "larva_conv3x3_wgrad": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

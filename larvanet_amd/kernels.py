@@ -60,6 +60,30 @@ def pack_weights(w, cin_off=0, cin=None, cin_pad=None, want_bwd=True):
     return fwd, bwd
 
 
+def pack_weights_batch(jobs):
+    """jobs: list of (w, fwd_buf, bwd_buf or None, cout, cin_k, cin_off): packs every weight
+    (slice) into its persistent kernel-layout buffers with one launch per 64 jobs."""
+    lib = hip_lib.load()
+    for i in range(0, len(jobs), 64):
+        chunk = jobs[i:i + 64]
+        ws, fs, bs, couts, cins, totals, offs = [], [], [], [], [], [], []
+        for (w, fwd, bwd, cout, cin_k, cin_off) in chunk:
+            _chk(w, "w")
+            if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or int(w.shape[0]) != cout:
+                raise RuntimeError("larvanet_amd: only [cout][cin][3][3] weights are supported")
+            ws.append(w.data_ptr())
+            fs.append(_chk(fwd, "wpk_fwd", (packed_weight_floats(cout, cin_k),)))
+            bs.append(None if bwd is None else _chk(bwd, "wpk_bwd", (packed_weight_floats(cin_k, cout),)))
+            couts.append(cout)
+            cins.append(cin_k)
+            totals.append(int(w.shape[1]))
+            offs.append(cin_off)
+        code = lib.larva_pack_weights_batch(hip_lib.ptr_array(ws), hip_lib.ptr_array(fs), hip_lib.ptr_array(bs),
+                                            hip_lib.int_array(couts), hip_lib.int_array(cins),
+                                            hip_lib.int_array(totals), hip_lib.int_array(offs), len(chunk), _stream())
+        hip_lib.check(code, "larva_pack_weights_batch")
+
+
 def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=None,
             shuffle=False, base=None, out=None):
     """Fused 3x3 conv over the channel concatenation of `srcs` (list of [N][c][H][W]).
@@ -90,6 +114,23 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
         _opt(base, "base", hr), out.data_ptr(), N, cout, H, W, 1 if relu else 0, 1 if shuffle else 0, _stream())
     hip_lib.check(code, "larva_conv3x3_fwd")
     return out
+
+
+def conv3x3_relu_timed(x, wpk, cout, bias, out, iters):
+    """Measurement only: (mean_ms, min_ms) of the fused conv+ReLU launch, from kernel-attached
+    events (the kernel's own begin/end timestamps)."""
+    import ctypes
+    lib = hip_lib.load()
+    N, cin, H, W = (int(v) for v in x.shape)
+    _chk(x, "x")
+    _chk(wpk, "wpk", (packed_weight_floats(cout, cin),))
+    _chk(out, "out", (N, cout, H, W))
+    mean, best = ctypes.c_float(0), ctypes.c_float(0)
+    code = lib.larva_conv3x3_fwd_timed(hip_lib.ptr_array([x.data_ptr()]), 1, cin, wpk.data_ptr(),
+                                       _opt(bias, "bias", (cout,)), None, None, None, None, out.data_ptr(),
+                                       N, cout, H, W, 1, 0, _stream(), iters, ctypes.byref(mean), ctypes.byref(best))
+    hip_lib.check(code, "larva_conv3x3_fwd_timed")
+    return float(mean.value), float(best.value)
 
 
 def wgrad_partial_floats(cout, cin, splits):

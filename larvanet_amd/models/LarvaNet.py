@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .. import dist as ldist
 from .. import kernels as K
-from ..autograd import BodyFn, HeadFn, L1LossFn, LegFn, PackedConv
+from ..autograd import BodyFn, HeadFn, L1LossFn, LegFn, PackedConv, pack_all
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
 from .base import BaseModel
 
@@ -150,11 +150,20 @@ class LarvaNetModule(nn.Module):
         for i, nb in enumerate(parse_num_blocks(args)):
             setattr(self, "body_%d" % i, LarvaBody(num_blocks=nb))
 
+    def packed_convs(self):
+        out = []
+        for m in self.modules():
+            out += ([m._pc] if hasattr(m, "_pc") else []) + list(getattr(m, "_pcs", []))
+        return out
+
     def invalidate_packed_weights(self):
         """Forget the kernel-layout weight images (call after changing weights behind torch's back)."""
-        for m in self.modules():
-            for pc in ([m._pc] if hasattr(m, "_pc") else []) + list(getattr(m, "_pcs", [])):
-                pc.invalidate()
+        for pc in self.packed_convs():
+            pc.invalidate()
+
+    def refresh_packed_weights(self):
+        """Rebuild every conv's kernel-layout image with one batched launch (training forward)."""
+        pack_all(self.packed_convs())
 
     def base(self, x):
         """F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False) (models/LarvaNet.py:283-285)."""
@@ -238,6 +247,7 @@ class LarvaNet(BaseModel):
     def _exit_losses(self, input_tensor, truth_tensor):
         """Forward through every exit (models/LarvaNet.py:102-109). Returns (loss, last output)."""
         net = self.model
+        net.refresh_packed_weights()
         fea = net.head(input_tensor)
         base = net.base(input_tensor)
         loss = 0

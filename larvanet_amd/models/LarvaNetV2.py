@@ -94,6 +94,7 @@ class LarvaNet(V1.LarvaNet):
     def _exit_losses(self, input_tensor, truth_tensor):
         """models/LarvaNetV2.py:104-123: every exit plus the tail, / (M + 1)."""
         net = self.model
+        net.refresh_packed_weights()
         fea = net.head(input_tensor)
         base = net.base(input_tensor)
         loss = 0
