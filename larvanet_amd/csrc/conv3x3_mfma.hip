@@ -1,0 +1,717 @@
+// Fused 3x3 convolution (stride 1, zero pad 1, NCHW fp32) for gfx950 as an implicit GEMM on
+// v_mfma_f32_16x16x4_f32, with the reference's elementwise neighbours fused into the epilogue.
+//
+// Replaces, per launch, these reference call sites (file:line into the reference tree):
+//   conv+ReLU                      models/LarvaNet.py:210-211, 256-257
+//   conv + torch.add(x, res)       models/LarvaNet.py:212, 217-220
+//   last block conv + outer skip   models/LarvaNet.py:246-248   (two residual operands)
+//   conv -> PixelShuffle(4) -> += base   models/LarvaNet.py:258, 261, 263-267   (mode 1)
+//   torch.cat(features) + merge conv     models/LarvaNetV2.py:328-330  (several source tensors)
+// and, with tap-mirrored / channel-transposed packed weights, the input-gradient (dgrad) of each
+// of them, with the ReLU-backward mask and the skip-gradient adds fused the same way.
+//
+// GEMM view per workgroup (one 3 x 48 pixel tile):  D[cout][pixel] = sum_k W[cout][k] * im2col[k][pixel],
+//   k = (chunk of 8 input channels) x (tap 0..8) x (2 k-steps of 4 channels).
+//   MFMA A operand = weights (M = cout), B operand = activations (N = pixel), so each lane ends
+//   up with 4 consecutive output channels of ONE pixel -- exactly the (i = lane>>4, j = reg)
+//   sub-pixels of PixelShuffle(4), which makes the shuffle a single aligned 16-byte store.
+//
+// Staging: each K chunk (8-channel halo tile, 10 KiB, + its 9x8xCOUT weights) is one LDS stage.
+//   VEC  (W % 4 == 0, 16-byte aligned tensors): LDS-DMA (global_load_lds_dwordx4) into a ring of
+//        3 stages, two chunks in flight behind a counted vmcnt, one barrier per chunk, no staging
+//        registers; 72 KiB of LDS and < 128 VGPRs per workgroup, so two workgroups (of this or
+//        another kernel) share a CU and fill each other's prologue / epilogue bubbles.
+//   !VEC (any W): the same stage image filled through registers (scalar loads), 2 stages.
+//
+// Roofline: fp32 MFMA (2*9*Cin*Cout FLOP per pixel; 41 472 at 48 channels) -- see DESIGN.md.
+#include "larva_common.h"
+#include <hip/hip_ext.h>
+
+// Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
+// bit 0 = skip the MFMA blocks, bit 1 = skip the global->LDS staging, bit 2 = skip the
+// epilogue's global traffic, bit 3 = return at kernel entry.
+#ifndef LARVA_DIAG
+#define LARVA_DIAG 0
+#endif
+#ifndef LARVA_DIAG_ONLY48
+#define LARVA_DIAG_ONLY48 0
+#endif
+
+namespace larva {
+
+constexpr int kCh = 8;  // input channels per K chunk
+
+// Source of every LDS-DMA lane that falls outside the image (zero padding) or into layout padding.
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct ConvArgs {
+  const float* src[kMaxSrc];  // channel-concatenated inputs, each [N][cin_per_src][H][W]
+  const float* wpk;           // packed weights [n_chunks][9][8][CS]
+  const float* bias;          // [COUT] or null
+  const float* res0;          // [N][COUT][H][W]            (added first)
+  const float* res1;          // [N][COUT][H][W]            (added second)
+  const float* mask;          // [N][COUT][H][W]            (v = mask > 0 ? v : 0, before the adds)
+  const float* base;          // pixel-shuffle store: [N][COUT/16][4H][4W]
+  float* out;                 // [N][COUT][H][W], or [N][COUT/16][4H][4W] for the pixel-shuffle store
+  int cin_per_src;            // multiple of 8
+  int n_chunks;               // total input channels / 8
+  int N, H, W;
+  int tiles_x, tiles_y;
+};
+
+// Epilogue variants (compile-time so that every residual/mask load of a wave is in flight at
+// once instead of one dependent L2 round trip per runtime branch).
+enum Epi : int {
+  kEpiPlain = 0,        // out = acc + bias
+  kEpiRelu = 1,         // out = max(acc + bias, 0)
+  kEpiMask = 2,         // out = mask > 0 ? acc + bias : 0            (ReLU backward)
+  kEpiRes1 = 3,         // out = (acc + bias) + res0
+  kEpiRes2 = 4,         // out = ((acc + bias) + res0) + res1
+  kEpiShuffle = 5,      // pixel-shuffle(4) store
+  kEpiShuffleBase = 6,  // pixel-shuffle(4) store, + base
+  kEpiCount = 7
+};
+
+template <int COUT>
+struct ConvCfg {
+  static constexpr int CT = COUT / 16;
+  static constexpr int CS = cout_stride(COUT);
+  static constexpr int PS = 304;  // plane stride of a staged channel: >= 5*kRS and == 16 (mod 32)
+  // One stage = [8 channel planes, padded to 10 KiB][9*8 weight rows, padded to whole KiB]; every
+  // 1 KiB "piece" is what one wave-level LDS-DMA instruction writes.
+  static constexpr int IN_PIECES = 10;
+  static constexpr int IN_FLOATS = IN_PIECES * 256;
+  static constexpr int IN_SLOTS_PER_PLANE = PS / 4;                         // 76 float4 slots
+  static constexpr int W_USED = 9 * kCh * CS;
+  static constexpr int W_PIECES = (W_USED + 255) / 256;
+  static constexpr int W_FLOATS = W_PIECES * 256;
+  static constexpr int PIECES = IN_PIECES + W_PIECES;
+  static constexpr int NPW = (PIECES + 3) / 4;                              // pieces per wave per chunk
+  static constexpr int STAGE_FLOATS = IN_FLOATS + W_FLOATS;
+  static constexpr int STEPS = 9 * (kCh / 4);                               // 18 k-steps per chunk
+  static constexpr size_t LDS_BYTES_DMA = 3 * STAGE_FLOATS * sizeof(float);
+  static constexpr size_t LDS_BYTES_REG = 2 * STAGE_FLOATS * sizeof(float);
+  // register-staged path
+  static constexpr int RIN_SLOTS = kCh * kHaloRows * (kRS / 4);             // 560 float4 slots
+  static constexpr int RIN_ITERS = (RIN_SLOTS + 255) / 256;
+  static constexpr int RW_SLOTS = W_USED / 4;
+  static constexpr int RW_ITERS = (RW_SLOTS + 255) / 256;
+  static_assert(kCh * PS <= IN_FLOATS, "input planes must fit their pieces");
+};
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA staging (VEC path)
+// ---------------------------------------------------------------------------------------------
+template <int COUT>
+struct DmaPlan {
+  // Per piece i of this wave (piece index p = wave + 4 i, clamped): the lane's source offset in
+  // floats relative to the chunk's image base (input pieces) or weight base (weight pieces), or
+  // -1 when the lane's 16 bytes are zero padding; plus the wave-uniform LDS offset and kind.
+  int off[ConvCfg<COUT>::NPW];
+  int lds_off[ConvCfg<COUT>::NPW];
+  unsigned is_w;  // bit i: piece i is a weight piece (wave-uniform)
+  unsigned ok;    // bit i: this lane's 16 bytes of piece i come from memory (else zeros)
+};
+
+template <int COUT>
+__device__ __forceinline__ void make_plan(const ConvArgs& a, int wave, int lane, int y0, int x0,
+                                          DmaPlan<COUT>& pl) {
+  using C = ConvCfg<COUT>;
+  pl.is_w = 0;
+  pl.ok = 0;
+#pragma unroll
+  for (int i = 0; i < C::NPW; ++i) {
+    const int p = min(wave + 4 * i, C::PIECES - 1);  // surplus pieces repeat the last one (same bytes)
+    // input piece
+    const int slot = p * 64 + lane;
+    const int ci = slot / C::IN_SLOTS_PER_PLANE;
+    const int rem = slot - ci * C::IN_SLOTS_PER_PLANE;
+    const int r = rem / (kRS / 4);
+    const int q = rem - r * (kRS / 4);
+    const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+    const bool in_ok = ci < kCh && r < kHaloRows && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const int in_off = (ci * a.H + gy) * a.W + gx;
+    // weight piece
+    const int ws = (p - C::IN_PIECES) * 64 + lane;
+    const bool w_ok = ws * 4 < C::W_USED;
+    const bool isw = p >= C::IN_PIECES;  // wave-uniform
+    const bool ok = isw ? w_ok : in_ok;
+    pl.off[i] = ok ? (isw ? ws * 4 : in_off) : 0;
+    pl.lds_off[i] = isw ? C::IN_FLOATS + (p - C::IN_PIECES) * 256 : p * 256;
+    pl.is_w |= (isw ? 1u : 0u) << i;
+    pl.ok |= (ok ? 1u : 0u) << i;
+  }
+  pl.is_w = __builtin_amdgcn_readfirstlane(pl.is_w);
+}
+
+struct ChunkSrc {
+  const float* img;  // first of the chunk's 8 channel planes of image n
+  const float* wgt;  // the chunk's packed weights
+};
+
+template <int COUT>
+__device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int n) {
+  using C = ConvCfg<COUT>;
+  const int c0 = chunk * kCh;
+  const int s_idx = c0 / a.cin_per_src;
+  const int c_in_src = c0 - s_idx * a.cin_per_src;
+  ChunkSrc cs;
+  cs.img = a.src[s_idx] + ((size_t)n * a.cin_per_src + c_in_src) * ((size_t)a.H * a.W);
+  cs.wgt = a.wpk + (size_t)chunk * C::W_USED;
+  return cs;
+}
+
+// One 1 KiB piece: lane l's 16 bytes go to stage + lds_off + 16 l.  Branch-free source select
+// (integer arithmetic on purpose: a pointer ternary becomes exec-masked branches here).
+template <int COUT>
+__device__ __forceinline__ void dma_piece(const DmaPlan<COUT>& pl, int i, const float* img, const float* wgt,
+                                          float* stage) {
+  const bool isw = (pl.is_w >> i) & 1u;  // scalar
+  const uint64_t base = reinterpret_cast<uint64_t>(isw ? wgt : img);
+  const uint64_t zero = reinterpret_cast<uint64_t>(&g_zero_page[0]);
+  const uint64_t addr = ((pl.ok >> i) & 1u) ? base + 4ull * (uint32_t)pl.off[i] : zero;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
+                                   (__attribute__((address_space(3))) void*)(stage + pl.lds_off[i]), 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register staging (!VEC path): same stage image, scalar global loads with per-element masks.
+// ---------------------------------------------------------------------------------------------
+template <int COUT>
+struct RegStaging {
+  f32x4 in[ConvCfg<COUT>::RIN_ITERS];
+  f32x4 w[ConvCfg<COUT>::RW_ITERS];
+};
+
+template <int COUT>
+__device__ __forceinline__ void reg_load(const ConvArgs& a, const ChunkSrc& cs, int y0, int x0, int tid,
+                                         RegStaging<COUT>& st) {
+  using C = ConvCfg<COUT>;
+  const size_t plane = (size_t)a.H * a.W;
+#pragma unroll
+  for (int i = 0; i < C::RIN_ITERS; ++i) {
+    const int s = min(tid + i * 256, C::RIN_SLOTS - 1);
+    const int ci = s / (kHaloRows * (kRS / 4));
+    const int rem = s - ci * (kHaloRows * (kRS / 4));
+    const int r = rem / (kRS / 4);
+    const int q = rem - r * (kRS / 4);
+    const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+    const bool row_ok = gy >= 0 && gy < a.H;
+    const float* row = cs.img + (size_t)ci * plane + (size_t)min(max(gy, 0), a.H - 1) * a.W;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int x = gx + e;
+      const float t = row[min(max(x, 0), a.W - 1)];
+      v[e] = (row_ok && x >= 0 && x < a.W) ? t : 0.f;
+    }
+    st.in[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < C::RW_ITERS; ++i) {
+    const int s = min(tid + i * 256, C::RW_SLOTS - 1);
+    const float* p = cs.wgt + 4 * s;  // packed images are only guaranteed 4-byte aligned here
+    st.w[i] = f32x4{p[0], p[1], p[2], p[3]};
+  }
+}
+
+template <int COUT>
+__device__ __forceinline__ void reg_store(float* stage, int tid, const RegStaging<COUT>& st) {
+  using C = ConvCfg<COUT>;
+#pragma unroll
+  for (int i = 0; i < C::RIN_ITERS; ++i) {
+    const int s = tid + i * 256;
+    if (s < C::RIN_SLOTS) {
+      const int ci = s / (kHaloRows * (kRS / 4));
+      const int rem = s - ci * (kHaloRows * (kRS / 4));
+      const int r = rem / (kRS / 4);
+      const int q = rem - r * (kRS / 4);
+      *reinterpret_cast<f32x4*>(stage + ci * C::PS + r * kRS + 4 * q) = st.in[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < C::RW_ITERS; ++i) {
+    const int s = tid + i * 256;
+    if (s < C::RW_SLOTS) *reinterpret_cast<f32x4*>(stage + C::IN_FLOATS + 4 * s) = st.w[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA block of one chunk
+// ---------------------------------------------------------------------------------------------
+// Operands of k-step `step` (= tap*2 + kk) of one chunk.
+template <int COUT, int NCT, int PG0, int NPG>
+__device__ __forceinline__ void read_operands(const float* a_base, const float* b_base, int step,
+                                              float (&av)[NCT], float (&bv)[NPG]) {
+  using C = ConvCfg<COUT>;
+  const int tap = step / (kCh / 4), kk = step % (kCh / 4);
+  const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) av[c] = a_base[(tap * kCh + kk * 4) * C::CS + c * 16];
+#pragma unroll
+  for (int p = 0; p < NPG; ++p) {
+    const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+    bv[p] = b_base[kk * 4 * C::PS + (prow + ky) * kRS + pcol * 16 + kx];
+  }
+}
+
+// One chunk of K (8 channels x 9 taps = 18 k-steps) for a wave that owns cout groups
+// [ct0, ct0+NCT) and pixel groups [PG0, PG0+NPG) of the tile.  One wave per SIMD means nobody
+// else hides the LDS latency, so the operands of step s+1 are read while step s multiplies
+// (hipcc otherwise sinks every ds_read to just above its first use, lgkmcnt(0) per pair of
+// MFMAs; the sched_barriers pin "reads of s+1, [one LDS-DMA piece], MFMAs of s").
+// PREFETCH: the wave's NPW LDS-DMA pieces of the chunk two ahead are issued between k-steps.
+template <int COUT, int NCT, int PG0, int NPG, bool PREFETCH>
+__device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int lane, f32x4 (&acc)[NCT][NPG],
+                                           const DmaPlan<COUT>& pl, const float* nxt_img, const float* nxt_wgt,
+                                           float* nxt_stage, bool do_prefetch) {
+  using C = ConvCfg<COUT>;
+  const int lr = lane & 15, lq = lane >> 4;
+  const float* a_base = stage + C::IN_FLOATS + lq * C::CS + lr + ct0 * 16;
+  const float* b_base = stage + lq * C::PS + lr + 3;
+  constexpr int kEvery = C::STEPS / C::NPW > 0 ? C::STEPS / C::NPW : 1;
+  float av[2][NCT], bv[2][NPG];
+  read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, 0, av[0], bv[0]);
+#pragma unroll
+  for (int step = 0; step < C::STEPS; ++step) {
+    if (step + 1 < C::STEPS)
+      read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+    if constexpr (PREFETCH) {
+      if (step % kEvery == 0 && step / kEvery < C::NPW) {
+        if (do_prefetch) dma_piece<COUT>(pl, step / kEvery, nxt_img, nxt_wgt, nxt_stage);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p)
+        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][c], bv[step & 1][p], acc[c][p], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Wait until all but the `KEEP` youngest vector-memory operations of this wave are done, then
+// meet the other waves.  Raw barrier on purpose: __syncthreads() would drain every LDS-DMA.
+template <int KEEP>
+__device__ __forceinline__ void wait_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int COUT, bool VEC, int EPI, int NCT, int PG0, int NPG>
+__device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0, int wave, int n, int y0,
+                                         int x0, int tid) {
+  using C = ConvCfg<COUT>;
+  const int lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  // Bias is fetched first (older than every LDS-DMA, so the counted waits below cover it) and
+  // added in the epilogue.
+  f32x4 bias[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) bias[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[c][r] = a.bias[(ct0 + c) * 16 + lq * 4 + r];
+  }
+
+  f32x4 acc[NCT][NPG];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int p = 0; p < NPG; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if constexpr (VEC) {
+    // ---- LDS-DMA ring: chunk c lives in stage c % 3; chunks c+1 and c+2 are in flight --------
+    DmaPlan<COUT> pl;
+    make_plan<COUT>(a, wave, lane, y0, x0, pl);
+    if constexpr (!(LARVA_DIAG & 2)) {
+      const int pre = a.n_chunks < 2 ? a.n_chunks : 2;
+      for (int c = 0; c < pre; ++c) {
+        const ChunkSrc cs = chunk_src<COUT>(a, c, n);
+#pragma unroll
+        for (int i = 0; i < C::NPW; ++i) dma_piece<COUT>(pl, i, cs.img, cs.wgt, smem + c * C::STAGE_FLOATS);
+      }
+    }
+    int stage = 0;
+    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+      // The chunk's own pieces have landed (the NPW youngest operations belong to chunk+1) and,
+      // after the barrier, everybody's have, and everybody is done with the stage that
+      // chunk+2 is about to overwrite.
+      if (chunk + 1 < a.n_chunks) wait_and_barrier<C::NPW>();
+      else wait_and_barrier<0>();
+      const bool more = (chunk + 2 < a.n_chunks) && !(LARVA_DIAG & 2);
+      const ChunkSrc nxt = chunk_src<COUT>(a, more ? chunk + 2 : chunk, n);
+      const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
+      if constexpr (!(LARVA_DIAG & 1))
+        mfma_chunk<COUT, NCT, PG0, NPG, true>(smem + stage * C::STAGE_FLOATS, ct0, lane, acc, pl, nxt.img, nxt.wgt,
+                                              smem + nstage * C::STAGE_FLOATS, more);
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+  } else {
+    // ---- register staging, 2 stages ------------------------------------------------------------
+    RegStaging<COUT> st;
+    if constexpr (!(LARVA_DIAG & 2)) {
+      reg_load<COUT>(a, chunk_src<COUT>(a, 0, n), y0, x0, tid, st);
+      reg_store<COUT>(smem, tid, st);
+    }
+    __syncthreads();
+    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+      float* cur = smem + (chunk & 1) * C::STAGE_FLOATS;
+      float* nxt = smem + ((chunk & 1) ^ 1) * C::STAGE_FLOATS;
+      const bool more = chunk + 1 < a.n_chunks;
+      if constexpr (!(LARVA_DIAG & 2)) {
+        if (more) reg_load<COUT>(a, chunk_src<COUT>(a, chunk + 1, n), y0, x0, tid, st);
+      }
+      if constexpr (!(LARVA_DIAG & 1))
+        mfma_chunk<COUT, NCT, PG0, NPG, false>(cur, ct0, lane, acc, DmaPlan<COUT>{}, nullptr, nullptr, nullptr, false);
+      if constexpr (!(LARVA_DIAG & 2)) {
+        if (more) reg_store<COUT>(nxt, tid, st);
+      }
+      __syncthreads();
+    }
+  }
+
+  if constexpr ((LARVA_DIAG & 4) != 0) {  // keep the accumulators alive, touch no global memory
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) asm volatile("" ::"v"(acc[c][p]));
+    return;
+  }
+
+  // Epilogue.  Lane (lr, lq) holds, in acc[c][p][r], output channel (ct0+c)*16 + lq*4 + r of
+  // pixel (y0 + pg/3, x0 + (pg%3)*16 + lr).
+  if constexpr (EPI == kEpiShuffle || EPI == kEpiShuffleBase) {
+    // PixelShuffle(4): out[n, C, 4y+i, 4x+j] = conv[n, 16C + 4i + j, y, x]; here C = ct0+c,
+    // i = lq, j = r -> one aligned 16-byte store per lane (models/LarvaNet.py:261,265-266).
+    const int HH = 4 * a.H, WW = 4 * a.W;
+    f32x4 basev[NCT][NPG];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
+        const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
+        if constexpr (EPI == kEpiShuffleBase) basev[c][p] = *reinterpret_cast<const f32x4*>(a.base + idx);
+      }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int y = y0 + prow, x = x0 + pcol * 16 + lr;
+        const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
+        f32x4 v = acc[c][p] + bias[c];
+        if constexpr (EPI == kEpiShuffleBase) v += basev[c][p];
+        if (y < a.H && x < a.W) *reinterpret_cast<f32x4*>(a.out + idx) = v;
+      }
+  } else {
+    const size_t plane = (size_t)a.H * a.W;
+    constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1) ? 1 : (EPI == kEpiRes2 ? 2 : 0);
+    f32x4 aux[NAUX > 0 ? NAUX : 1][NCT][NPG];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
+        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.W + x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (EPI == kEpiMask) aux[0][c][p][r] = a.mask[idx0 + r * plane];
+          if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) aux[0][c][p][r] = a.res0[idx0 + r * plane];
+          if constexpr (EPI == kEpiRes2) aux[1][c][p][r] = a.res1[idx0 + r * plane];
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int y = y0 + prow, x = x0 + pcol * 16 + lr;
+        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.W + x;
+        const f32x4 v = acc[c][p] + bias[c];
+        if (y < a.H && x < a.W) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float o = v[r];
+            if constexpr (EPI == kEpiRelu) o = fmaxf(o, 0.f);
+            if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
+            if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
+            if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
+            a.out[idx0 + r * plane] = o;
+          }
+        }
+      }
+  }
+}
+
+// VEC: 2 workgroups per CU (launch bound 2 waves/SIMD caps the registers at 256).
+template <int COUT, bool VEC, int EPI>
+__global__ __launch_bounds__(256, VEC ? 2 : 1) void conv3x3_mfma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if constexpr ((LARVA_DIAG & 8) != 0) return;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = tile % a.tiles_x;
+  const int t2 = tile / a.tiles_x;
+  const int ty = t2 % a.tiles_y;
+  const int n = t2 / a.tiles_y;
+  const int x0 = tx * kTileCols, y0 = ty * kTileRows;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // 9 pixel groups x CT cout groups, dealt to the 4 waves (one per SIMD) as evenly as a
+  // rectangular (cout groups) x (pixel groups) ownership allows.
+  if constexpr (COUT == 48) {  // 27 -> 7,7,7,6
+    if (wave < 3) run_role<COUT, VEC, EPI, 1, 0, 7>(a, smem, wave, wave, n, y0, x0, tid);
+    else run_role<COUT, VEC, EPI, 3, 7, 2>(a, smem, 0, wave, n, y0, x0, tid);
+  } else if constexpr (COUT == 32) {  // 18 -> 5,5,4,4
+    if (wave < 2) run_role<COUT, VEC, EPI, 1, 0, 5>(a, smem, wave, wave, n, y0, x0, tid);
+    else run_role<COUT, VEC, EPI, 1, 5, 4>(a, smem, wave - 2, wave, n, y0, x0, tid);
+  } else {  // COUT == 64: 36 -> 9,9,9,9
+    static_assert(COUT == 64, "unsupported channel count");
+    run_role<COUT, VEC, EPI, 1, 0, 9>(a, smem, wave, wave, n, y0, x0, tid);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing: [Cout][Cin][3][3] (PyTorch layout, models/LarvaNet.py:210) ->
+//   fwd  [Cin/8][9][8][CS(Cout)]   wpk[chunk][tap][k][co]  = W[co][chunk*8+k][tap]
+//   bwd  [Cout/8][9][8][CS(Cin)]   wpk[chunk][tap][k][ci]  = W[chunk*8+k][ci][8-tap]
+// (dgrad is the same convolution with the channel roles swapped and the taps point-mirrored).
+// `w_cin_total`/`w_cin_off` select a channel slice of a wider weight (merge conv of LarvaNetV2);
+// channels at or beyond w_cin_total pack as zero (the 3-channel head conv padded to 8).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxPackJobs = 64;
+
+struct PackJob {
+  const float* w;
+  float* fwd;
+  float* bwd;
+  int cout, cin, w_cin_total, w_cin_off;
+};
+
+struct PackBatch {
+  PackJob job[kMaxPackJobs];
+};
+
+__host__ __device__ constexpr int packed_floats(int cout, int cin) {
+  return (cin / kCh) * 9 * kCh * cout_stride(cout);
+}
+
+// All layers of a network in one launch (blockIdx.y = layer): 41 packs per training step would
+// otherwise be 41 launch boundaries for 3 us of work each.
+__global__ void pack_weights_batch_kernel(PackBatch b) {
+  const PackJob& j = b.job[blockIdx.y];
+  const int csf = cout_stride(j.cout), csb = cout_stride(j.cin);
+  const int nf = packed_floats(j.cout, j.cin);
+  const int nb = packed_floats(j.cin, j.cout);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += gridDim.x * blockDim.x) {
+    if (i < nf) {
+      if (!j.fwd) continue;
+      const int co = i % csf;
+      int t = i / csf;
+      const int k = t % kCh; t /= kCh;
+      const int tap = t % 9;
+      const int chunk = t / 9;
+      const int cin_abs = j.w_cin_off + chunk * kCh + k;
+      float v = 0.f;
+      if (co < j.cout && cin_abs < j.w_cin_total) v = j.w[((size_t)co * j.w_cin_total + cin_abs) * 9 + tap];
+      j.fwd[i] = v;
+    } else {
+      if (!j.bwd) continue;
+      const int q = i - nf;
+      const int ci = q % csb;
+      int t = q / csb;
+      const int k = t % kCh; t /= kCh;
+      const int tap = t % 9;
+      const int chunk = t / 9;
+      float v = 0.f;
+      if (ci < j.cin && j.w_cin_off + ci < j.w_cin_total)
+        v = j.w[((size_t)(chunk * kCh + k) * j.w_cin_total + j.w_cin_off + ci) * 9 + (8 - tap)];
+      j.bwd[q] = v;
+    }
+  }
+}
+
+// Optional kernel-attached events (hipExtLaunchKernelGGL): start/stop carry the kernel's own
+// begin/end timestamps, i.e. the duration a profiler reports, without launch gaps.
+struct LaunchTiming {
+  hipEvent_t start, stop;
+};
+
+template <int COUT, bool VEC, int EPI>
+static hipError_t launch_conv_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
+  using C = ConvCfg<COUT>;
+  constexpr size_t lds = VEC ? C::LDS_BYTES_DMA : C::LDS_BYTES_REG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<COUT, VEC, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = a.N * a.tiles_x * a.tiles_y;
+  if (tm)
+    hipExtLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(256), lds, stream,
+                          tm->start, tm->stop, 0, a);
+  else
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(256), lds, stream, a);
+  return hipGetLastError();
+}
+
+template <int COUT, bool VEC>
+static hipError_t launch_conv_v(const ConvArgs& a, int epi, hipStream_t stream, const LaunchTiming* tm) {
+  switch (epi) {
+    case kEpiPlain: return launch_conv_e<COUT, VEC, kEpiPlain>(a, stream, tm);
+    case kEpiRelu: return launch_conv_e<COUT, VEC, kEpiRelu>(a, stream, tm);
+    case kEpiMask: return launch_conv_e<COUT, VEC, kEpiMask>(a, stream, tm);
+    case kEpiRes1: return launch_conv_e<COUT, VEC, kEpiRes1>(a, stream, tm);
+    case kEpiRes2: return launch_conv_e<COUT, VEC, kEpiRes2>(a, stream, tm);
+    case kEpiShuffle: return launch_conv_e<COUT, VEC, kEpiShuffle>(a, stream, tm);
+    case kEpiShuffleBase: return launch_conv_e<COUT, VEC, kEpiShuffleBase>(a, stream, tm);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int COUT>
+static hipError_t launch_conv(const ConvArgs& a, bool vec, int epi, hipStream_t stream, const LaunchTiming* tm) {
+  return vec ? launch_conv_v<COUT, true>(a, epi, stream, tm) : launch_conv_v<COUT, false>(a, epi, stream, tm);
+}
+
+}  // namespace larva
+
+using namespace larva;
+
+extern "C" {
+
+// Number of floats of one packed weight image for a conv with `cin` input channels (multiple of
+// 8) and `cout` output channels (32, 48 or 64).
+long long larva_packed_weight_floats(int cout, int cin) { return (long long)packed_floats(cout, cin); }
+
+// njobs (<= 64) packs in one launch; arrays are host arrays of length njobs.
+int larva_pack_weights_batch(const float* const* w, float* const* wpk_fwd, float* const* wpk_bwd,
+                             const int* cout, const int* cin, const int* w_cin_total,
+                             const int* w_cin_off, int njobs, void* stream) {
+  if (njobs < 1 || njobs > kMaxPackJobs) return (int)hipErrorInvalidValue;
+  PackBatch b{};
+  int max_total = 0;
+  for (int i = 0; i < njobs; ++i) {
+    if (!w[i] || cout[i] % kCh || cin[i] % kCh || cout[i] <= 0 || cin[i] <= 0) return (int)hipErrorInvalidValue;
+    b.job[i] = PackJob{w[i], wpk_fwd[i], wpk_bwd[i], cout[i], cin[i], w_cin_total[i], w_cin_off[i]};
+    const int total = packed_floats(cout[i], cin[i]) + packed_floats(cin[i], cout[i]);
+    max_total = total > max_total ? total : max_total;
+  }
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((max_total + 255) / 256, njobs), dim3(256), 0,
+                     (hipStream_t)stream, b);
+  return (int)hipGetLastError();
+}
+
+int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout, int cin,
+                       int w_cin_total, int w_cin_off, void* stream) {
+  return larva_pack_weights_batch(&w, &wpk_fwd, &wpk_bwd, &cout, &cin, &w_cin_total, &w_cin_off, 1, stream);
+}
+
+// Fused 3x3 convolution.  `src` is an array of `n_src` device pointers (channel concatenation,
+// each tensor [N][cin_per_src][H][W]); `wpk` a packed weight image from larva_pack_weights for
+// (cout, n_src*cin_per_src).  Epilogue, in this order: relu -> mask -> +res0 -> +res1 -> store
+// (mode 0, [N][cout][H][W]) or pixel-shuffle(4) store with optional +base (mode 1,
+// [N][cout/16][4H][4W]).  Stream-ordered, never allocates or synchronises.
+static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                         const float* bias, const float* res0, const float* res1, const float* mask,
+                         const float* base, float* out, int N, int cout, int H, int W, int relu,
+                         int mode, void* stream, const LaunchTiming* tm) {
+  if (n_src < 1 || n_src > kMaxSrc || cin_per_src % kCh || cin_per_src <= 0 || N <= 0 || H <= 0 || W <= 0)
+    return (int)hipErrorInvalidValue;
+  if (mode != 0 && mode != 1) return (int)hipErrorInvalidValue;
+  if ((long long)cin_per_src * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;  // 32-bit lane offsets
+  if (!wpk || !out) return (int)hipErrorInvalidValue;
+  ConvArgs a{};
+  bool aligned = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(wpk) & 15) == 0);
+  for (int i = 0; i < n_src; ++i) {
+    if (!src[i]) return (int)hipErrorInvalidValue;
+    a.src[i] = src[i];
+    aligned = aligned && ((reinterpret_cast<uintptr_t>(src[i]) & 15) == 0);
+  }
+  a.wpk = wpk; a.bias = bias; a.res0 = res0; a.res1 = res1; a.mask = mask; a.base = base;
+  a.out = out;
+  a.cin_per_src = cin_per_src;
+  a.n_chunks = n_src * cin_per_src / kCh;
+  a.N = N; a.H = H; a.W = W;
+  a.tiles_x = (W + kTileCols - 1) / kTileCols;
+  a.tiles_y = (H + kTileRows - 1) / kTileRows;
+  // Map the requested fusion onto a compiled epilogue (relu -> mask -> +res0 -> +res1).
+  int epi;
+  if (mode == 1) {
+    if (relu || mask || res0 || res1) return (int)hipErrorInvalidValue;
+    epi = base ? kEpiShuffleBase : kEpiShuffle;
+  } else {
+    if (base) return (int)hipErrorInvalidValue;
+    const int code = (relu ? 1 : 0) | (mask ? 2 : 0) | (res0 ? 4 : 0) | (res1 ? 8 : 0);
+    switch (code) {
+      case 0: epi = kEpiPlain; break;
+      case 1: epi = kEpiRelu; break;
+      case 2: epi = kEpiMask; break;
+      case 4: epi = kEpiRes1; break;
+      case 12: epi = kEpiRes2; break;
+      default: return (int)hipErrorInvalidValue;
+    }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  switch (cout) {
+#if !LARVA_DIAG_ONLY48
+    case 32: return (int)launch_conv<32>(a, aligned, epi, s, tm);
+    case 64: return (int)launch_conv<64>(a, aligned, epi, s, tm);
+#endif
+    case 48: return (int)launch_conv<48>(a, aligned, epi, s, tm);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+int larva_conv3x3_fwd(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                      const float* bias, const float* res0, const float* res1, const float* mask,
+                      const float* base, float* out, int N, int cout, int H, int W, int relu,
+                      int mode, void* stream) {
+  return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, relu,
+                       mode, stream, nullptr);
+}
+
+// Measurement only (synchronises; not capturable): runs the same launch `iters` times with
+// kernel-attached events and returns the mean and minimum kernel duration in milliseconds.
+int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                            const float* bias, const float* res0, const float* res1, const float* mask,
+                            const float* base, float* out, int N, int cout, int H, int W, int relu,
+                            int mode, void* stream, int iters, float* mean_ms, float* min_ms) {
+  if (iters < 1 || !mean_ms || !min_ms) return (int)hipErrorInvalidValue;
+  LaunchTiming tm{};
+  hipError_t e = hipEventCreate(&tm.start);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventCreate(&tm.stop);
+  if (e != hipSuccess) return (int)e;
+  double sum = 0.0;
+  float best = 1e30f;
+  int rc = 0;
+  for (int i = 0; i < iters && rc == 0; ++i) {
+    rc = conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, relu,
+                       mode, stream, &tm);
+    if (rc) break;
+    e = hipEventSynchronize(tm.stop);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, tm.start, tm.stop);
+    if (e != hipSuccess) { rc = (int)e; break; }
+    sum += ms;
+    best = ms < best ? ms : best;
+  }
+  (void)hipEventDestroy(tm.start);
+  (void)hipEventDestroy(tm.stop);
+  *mean_ms = (float)(sum / iters);
+  *min_ms = best;
+  return rc;
+}
+
+}  // extern "C"

@@ -50,8 +50,8 @@ def pack_weights(w, cin_off=0, cin=None, cin_pad=None, want_bwd=True):
     cin_k = cin if cin_pad is None else cin_pad
     if cin_k > cin and cin_off + cin != cin_total:
         raise RuntimeError("larvanet_amd: zero padding needs a slice that ends at cin_total")
-    if cin_k % 16 or cout % 16 or cin_k < cin:
-        raise RuntimeError("larvanet_amd: channel counts must be multiples of 16 (cout=%d cin=%d)" % (cout, cin_k))
+    if cin_k % 8 or cout % 8 or cin_k < cin:
+        raise RuntimeError("larvanet_amd: channel counts must be multiples of 8 (cout=%d cin=%d)" % (cout, cin_k))
     fwd = torch.empty(packed_weight_floats(cout, cin_k), device=w.device, dtype=torch.float32)
     bwd = torch.empty(packed_weight_floats(cin_k, cout), device=w.device, dtype=torch.float32) if want_bwd else None
     code = lib.larva_pack_weights(w.data_ptr(), fwd.data_ptr(), bwd.data_ptr() if want_bwd else None,
@@ -98,8 +98,8 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     if cout not in _SUPPORTED_COUT:
         raise RuntimeError("larvanet_amd: cout must be one of %s" % (_SUPPORTED_COUT,))
     N, cps, H, W = (int(v) for v in srcs[0].shape)
-    if cps % 16:
-        raise RuntimeError("larvanet_amd: input channels per tensor must be a multiple of 16")
+    if cps % 8:
+        raise RuntimeError("larvanet_amd: input channels per tensor must be a multiple of 8")
     ptrs = [_chk(s, "src[%d]" % i, (N, cps, H, W)) for i, s in enumerate(srcs)]
     cin = cps * len(srcs)
     _chk(wpk, "wpk", (packed_weight_floats(cout, cin),))
