@@ -108,8 +108,6 @@ struct DmaPlan {
   // floats relative to the chunk's image base (input pieces) or weight base (weight pieces), or
   // -1 when the lane's 16 bytes are zero padding; plus the wave-uniform LDS offset and kind.
   int off[ConvCfg<COUT>::NPW];
-  int lds_off[ConvCfg<COUT>::NPW];
-  unsigned is_w;  // bit i: piece i is a weight piece (wave-uniform)
   unsigned ok;    // bit i: this lane's 16 bytes of piece i come from memory (else zeros)
 };
 
@@ -117,7 +115,7 @@ template <int COUT>
 __device__ __forceinline__ void make_plan(const ConvArgs& a, int wave, int lane, int y0, int x0,
                                           DmaPlan<COUT>& pl) {
   using C = ConvCfg<COUT>;
-  pl.is_w = 0;
+  static_assert(C::NPW <= 32, "validity mask is 32 bits");
   pl.ok = 0;
 #pragma unroll
   for (int i = 0; i < C::NPW; ++i) {
@@ -137,11 +135,8 @@ __device__ __forceinline__ void make_plan(const ConvArgs& a, int wave, int lane,
     const bool isw = p >= C::IN_PIECES;  // wave-uniform
     const bool ok = isw ? w_ok : in_ok;
     pl.off[i] = ok ? (isw ? ws * 4 : in_off) : 0;
-    pl.lds_off[i] = isw ? C::IN_FLOATS + (p - C::IN_PIECES) * 256 : p * 256;
-    pl.is_w |= (isw ? 1u : 0u) << i;
     pl.ok |= (ok ? 1u : 0u) << i;
   }
-  pl.is_w = __builtin_amdgcn_readfirstlane(pl.is_w);
 }
 
 struct ChunkSrc {
@@ -164,14 +159,15 @@ __device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int 
 // One 1 KiB piece: lane l's 16 bytes go to stage + lds_off + 16 l.  Branch-free source select
 // (integer arithmetic on purpose: a pointer ternary becomes exec-masked branches here).
 template <int COUT>
-__device__ __forceinline__ void dma_piece(const DmaPlan<COUT>& pl, int i, const float* img, const float* wgt,
-                                          float* stage) {
-  const bool isw = (pl.is_w >> i) & 1u;  // scalar
+__device__ __forceinline__ void dma_piece(const DmaPlan<COUT>& pl, int i, int wave, const float* img,
+                                          const float* wgt, float* stage) {
+  using C = ConvCfg<COUT>;
+  const int p = min(wave + 4 * i, C::PIECES - 1);  // scalar; weight pieces follow the input pieces in LDS
+  const bool isw = p >= C::IN_PIECES;
   const uint64_t base = reinterpret_cast<uint64_t>(isw ? wgt : img);
   const uint64_t zero = reinterpret_cast<uint64_t>(&g_zero_page[0]);
   const uint64_t addr = ((pl.ok >> i) & 1u) ? base + 4ull * (uint32_t)pl.off[i] : zero;
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)addr,
-                                   (__attribute__((address_space(3))) void*)(stage + pl.lds_off[i]), 16, 0, 0);
+  lds_dma<16>(reinterpret_cast<const void*>(addr), stage + p * 256);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -262,9 +258,9 @@ __device__ __forceinline__ void read_operands(const float* a_base, const float* 
 // MFMAs; the sched_barriers pin "reads of s+1, [one LDS-DMA piece], MFMAs of s").
 // PREFETCH: the wave's NPW LDS-DMA pieces of the chunk two ahead are issued between k-steps.
 template <int COUT, int NCT, int PG0, int NPG, bool PREFETCH>
-__device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int lane, f32x4 (&acc)[NCT][NPG],
-                                           const DmaPlan<COUT>& pl, const float* nxt_img, const float* nxt_wgt,
-                                           float* nxt_stage, bool do_prefetch) {
+__device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave, int lane,
+                                           f32x4 (&acc)[NCT][NPG], const DmaPlan<COUT>& pl, const float* nxt_img,
+                                           const float* nxt_wgt, float* nxt_stage) {
   using C = ConvCfg<COUT>;
   const int lr = lane & 15, lq = lane >> 4;
   const float* a_base = stage + C::IN_FLOATS + lq * C::CS + lr + ct0 * 16;
@@ -277,9 +273,10 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int lane
     if (step + 1 < C::STEPS)
       read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
     if constexpr (PREFETCH) {
-      if (step % kEvery == 0 && step / kEvery < C::NPW) {
-        if (do_prefetch) dma_piece<COUT>(pl, step / kEvery, nxt_img, nxt_wgt, nxt_stage);
-      }
+      // unconditional (no branch inside the unrolled loop: a control-flow join makes hipcc wait
+      // lgkmcnt(0), i.e. for the operand reads it has just issued)
+      if (step % kEvery == 0 && step / kEvery < C::NPW)
+        dma_piece<COUT>(pl, step / kEvery, wave, nxt_img, nxt_wgt, nxt_stage);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -328,29 +325,38 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     // ---- LDS-DMA ring: chunk c lives in stage c % 3; chunks c+1 and c+2 are in flight --------
     DmaPlan<COUT> pl;
     make_plan<COUT>(a, wave, lane, y0, x0, pl);
+    // Chunk c is followed in the ring by chunk c+1 and c+2; past the end the last chunk is simply
+    // streamed again into a stage nobody reads any more, which keeps every wait the same counted
+    // vmcnt(NPW) and the MFMA loop free of branches.
+    const int last = a.n_chunks - 1;
     if constexpr (!(LARVA_DIAG & 2)) {
-      const int pre = a.n_chunks < 2 ? a.n_chunks : 2;
-      for (int c = 0; c < pre; ++c) {
-        const ChunkSrc cs = chunk_src<COUT>(a, c, n);
 #pragma unroll
-        for (int i = 0; i < C::NPW; ++i) dma_piece<COUT>(pl, i, cs.img, cs.wgt, smem + c * C::STAGE_FLOATS);
+      for (int c = 0; c < 2; ++c) {
+        const ChunkSrc cs = chunk_src<COUT>(a, min(c, last), n);
+#pragma unroll
+        for (int i = 0; i < C::NPW; ++i) dma_piece<COUT>(pl, i, wave, cs.img, cs.wgt, smem + c * C::STAGE_FLOATS);
       }
     }
     int stage = 0;
-    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+    for (int chunk = 0; chunk <= last; ++chunk) {
       // The chunk's own pieces have landed (the NPW youngest operations belong to chunk+1) and,
       // after the barrier, everybody's have, and everybody is done with the stage that
       // chunk+2 is about to overwrite.
-      if (chunk + 1 < a.n_chunks) wait_and_barrier<C::NPW>();
-      else wait_and_barrier<0>();
-      const bool more = (chunk + 2 < a.n_chunks) && !(LARVA_DIAG & 2);
-      const ChunkSrc nxt = chunk_src<COUT>(a, more ? chunk + 2 : chunk, n);
+      wait_and_barrier<(LARVA_DIAG & 2) ? 0 : C::NPW>();
+      const ChunkSrc nxt = chunk_src<COUT>(a, min(chunk + 2, last), n);
       const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
-      if constexpr (!(LARVA_DIAG & 1))
-        mfma_chunk<COUT, NCT, PG0, NPG, true>(smem + stage * C::STAGE_FLOATS, ct0, lane, acc, pl, nxt.img, nxt.wgt,
-                                              smem + nstage * C::STAGE_FLOATS, more);
+      if constexpr (!(LARVA_DIAG & 1)) {
+        if constexpr (!(LARVA_DIAG & 2))
+          mfma_chunk<COUT, NCT, PG0, NPG, true>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt.img,
+                                                nxt.wgt, smem + nstage * C::STAGE_FLOATS);
+        else
+          mfma_chunk<COUT, NCT, PG0, NPG, false>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt.img,
+                                                 nxt.wgt, smem + nstage * C::STAGE_FLOATS);
+      }
       stage = stage == 2 ? 0 : stage + 1;
     }
+    // no LDS-DMA may be in flight when the workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     // ---- register staging, 2 stages ------------------------------------------------------------
     RegStaging<COUT> st;
@@ -367,7 +373,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         if (more) reg_load<COUT>(a, chunk_src<COUT>(a, chunk + 1, n), y0, x0, tid, st);
       }
       if constexpr (!(LARVA_DIAG & 1))
-        mfma_chunk<COUT, NCT, PG0, NPG, false>(cur, ct0, lane, acc, DmaPlan<COUT>{}, nullptr, nullptr, nullptr, false);
+        mfma_chunk<COUT, NCT, PG0, NPG, false>(cur, ct0, wave, lane, acc, DmaPlan<COUT>{}, nullptr, nullptr, nullptr);
       if constexpr (!(LARVA_DIAG & 2)) {
         if (more) reg_store<COUT>(nxt, tid, st);
       }

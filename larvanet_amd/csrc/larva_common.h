@@ -40,4 +40,29 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return base + (b >> 3);
 }
 
+// LDS-DMA (global_load_lds_*): lane l's BYTES bytes at `gsrc` land at LDS byte address
+// lds_base + BYTES * l.  Issued through inline asm on purpose: with the compiler builtin in a
+// loop, hipcc (ROCm 7.2) turns every counted lgkmcnt(N) in front of the MFMAs into lgkmcnt(0),
+// i.e. waits for the operand reads it has only just issued.  The statement saves/restores M0
+// (compiler-reserved) and pads the SALU-write-M0 -> LDS-DMA hazard itself; the DMA is invisible
+// to hipcc's vmcnt bookkeeping, so callers count it by hand (s_waitcnt vmcnt(N)) and drain it
+// with vmcnt(0) before the workgroup ends.
+template <int BYTES>
+__device__ __forceinline__ void lds_dma(const void* gsrc, float* lds_dst_wave_uniform) {
+  static_assert(BYTES == 16 || BYTES == 4, "LDS-DMA widths used here");
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds_dst_wave_uniform));
+  unsigned keep;
+  if constexpr (BYTES == 16)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
 }  // namespace larva

@@ -5,10 +5,11 @@
 //   db[co]             = sum_{n,y,x} dy[n][co][y][x]
 //
 // as a split-K GEMM on v_mfma_f32_16x16x4_f32: M = co, N = (ci, tap), K = pixels.  A workgroup
-// walks a contiguous run of 3x48-pixel tiles; per tile it stages dy (3 rows) and x (5 halo rows)
-// in LDS, and every wave keeps the accumulators of ALL co groups x its share of the (ci group,
-// tap) operands in registers across the whole run, so a partial image is written exactly once
-// per workgroup.  A second, batched kernel sums the per-workgroup partial images in a fixed
+// walks a contiguous run of 1x48-pixel tiles; per tile dy (1 row) and x (3 halo rows) are
+// streamed into a 2-stage LDS ring by LDS-DMA (no staging registers), the next tile landing
+// under the current tile's MFMAs; every wave keeps the accumulators of ALL co groups x its share
+// of the (ci group, tap) operands in registers across the whole run, so a partial image is
+// written exactly once per workgroup.  A second, batched kernel sums the per-workgroup partial images in a fixed
 // order (bitwise reproducible, no float atomics) and writes the PyTorch-layout gradient.
 //
 // Several layers are processed by ONE launch (blockIdx.y = job): in the backward pass no
@@ -35,159 +36,125 @@ struct WgradBatch {
   int vec_ok;
 };
 
-template <int COUT, int CIN>
+// Source of every LDS-DMA lane that is zero padding (outside the image, or layout padding).
+__device__ __attribute__((aligned(16))) float g_wg_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+// One tile = ONE image row x 48 columns (12 k-steps of 4 pixels).  Per tile the stage holds
+//   dy [COUT][PSD = 52]            (48 pixels + 4 pad)
+//   x  [CIN][3 halo rows][kRS] at channel stride PSX = 172 (row idx 3 = x0-1, 4..51 = x0..x0+47, 52 = x0+48)
+// in 1 KiB (VEC: 16 B per lane) or 256 B (!VEC: 4 B per lane) LDS-DMA pieces.  Channel strides
+// are multiples of 4 floats (DMA lanes are 16-byte slots) with stride/4 odd: the 16 channels x 2
+// pixels of a 32-lane ds_read_b32 group then fall on 16 banks, 2 lanes each -- a 2-way conflict
+// that costs nothing here (10 LDS reads per 21 MFMAs).
+template <int COUT, int CIN, bool VEC>
 struct WgCfg {
   static constexpr int CT = COUT / 16;
   static constexpr int NB = (CIN / 16) * 9;  // B operands: (ci group, tap)
-  static constexpr int NBW = (NB + 3) / 4;   // per wave (last waves may own one fewer)
-  // Channel strides == 2*odd (mod 32): 16 channels x 2 adjacent pixels hit 32 distinct banks.
-  static constexpr int PSD = 146;            // dy: 3 rows x 48
-  static constexpr int PSX = 278;            // x : 5 rows x kRS (tail of the last row unused)
-  static constexpr int DY_FLOATS = COUT * PSD;
-  static constexpr int X_FLOATS = CIN * PSX + 8;
-  static constexpr size_t LDS_BYTES = (DY_FLOATS + X_FLOATS) * sizeof(float);
-  static constexpr int DY_SLOTS = COUT * kTileRows * (kTileCols / 4);
-  static constexpr int X_SLOTS = CIN * kHaloRows * (kRS / 4);
-  static constexpr int DY_ITERS = (DY_SLOTS + 255) / 256;
-  static constexpr int X_ITERS = (X_SLOTS + 255) / 256;
+  static constexpr int PSD = 52;
+  static constexpr int PSX = 172;
+  static constexpr int EL = VEC ? 4 : 1;               // floats per DMA lane
+  static constexpr int PIECE = 64 * EL;                // floats per DMA instruction
+  static constexpr int DY_PIECES = (COUT * PSD + PIECE - 1) / PIECE;
+  static constexpr int X_PIECES = (CIN * PSX + PIECE - 1) / PIECE;
+  static constexpr int DY_FLOATS = DY_PIECES * PIECE;
+  static constexpr int X_FLOATS = X_PIECES * PIECE;
+  static constexpr int PIECES = DY_PIECES + X_PIECES;
+  static constexpr int NPW = (PIECES + 3) / 4;         // pieces per wave per tile
+  static constexpr int STAGE_FLOATS = DY_FLOATS + X_FLOATS;
+  static constexpr size_t LDS_BYTES = 2 * STAGE_FLOATS * sizeof(float);
+  static constexpr int KSTEPS = kTileCols / 4;         // 12
+  static constexpr int PER_STEP = (NPW + KSTEPS - 1) / KSTEPS;
   static constexpr int PARTIAL_FLOATS = NB * CT * 256 + COUT;
 };
 
-template <int COUT, int CIN>
-struct WgStaging {
-  f32x4 dy[WgCfg<COUT, CIN>::DY_ITERS];
-  f32x4 x[WgCfg<COUT, CIN>::X_ITERS];
-  uint32_t ok_dy, ok_x;
+template <int COUT, int CIN, bool VEC>
+struct WgPlan {
+  // piece i of this wave: lane's source offset (floats) relative to dy/x at (image n, row y,
+  // column 0), LDS offset, and validity classes (bit i): always-padding lanes have no bit set.
+  int off[WgCfg<COUT, CIN, VEC>::NPW];
+  unsigned long long ok_mid;    // valid whatever the row
+  unsigned long long need_top;  // valid only if row y-1 exists
+  unsigned long long need_bot;  // valid only if row y+1 exists
 };
 
 template <int COUT, int CIN, bool VEC>
-__device__ __forceinline__ void wg_load(const WgradBatch& b, const WgradJob& j, int tile, int tid,
-                                        WgStaging<COUT, CIN>& st) {
-  using C = WgCfg<COUT, CIN>;
-  const int tx = tile % b.tiles_x;
-  const int t2 = tile / b.tiles_x;
-  const int ty = t2 % b.tiles_y;
-  const int n = t2 / b.tiles_y;
-  const int x0 = tx * kTileCols, y0 = ty * kTileRows;
-  const size_t plane = (size_t)b.H * b.W;
-  uint32_t ok_dy = 0, ok_x = 0;
-  const float* dyimg = j.dy + (size_t)n * COUT * plane;
+__device__ __forceinline__ void wg_make_plan(const WgradBatch& b, int wave, int lane, int x0,
+                                             WgPlan<COUT, CIN, VEC>& pl) {
+  using C = WgCfg<COUT, CIN, VEC>;
+  static_assert(C::NPW <= 64, "validity masks are 64 bits");
+  pl.ok_mid = pl.need_top = pl.need_bot = 0;
 #pragma unroll
-  for (int i = 0; i < C::DY_ITERS; ++i) {
-    int s = tid + i * 256;
-    const bool live = s < C::DY_SLOTS;
-    s = live ? s : 0;
-    const int co = s / (kTileRows * 12);
-    const int rem = s - co * (kTileRows * 12);
-    const int r = rem / 12;
-    const int q = rem - r * 12;
-    const int gy = y0 + r, gx = x0 + 4 * q;
-    const bool row_ok = live && gy < b.H;
-    const float* row = dyimg + (size_t)co * plane + (size_t)min(gy, b.H - 1) * b.W;
-    f32x4 v;
-    if constexpr (VEC) {
-      v = *reinterpret_cast<const f32x4*>(row + min(gx, b.W - 4));
-      ok_dy |= ((row_ok && gx < b.W) ? 1u : 0u) << i;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (row_ok && gx + e < b.W) ? row[min(gx + e, b.W - 1)] : 0.f;
-    }
-    st.dy[i] = v;
+  for (int i = 0; i < C::NPW; ++i) {
+    const int p = min(wave + 4 * i, C::PIECES - 1);
+    const bool isx = p >= C::DY_PIECES;
+    // dy element
+    const int de = (p * 64 + lane) * C::EL;
+    const int dco = de / C::PSD, dcol = de - dco * C::PSD;
+    const bool d_ok = dco < COUT && dcol < kTileCols && x0 + dcol < b.W;
+    const int d_off = dco * b.H * b.W + x0 + dcol;
+    // x element
+    const int xe = ((p - C::DY_PIECES) * 64 + lane) * C::EL;
+    const int xci = xe / C::PSX, xrem = xe - xci * C::PSX;
+    const int xr = xrem / kRS, xidx = xrem - xr * kRS;
+    const int gx = x0 - 4 + xidx;
+    const bool x_ok = xci < CIN && xr < 3 && gx >= 0 && gx < b.W;
+    const int x_off = (xci * b.H + (xr - 1)) * b.W + gx;
+    const bool ok = isx ? x_ok : d_ok;
+    pl.off[i] = ok ? (isx ? x_off : d_off) : 0;
+    const unsigned long long bit = (ok ? 1ull : 0ull) << i;
+    if (isx && xr == 0) pl.need_top |= bit;
+    else if (isx && xr == 2) pl.need_bot |= bit;
+    else pl.ok_mid |= bit;
   }
-  const float* ximg = j.x + (size_t)n * CIN * plane;
-#pragma unroll
-  for (int i = 0; i < C::X_ITERS; ++i) {
-    int s = tid + i * 256;
-    const bool live = s < C::X_SLOTS;
-    s = live ? s : 0;
-    const int ci = s / (kHaloRows * 14);
-    const int rem = s - ci * (kHaloRows * 14);
-    const int r = rem / 14;
-    const int q = rem - r * 14;
-    const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
-    const bool row_ok = live && gy >= 0 && gy < b.H;
-    const float* row = ximg + (size_t)ci * plane + (size_t)min(max(gy, 0), b.H - 1) * b.W;
-    f32x4 v;
-    if constexpr (VEC) {
-      v = *reinterpret_cast<const f32x4*>(row + min(max(gx, 0), b.W - 4));
-      ok_x |= ((row_ok && gx >= 0 && gx < b.W) ? 1u : 0u) << i;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int x = gx + e;
-        v[e] = (row_ok && x >= 0 && x < b.W) ? row[min(max(x, 0), b.W - 1)] : 0.f;
-      }
-    }
-    st.x[i] = v;
-  }
-  st.ok_dy = ok_dy;
-  st.ok_x = ok_x;
 }
 
-__device__ __forceinline__ void lds_store4(float* p, f32x4 v) {
-  // Channel bases are only 8-byte aligned (odd strides/2), so two 8-byte stores.
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
-  *reinterpret_cast<f32x2*>(p + 2) = f32x2{v[2], v[3]};
-}
+struct WgTile {
+  const float* dy;  // dy at (n, channel 0, row y, column 0)
+  const float* x;   // x  at (n, channel 0, row y, column 0)
+  unsigned long long ok;  // per-lane validity bits for this tile's rows
+};
 
 template <int COUT, int CIN, bool VEC>
-__device__ __forceinline__ void wg_store(float* s_dy, float* s_x, int tid,
-                                         const WgStaging<COUT, CIN>& st) {
-  using C = WgCfg<COUT, CIN>;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < C::DY_ITERS; ++i) {
-    const int s = tid + i * 256;
-    if (i * 256 + 255 < C::DY_SLOTS || s < C::DY_SLOTS) {
-      const int co = s / (kTileRows * 12);
-      const int rem = s - co * (kTileRows * 12);
-      const int r = rem / 12;
-      const int q = rem - r * 12;
-      f32x4 v = st.dy[i];
-      if constexpr (VEC) v = ((st.ok_dy >> i) & 1u) ? v : zero;
-      lds_store4(s_dy + co * C::PSD + r * kTileCols + 4 * q, v);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < C::X_ITERS; ++i) {
-    const int s = tid + i * 256;
-    if (i * 256 + 255 < C::X_SLOTS || s < C::X_SLOTS) {
-      const int ci = s / (kHaloRows * 14);
-      const int rem = s - ci * (kHaloRows * 14);
-      const int r = rem / 14;
-      const int q = rem - r * 14;
-      f32x4 v = st.x[i];
-      if constexpr (VEC) v = ((st.ok_x >> i) & 1u) ? v : zero;
-      lds_store4(s_x + ci * C::PSX + r * kRS + 4 * q, v);
-    }
-  }
+__device__ __forceinline__ void wg_dma_piece(const WgPlan<COUT, CIN, VEC>& pl, int i, int wave, const WgTile& t,
+                                             float* stage) {
+  using C = WgCfg<COUT, CIN, VEC>;
+  const int p = min(wave + 4 * i, C::PIECES - 1);  // scalar; the x pieces follow the dy pieces in LDS
+  const bool isx = p >= C::DY_PIECES;
+  float* dst = stage + p * C::PIECE;
+  const uint64_t base = reinterpret_cast<uint64_t>(isx ? t.x : t.dy);
+  const uint64_t zero = reinterpret_cast<uint64_t>(&g_wg_zero_page[0]);
+  // 64-bit signed offset: the x base may sit one row before the tensor start for row y-1 of y = 0
+  // (those lanes are invalid and read the zero page instead).
+  const uint64_t addr = ((t.ok >> i) & 1ull) ? base + 4ll * (long long)pl.off[i] : zero;
+  lds_dma<VEC ? 16 : 4>(reinterpret_cast<const void*>(addr), dst);
 }
 
-// k-step `ks` of a tile covers pixels (row = ks / 12, cols 4*(ks%12) .. +3).
-template <int COUT, int CIN, int B0, int NBW>
+// k-step `ks` covers pixels (4 ks .. 4 ks + 3) of the tile's row.
+template <int COUT, int CIN, bool VEC, int B0, int NBW>
 __device__ __forceinline__ void wg_read(const float* a_base, const float* b_base, int ks,
                                         float (&av)[COUT / 16], float (&bv)[NBW]) {
-  using C = WgCfg<COUT, CIN>;
-  const int row = ks / 12, col = 4 * (ks % 12);
+  using C = WgCfg<COUT, CIN, VEC>;
+  const int col = 4 * ks;
 #pragma unroll
-  for (int c = 0; c < C::CT; ++c) av[c] = a_base[c * 16 * C::PSD + row * kTileCols + col];
+  for (int c = 0; c < C::CT; ++c) av[c] = a_base[c * 16 * C::PSD + col];
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
     const int bi = B0 + j, cit = bi / 9, tap = bi % 9, ky = tap / 3, kx = tap % 3;
-    bv[j] = b_base[cit * 16 * C::PSX + (row + ky) * kRS + col + kx];
+    bv[j] = b_base[cit * 16 * C::PSX + ky * kRS + col + kx];
   }
+}
+
+template <int KEEP>
+__device__ __forceinline__ void wg_wait_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int COUT, int CIN, bool VEC, int B0, int NBW>
 __device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, float* smem,
-                                        int split, int splits, int tid, bool bias_wave) {
-  using C = WgCfg<COUT, CIN>;
+                                        int split, int splits, int wave, int tid, bool bias_wave) {
+  using C = WgCfg<COUT, CIN, VEC>;
   const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
-  float* s_dy = smem;
-  float* s_x = smem + C::DY_FLOATS;
-  const float* a_base = s_dy + lr * C::PSD + lq;
-  const float* b_base = s_x + lr * C::PSX + lq + 3;
 
   f32x4 acc[C::CT][NBW];
 #pragma unroll
@@ -198,28 +165,56 @@ __device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, 
 #pragma unroll
   for (int c = 0; c < C::CT; ++c) bsum[c] = 0.f;
 
-  const int total = b.N * b.tiles_x * b.tiles_y;
+  // tiles are (n, y, tx) with tx fastest; this workgroup owns a contiguous run
+  const int total = b.N * b.H * b.tiles_x;
   const int t_begin = (int)(((long long)total * split) / splits);
   const int t_end = (int)(((long long)total * (split + 1)) / splits);
+  const size_t plane = (size_t)b.H * b.W;
 
-  // The next tile's global loads ride in registers under the MFMA block of the current one;
-  // at 64x64 channels accumulators + staging exceed the register file, so that shape loads
-  // its tile synchronously instead.
-  constexpr bool kPrefetch = (COUT * CIN <= 48 * 48);
-  WgStaging<COUT, CIN> st;
-  if (kPrefetch && t_begin < t_end) wg_load<COUT, CIN, VEC>(b, j, t_begin, tid, st);
+  WgPlan<COUT, CIN, VEC> pl;
+  int plan_tx = -1;
+  auto tile_of = [&](int t, WgTile& wt) {
+    const int tx = t % b.tiles_x;
+    const int t2 = t / b.tiles_x;
+    const int y = t2 % b.H;
+    const int n = t2 / b.H;
+    if (tx != plan_tx) {  // wave-uniform; only ever re-planned for images wider than one tile
+      wg_make_plan<COUT, CIN, VEC>(b, wave, lane, tx * kTileCols, pl);
+      plan_tx = tx;
+    }
+    wt.dy = j.dy + (size_t)n * COUT * plane + (size_t)y * b.W;
+    wt.x = j.x + (size_t)n * CIN * plane + (size_t)y * b.W;
+    wt.ok = pl.ok_mid | (y > 0 ? pl.need_top : 0ull) | (y + 1 < b.H ? pl.need_bot : 0ull);
+  };
+
+  WgTile cur{}, nxt{};
+  if (t_begin < t_end) {
+    tile_of(t_begin, cur);
+#pragma unroll
+    for (int i = 0; i < C::NPW; ++i) wg_dma_piece<COUT, CIN, VEC>(pl, i, wave, cur, smem);
+  }
   for (int t = t_begin; t < t_end; ++t) {
-    if (!kPrefetch) wg_load<COUT, CIN, VEC>(b, j, t, tid, st);
-    __syncthreads();  // every wave is done reading the previous tile
-    wg_store<COUT, CIN, VEC>(s_dy, s_x, tid, st);
-    __syncthreads();
-    if (kPrefetch && t + 1 < t_end) wg_load<COUT, CIN, VEC>(b, j, t + 1, tid, st);
+    // tile t has landed (every wave's pieces, after the barrier) and every wave is done with the
+    // other stage, which tile t+1 now streams into underneath this tile's MFMAs.  Past the end
+    // the last tile is streamed once more (nobody reads it): no branch inside the MFMA loop.
+    wg_wait_and_barrier<0>();
+    float* stage = smem + ((t - t_begin) & 1) * C::STAGE_FLOATS;
+    float* ostage = smem + (((t - t_begin) & 1) ^ 1) * C::STAGE_FLOATS;
+    tile_of(min(t + 1, t_end - 1), nxt);
+    const float* a_base = stage + lr * C::PSD + lq;
+    const float* b_base = stage + C::DY_FLOATS + lr * C::PSX + lq + 3;
 
     float av[2][C::CT], bv[2][NBW];
-    wg_read<COUT, CIN, B0, NBW>(a_base, b_base, 0, av[0], bv[0]);
+    wg_read<COUT, CIN, VEC, B0, NBW>(a_base, b_base, 0, av[0], bv[0]);
 #pragma unroll
-    for (int ks = 0; ks < 36; ++ks) {
-      if (ks + 1 < 36) wg_read<COUT, CIN, B0, NBW>(a_base, b_base, ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      if (ks + 1 < C::KSTEPS)
+        wg_read<COUT, CIN, VEC, B0, NBW>(a_base, b_base, ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+#pragma unroll
+      for (int u = 0; u < C::PER_STEP; ++u) {
+        const int i = ks * C::PER_STEP + u;
+        if (i < C::NPW) wg_dma_piece<COUT, CIN, VEC>(pl, i, wave, nxt, ostage);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < C::CT; ++c)
@@ -233,6 +228,8 @@ __device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, 
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // no LDS-DMA may be in flight when the workgroup's LDS is released
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // Partial image: [b][ct][lane][4] = the accumulator registers as they stand (1 KiB per tile
   // per store instruction, fully coalesced).  acc[c][k][r] = dW[co = 16c + 4lq + r][ci = 16*cit + lr][tap].
@@ -253,9 +250,11 @@ __device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, 
   }
 }
 
+// 2 waves/SIMD launch bound: <= 256 registers, so a conv workgroup (72 KiB LDS, < 128 VGPRs)
+// fits on the same CU beside this one (86 KiB LDS at 48 channels).
 template <int COUT, int CIN, bool VEC>
-__global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(WgradBatch b) {
-  using C = WgCfg<COUT, CIN>;
+__global__ __launch_bounds__(256, (VEC && COUT * CIN <= 48 * 48) ? 2 : 1) void wgrad3x3_kernel(WgradBatch b) {
+  using C = WgCfg<COUT, CIN, VEC>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WgradJob& j = b.job[blockIdx.y];
   const int tid = threadIdx.x;
@@ -265,10 +264,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(WgradBatch b) {
   // 27 -> 7,7,7,6; 36 -> 9,9,9,9.
   constexpr int NB = C::NB;
   constexpr int W0 = (NB + 3) / 4, W1 = (NB + 2) / 4, W2 = (NB + 1) / 4, W3 = NB / 4;
-  if (wave == 0) wg_role<COUT, CIN, VEC, 0, W0>(b, j, smem, split, splits, tid, true);
-  else if (wave == 1) wg_role<COUT, CIN, VEC, W0, W1>(b, j, smem, split, splits, tid, false);
-  else if (wave == 2) wg_role<COUT, CIN, VEC, W0 + W1, W2>(b, j, smem, split, splits, tid, false);
-  else wg_role<COUT, CIN, VEC, W0 + W1 + W2, W3>(b, j, smem, split, splits, tid, false);
+  if (wave == 0) wg_role<COUT, CIN, VEC, 0, W0>(b, j, smem, split, splits, wave, tid, true);
+  else if (wave == 1) wg_role<COUT, CIN, VEC, W0, W1>(b, j, smem, split, splits, wave, tid, false);
+  else if (wave == 2) wg_role<COUT, CIN, VEC, W0 + W1, W2>(b, j, smem, split, splits, wave, tid, false);
+  else wg_role<COUT, CIN, VEC, W0 + W1 + W2, W3>(b, j, smem, split, splits, wave, tid, false);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -327,21 +326,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceBatch rb) {
 
 template <int COUT, int CIN>
 static hipError_t launch_wgrad(const WgradBatch& b, int njobs, int splits, hipStream_t stream) {
-  using C = WgCfg<COUT, CIN>;
+  constexpr size_t lds_v = WgCfg<COUT, CIN, true>::LDS_BYTES, lds_s = WgCfg<COUT, CIN, false>::LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_v);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if (b.vec_ok)
-    hipLaunchKernelGGL((wgrad3x3_kernel<COUT, CIN, true>), dim3(splits, njobs), dim3(256), C::LDS_BYTES, stream, b);
+    hipLaunchKernelGGL((wgrad3x3_kernel<COUT, CIN, true>), dim3(splits, njobs), dim3(256), lds_v, stream, b);
   else
-    hipLaunchKernelGGL((wgrad3x3_kernel<COUT, CIN, false>), dim3(splits, njobs), dim3(256), C::LDS_BYTES, stream, b);
+    hipLaunchKernelGGL((wgrad3x3_kernel<COUT, CIN, false>), dim3(splits, njobs), dim3(256), lds_s, stream, b);
   return hipGetLastError();
 }
 
@@ -379,8 +378,9 @@ int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* co
   }
   b.N = N; b.H = H; b.W = W;
   b.tiles_x = (W + kTileCols - 1) / kTileCols;
-  b.tiles_y = (H + kTileRows - 1) / kTileRows;
+  b.tiles_y = H;  // one image row per tile
   b.vec_ok = aligned ? 1 : 0;
+  if ((long long)(cin > cout ? cin : cout) * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
   const int total = N * b.tiles_x * b.tiles_y;
   if (splits > total) splits = total;
   rb.splits = splits; rb.cout = cout; rb.cin = cin;

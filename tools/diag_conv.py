@@ -47,37 +47,30 @@ def main():
     fwd, _ = K.pack_weights(w)
     out = torch.empty_like(x)
     out_hr = torch.empty_like(base)
-    sig = hip_lib.SIGNATURES["larva_conv3x3_fwd"]
+    import ctypes as ct
+    sig = hip_lib.SIGNATURES["larva_conv3x3_fwd_timed"]
     stream = torch.cuda.current_stream().cuda_stream
     epis = {"relu": dict(relu=1), "res1": dict(res0=r0), "res2": dict(res0=r0, res1=r1), "mask": dict(mask=r0),
             "shuffle+base": dict(mode=1, base=base)}
+    print("kernel-attached event timing (mean of 40 launches), us")
     print("%-26s" % "variant" + "".join("%14s" % e for e in epis))
     for v, label in VARIANTS.items():
         lib = ctypes.CDLL(os.path.join(OUT, "libconv_diag%d.so" % v))
-        fn = lib.larva_conv3x3_fwd
+        fn = lib.larva_conv3x3_fwd_timed
         fn.restype, fn.argtypes = sig
         row = []
         for e, kw in epis.items():
-            def call():
-                o = out_hr if kw.get("mode") else out
+            o = out_hr if kw.get("mode") else out
+            mean, best = ct.c_float(0), ct.c_float(0)
+            for iters in (5, 40):
                 code = fn(hip_lib.ptr_array([x.data_ptr()]), 1, 48, fwd.data_ptr(), b.data_ptr(),
                           kw["res0"].data_ptr() if "res0" in kw else None,
                           kw["res1"].data_ptr() if "res1" in kw else None,
                           kw["mask"].data_ptr() if "mask" in kw else None,
                           kw["base"].data_ptr() if "base" in kw else None, o.data_ptr(), 16, 48, 48, 48,
-                          kw.get("relu", 0), kw.get("mode", 0), stream)
+                          kw.get("relu", 0), kw.get("mode", 0), stream, iters, ct.byref(mean), ct.byref(best))
                 assert code == 0, code
-            for _ in range(5):
-                call()
-            torch.cuda.synchronize()
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
-            for s, t in evs:
-                s.record()
-                call()
-                t.record()
-            torch.cuda.synchronize()
-            ms = sorted(s.elapsed_time(t) for s, t in evs)
-            row.append(ms[len(ms) // 2] * 1e3)
+            row.append(mean.value * 1e3)
         print("%-26s" % ("%d %s" % (v, label)) + "".join("%11.1f us" % t for t in row))
 
 
