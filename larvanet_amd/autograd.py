@@ -17,6 +17,63 @@ from . import kernels as K
 _WGRAD_WORKGROUPS = 256
 
 
+class SideStreams:
+    """Concurrency inside one training step.  A conv launch keeps the matrix pipes busy only
+    about half of its duration (tile staging, the store burst and the launch floor are exposed),
+    and the conv / wgrad kernels are sized so that two workgroups share a CU -- so independent
+    work is put on side streams and the hardware overlaps it:
+      * `leg`:   exit i (leg convs + L1) runs beside body i+1, forward and -- because autograd
+                 replays a node on its forward stream -- backward;
+      * `wgrad`: weight-gradient batches (never on the critical path) run beside the dgrad chain.
+    Only active inside `with SideStreams.scope():` (the plugin's forward+backward), which joins
+    every side stream before it returns; anywhere else everything stays on the current stream.
+    Tensors that a side stream still reads are kept referenced until the join, so the caching
+    allocator cannot hand their memory out early (also during hipGraph capture)."""
+
+    active = False
+    _streams = {}
+    _keep = []
+
+    @classmethod
+    def get(cls, name):
+        dev = torch.cuda.current_device()
+        key = (dev, name)
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=dev)
+        return cls._streams[key]
+
+    @classmethod
+    def fork(cls, name, *tensors):
+        """Side stream `name`, ordered after everything issued so far on the current stream."""
+        side = cls.get(name)
+        side.wait_stream(torch.cuda.current_stream())
+        cls._keep.extend(tensors)
+        return side
+
+    @classmethod
+    def keep(cls, *tensors):
+        cls._keep.extend(tensors)
+
+    @classmethod
+    def join(cls):
+        cur = torch.cuda.current_stream()
+        for (dev, _), st in cls._streams.items():
+            if dev == torch.cuda.current_device():
+                cur.wait_stream(st)
+        cls._keep.clear()
+
+    class scope:
+        def __enter__(self):
+            SideStreams.active = torch.cuda.is_available()
+            return self
+
+        def __exit__(self, *exc):
+            if SideStreams.active:
+                SideStreams.join()
+            SideStreams.active = False
+            return False
+
+
 class PackedConv:
     """Kernel-layout images of one conv weight in persistent device buffers.
 
@@ -103,18 +160,34 @@ def _splits(njobs):
 
 
 def _wgrad(jobs, cout, cin):
-    """jobs: list of (dy, x, weight_like_for_shape, cin_off, cin_valid, want_bias) ->
-    list of (dw, db) fresh tensors."""
+    """jobs: list of (dy, x, weight shape, cin_off, cin_valid, shared dw or None) ->
+    list of (dw, db) fresh tensors.  Inside a SideStreams scope the launches go to the wgrad
+    side stream (the results are first needed by the optimizer, after the scope's join)."""
+    side = None
+    if SideStreams.active:
+        side = SideStreams.fork("wgrad", *[t for j in jobs for t in (j[0], j[1])])
+    ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
     out, batch = [], []
-    for (dy, x, wshape, cin_off, cin_valid, dw_shared) in jobs:
-        dw = dw_shared if dw_shared is not None else torch.empty(wshape, device=dy.device, dtype=torch.float32)
-        db = torch.empty((cout,), device=dy.device, dtype=torch.float32)
-        batch.append({"dy": dy, "x": x, "dw": dw, "db": db, "cin_off": cin_off, "cin_valid": cin_valid})
-        out.append((dw, db))
-    for i in range(0, len(batch), 16):
-        chunk = batch[i:i + 16]
-        K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
+    with ctx:
+        for (dy, x, wshape, cin_off, cin_valid, dw_shared) in jobs:
+            dw = dw_shared if dw_shared is not None else torch.empty(wshape, device=dy.device, dtype=torch.float32)
+            db = torch.empty((cout,), device=dy.device, dtype=torch.float32)
+            batch.append({"dy": dy, "x": x, "dw": dw, "db": db, "cin_off": cin_off, "cin_valid": cin_valid})
+            out.append((dw, db))
+        for i in range(0, len(batch), 16):
+            chunk = batch[i:i + 16]
+            parts = K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
+            if side is not None:
+                SideStreams.keep(*parts)
     return out
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 class HeadFn(torch.autograd.Function):

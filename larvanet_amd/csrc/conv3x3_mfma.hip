@@ -470,6 +470,9 @@ __global__ __launch_bounds__(256, VEC ? 2 : 1) void conv3x3_mfma_kernel(ConvArgs
   const int x0 = tx * kTileCols, y0 = ty * kTileRows;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Convs form the dependent chain of a step; weight-gradient workgroups that share the CU run
+  // at priority 0 and take the matrix pipe only when these waves cannot use it.
+  __builtin_amdgcn_s_setprio(1);
 
   // 9 pixel groups x CT cout groups, dealt to the 4 waves (one per SIMD) as evenly as a
   // rectangular (cout groups) x (pixel groups) ownership allows.

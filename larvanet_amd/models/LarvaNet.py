@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .. import dist as ldist
 from .. import kernels as K
-from ..autograd import BodyFn, HeadFn, L1LossFn, LegFn, PackedConv, pack_all
+from ..autograd import BodyFn, HeadFn, L1LossFn, LegFn, PackedConv, SideStreams, pack_all
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
 from .base import BaseModel
 
@@ -46,6 +46,14 @@ def _require_hip(t):
     if not t.is_cuda:
         raise RuntimeError("larvanet_amd: the network only runs on a HIP device (MI355X); "
                            "got a %s tensor and there is no CPU fallback" % t.device)
+
+
+class _NoScope:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 class L1Loss(nn.Module):
@@ -191,6 +199,7 @@ class LarvaNet(BaseModel):
         self.volume_per_step = 0
         self.sync_loss = True
         self.use_hip_graph = os.environ.get("LARVA_HIP_GRAPH", "1") != "0"
+        self.use_side_streams = os.environ.get("LARVA_SIDE_STREAMS", "1") != "0"
 
     # ------------------------------------------------------------------ flags
     def _add_args(self, parser):
@@ -244,19 +253,43 @@ class LarvaNet(BaseModel):
             self.scheduler = self._make_scheduler()
 
     # ------------------------------------------------------------------ training
+    def _exit(self, leg, fea, base, truth_tensor):
+        """One exit (leg + its L1 term); on the `leg` side stream when side streams are active, so
+        that it overlaps the next body (forward) and the previous body's backward."""
+        if not SideStreams.active:
+            out = leg(fea, base)
+            return out, self.loss_fn(out, truth_tensor)
+        main = torch.cuda.current_stream()
+        side = SideStreams.fork("leg", fea, base, truth_tensor)
+        with torch.cuda.stream(side):
+            out = leg(fea, base)
+            term = self.loss_fn(out, truth_tensor)
+        SideStreams.keep(out, term)
+        self._pending_exit_sync = True
+        return out, term
+
+    def _sync_exits(self):
+        if getattr(self, "_pending_exit_sync", False):
+            torch.cuda.current_stream().wait_stream(SideStreams.get("leg"))
+            self._pending_exit_sync = False
+
     def _exit_losses(self, input_tensor, truth_tensor):
         """Forward through every exit (models/LarvaNet.py:102-109). Returns (loss, last output)."""
         net = self.model
         net.refresh_packed_weights()
         fea = net.head(input_tensor)
         base = net.base(input_tensor)
-        loss = 0
+        terms = []
         out = None
         for i in range(self.args.num_modules):
             body = getattr(net, "body_%d" % i)
             fea = body(fea)
-            out = body.leg(fea, base)
-            loss = loss + self.loss_fn(out, truth_tensor)
+            out, term = self._exit(body.leg, fea, base, truth_tensor)
+            terms.append(term)
+        self._sync_exits()
+        loss = 0
+        for term in terms:
+            loss = loss + term
         return loss / self.args.num_modules, out
 
     # hipGraph path: one step issues ~330 short kernels; launched one by one from Python the GPU
@@ -272,14 +305,16 @@ class LarvaNet(BaseModel):
         with torch.cuda.stream(side):
             for _ in range(2):  # warm-up outside capture (lazy kernel attributes, allocator pools)
                 self.optim.zero_grad(set_to_none=True)
-                loss, _ = self._exit_losses(self._static_in, self._static_truth)
-                loss.backward()
+                with SideStreams.scope() if self.use_side_streams else _NoScope():
+                    loss, _ = self._exit_losses(self._static_in, self._static_truth)
+                    loss.backward()
         torch.cuda.current_stream().wait_stream(side)
         self.optim.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            loss, out = self._exit_losses(self._static_in, self._static_truth)
-            loss.backward()
+            with SideStreams.scope() if self.use_side_streams else _NoScope():
+                loss, out = self._exit_losses(self._static_in, self._static_truth)
+                loss.backward()
         self._graph, self._graph_loss, self._graph_out = graph, loss, out
         self._graph_shape = self._graph_key(input_tensor, truth_tensor)
 
@@ -292,9 +327,10 @@ class LarvaNet(BaseModel):
             self._static_truth.copy_(truth_tensor)
             self._graph.replay()  # gradients are overwritten in place: no zero_grad needed
             return self._graph_loss, self._graph_out
-        loss, out = self._exit_losses(input_tensor, truth_tensor)
         self.optim.zero_grad()
-        loss.backward()
+        with SideStreams.scope() if self.use_side_streams else _NoScope():
+            loss, out = self._exit_losses(input_tensor, truth_tensor)
+            loss.backward()
         return loss, out
 
     def train_step_larva(self, args, val_dataloader, input_tensor, truth_tensor, summary=None):

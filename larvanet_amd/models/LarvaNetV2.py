@@ -97,15 +97,19 @@ class LarvaNet(V1.LarvaNet):
         net.refresh_packed_weights()
         fea = net.head(input_tensor)
         base = net.base(input_tensor)
-        loss = 0
+        terms = []
         feats = []
         for i in range(self.args.num_modules):
             body = getattr(net, "body_%d" % i)
             fea = body(fea)
             feats.append(fea)
-            loss = loss + self.loss_fn(body.leg(fea, base), truth_tensor)
+            terms.append(self._exit(body.leg, fea, base, truth_tensor)[1])
         out = net.tail(feats, base)
-        loss = loss + self.loss_fn(out, truth_tensor)
+        terms.append(self.loss_fn(out, truth_tensor))
+        self._sync_exits()
+        loss = 0
+        for term in terms:
+            loss = loss + term
         return loss / (self.args.num_modules + 1), out
 
     def restore(self, ckpt_path, target=None):
