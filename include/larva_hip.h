@@ -81,12 +81,19 @@ int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* co
 int larva_bicubic4_fwd(const float* in, float* out, int N, int C, int H, int W, void* stream);
 
 /* ---- L1 loss ---------------------------------------------------------------------------------
- * nn.L1Loss() forward/backward, models/LarvaNet.py:85,108,113.  Pointers 16-byte aligned. */
+ * nn.L1Loss() forward/backward, models/LarvaNet.py:85,108,113.  Pointers 16-byte aligned.  The
+ * forward workspace (larva_l1_workspace_floats() floats) must be zero-filled once at allocation. */
 int larva_l1_workspace_floats(void);
 int larva_l1_fwd(const float* a, const float* b, long long numel, float* partial, float* loss,
                  void* stream);
 int larva_l1_bwd(const float* a, const float* b, const float* gout, long long numel, float* ga,
                  void* stream);
+/* nn.L1Loss backward fused with the nn.PixelShuffle(4) backward of the exit it scores
+ * (models/LarvaNet.py:108,113,261): a, b [N][C][4H][4W] -> ga [N][16C][H][W]. */
+int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, float* ga, int N, int C,
+                            int H, int W, void* stream);
+/* `loss += ...; loss / num_modules` (models/LarvaNet.py:104-109): out = (sum of n <= 8 device scalars) / divisor. */
+int larva_sum_scalars(const float* const* terms, int n, float divisor, float* out, void* stream);
 
 /* ---- PixelShuffle(4) backward (models/LarvaNet.py:261): in [N][C][4H][4W] -> out [N][16C][H][W] */
 int larva_pixel_unshuffle4(const float* in, float* out, int N, int C, int H, int W, void* stream);

@@ -31,6 +31,8 @@ class SideStreams:
     allocator cannot hand their memory out early (also during hipGraph capture)."""
 
     active = False
+    wgrad_on_side = False   # measured: wgrad alone already runs at 95 % of the MFMA peak and only
+                            # slows the conv chain down when it shares the CUs with it
     _streams = {}
     _keep = []
 
@@ -164,7 +166,7 @@ def _wgrad(jobs, cout, cin):
     list of (dw, db) fresh tensors.  Inside a SideStreams scope the launches go to the wgrad
     side stream (the results are first needed by the optimizer, after the scope's join)."""
     side = None
-    if SideStreams.active:
+    if SideStreams.active and SideStreams.wgrad_on_side:
         side = SideStreams.fork("wgrad", *[t for j in jobs for t in (j[0], j[1])])
     ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
     out, batch = [], []
@@ -302,6 +304,56 @@ class LegFn(torch.autograd.Function):
         (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c, None), (dyl, h, ctx.wshape, 0, c, None)], c, c)
         # base comes from a parameter-free interpolation of the network input: no gradient
         return dfea, None, None, dw1, db1, dw2, db2
+
+
+class ExitFn(torch.autograd.Function):
+    """One whole exit of the training step: LarvaLeg.forward followed by nn.L1Loss against the
+    truth (models/LarvaNet.py:107-108).  Same kernels as LegFn + L1LossFn, but the backward
+    writes the L1 gradient directly in the pixel-unshuffled layout the leg's dgrad/wgrad read
+    (one fused launch instead of l1_bwd + pixel_unshuffle, no HR-layout gradient tensor).
+    Returns (exit image, loss term); the image output carries no gradient path of its own."""
+
+    @staticmethod
+    def forward(ctx, fea, base, truth, pcs, w1, b1, w2, b2):
+        (f1, _), = pcs[0].get()
+        (f2, _), = pcs[1].get()
+        c = int(w1.shape[0])
+        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True)
+        out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base)
+        term = K.l1_fwd(out, truth)
+        ctx.save_for_backward(fea, h, out, truth)
+        ctx.pcs = pcs
+        ctx.wshape = tuple(w1.shape)
+        ctx.mark_non_differentiable(out)
+        return out, term
+
+    @staticmethod
+    def backward(ctx, _dout, gterm):
+        fea, h, out, truth = ctx.saved_tensors
+        pcs = ctx.pcs
+        c = ctx.wshape[0]
+        (_, bw1), = pcs[0].get()
+        (_, bw2), = pcs[1].get()
+        dyl = K.l1_bwd_unshuffle4(out, truth, gterm.contiguous())
+        dh = K.conv3x3(dyl, bw2, c, mask=h)
+        dfea = K.conv3x3(dh, bw1, c)
+        (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c, None), (dyl, h, ctx.wshape, 0, c, None)], c, c)
+        return dfea, None, None, None, dw1, db1, dw2, db2
+
+
+class MeanTermsFn(torch.autograd.Function):
+    """`loss += term` over the exits and `loss / num_modules` (models/LarvaNet.py:104-109) as one
+    launch; every term receives the same gradient g / n."""
+
+    @staticmethod
+    def forward(ctx, *terms):
+        ctx.n = len(terms)
+        return K.sum_scalars([t.contiguous() for t in terms], float(len(terms)))
+
+    @staticmethod
+    def backward(ctx, g):
+        gm = g / ctx.n
+        return (gm,) * ctx.n
 
 
 class MergeFn(torch.autograd.Function):

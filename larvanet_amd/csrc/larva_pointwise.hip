@@ -76,9 +76,14 @@ __global__ void bicubic4_kernel(const float* __restrict__ in, float* __restrict_
 // ---------------------------------------------------------------------------------------------
 constexpr int kL1Blocks = 1024;
 
+// `ticket` (one uint after the partials) counts finished blocks; the last one adds the
+// partials in index order (reproducible), writes the mean and resets the ticket to 0 for the next
+// call -- the workspace only has to be zeroed once, when it is allocated.
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a,
                                                          const float* __restrict__ b,
-                                                         long long numel, float* __restrict__ partial) {
+                                                         long long numel, float* __restrict__ partial,
+                                                         unsigned* __restrict__ ticket, float inv_numel,
+                                                         float* __restrict__ loss) {
   float s = 0.f;
   const long long n4 = numel >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -92,21 +97,33 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   __shared__ float ws[4];
+  __shared__ bool is_last;
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
-}
-
-__global__ __launch_bounds__(256) void l1_finish_kernel(const float* __restrict__ partial, int n,
-                                                        float inv_numel, float* __restrict__ loss) {
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  if (threadIdx.x == 0) {
+    // write-through store + agent-scope release before taking the ticket (cdna guide, Guideline 16)
+    __hip_atomic_store(&partial[blockIdx.x], (ws[0] + ws[1]) + (ws[2] + ws[3]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1);
+    if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!is_last) return;
+  float tsum = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+    tsum += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  __shared__ float ws[4];
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  for (int o = 32; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o);
   __syncthreads();
-  if (threadIdx.x == 0) *loss = ((ws[0] + ws[1]) + (ws[2] + ws[3])) * inv_numel;
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = tsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *loss = ((ws[0] + ws[1]) + (ws[2] + ws[3])) * inv_numel;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // d/da mean|a-b| * gout = sign(a-b) * gout / numel, sign(0) = 0 (ATen's l1 backward).
@@ -132,6 +149,48 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
       const float d = a[i] - b[i];
       ga[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
     }
+  }
+}
+
+// L1 backward fused with the PixelShuffle(4) backward of the exit it feeds: reads the exit
+// output and the truth in HR layout, writes sign(out - truth) * gout / numel straight into the
+// [N][16C][H][W] layout the leg's dgrad / wgrad consume (no HR-layout gradient tensor).
+__global__ void l1_bwd_unshuffle4_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                         const float* __restrict__ gout, float inv_numel,
+                                         float* __restrict__ out, int planes, int H, int W) {
+  const float g = gout[0] * inv_numel;
+  const int HH = 4 * H;
+  const long long total = (long long)planes * HH * W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % W);
+    const long long t2 = idx / W;
+    const int Y = (int)(t2 % HH);
+    const int p = (int)(t2 / HH);
+    const int y = Y >> 2, i = Y & 3;
+    const size_t src = ((size_t)p * HH + Y) * (4 * W) + 4 * x;
+    const f32x4 va = *reinterpret_cast<const f32x4*>(a + src);
+    const f32x4 vb = *reinterpret_cast<const f32x4*>(b + src);
+    float* o = out + (((size_t)p * 16 + 4 * i) * H + y) * W + x;
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = va[e] - vb[e];
+      o[e * plane] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    }
+  }
+}
+
+// out[0] = (t0 + t1 + ... ) / divisor over up to 8 device scalars, added in index order.
+struct ScalarList {
+  const float* p[8];
+  int n;
+};
+__global__ void sum_scalars_kernel(ScalarList l, float divisor, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < l.n; ++i) s += l.p[i][0];
+    out[0] = s / divisor;
   }
 }
 
@@ -209,18 +268,43 @@ int larva_bicubic4_fwd(const float* in, float* out, int N, int C, int H, int W, 
   return (int)hipGetLastError();
 }
 
-int larva_l1_workspace_floats(void) { return kL1Blocks; }
+int larva_l1_workspace_floats(void) { return kL1Blocks + 4; }
 
-// loss[0] = mean |a - b|; `partial` is a workspace of larva_l1_workspace_floats() floats.
-int larva_l1_fwd(const float* a, const float* b, long long numel, float* partial, float* loss,
+// loss[0] = mean |a - b|; `workspace` holds larva_l1_workspace_floats() floats and must be
+// zero-filled once when it is allocated (it carries a self-resetting block ticket); one launch.
+int larva_l1_fwd(const float* a, const float* b, long long numel, float* workspace, float* loss,
                  void* stream) {
-  if (!a || !b || !partial || !loss || numel <= 0) return (int)hipErrorInvalidValue;
+  if (!a || !b || !workspace || !loss || numel <= 0) return (int)hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return (int)hipErrorInvalidValue;
   int blocks = grid_for(numel / 4, 256);
   if (blocks > kL1Blocks) blocks = kL1Blocks;
-  hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, numel, partial);
-  hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks,
-                     1.0f / (float)numel, loss);
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, numel, workspace,
+                     reinterpret_cast<unsigned*>(workspace + kL1Blocks), 1.0f / (float)numel, loss);
+  return (int)hipGetLastError();
+}
+
+// L1 backward written in the pixel-unshuffled layout: a, b [N][C][4H][4W] -> ga [N][16C][H][W].
+int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, float* ga, int N, int C,
+                            int H, int W, void* stream) {
+  if (!a || !b || !gout || !ga || N <= 0 || C <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return (int)hipErrorInvalidValue;
+  const long long work = (long long)N * C * 4 * H * W;
+  const float inv = 1.0f / (float)(work * 4);
+  hipLaunchKernelGGL(l1_bwd_unshuffle4_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     gout, inv, ga, N * C, H, W);
+  return (int)hipGetLastError();
+}
+
+// out[0] = (sum of n <= 8 device scalars, added in index order) / divisor.
+int larva_sum_scalars(const float* const* terms, int n, float divisor, float* out, void* stream) {
+  if (!terms || n < 1 || n > 8 || !out) return (int)hipErrorInvalidValue;
+  ScalarList l{};
+  for (int i = 0; i < n; ++i) {
+    if (!terms[i]) return (int)hipErrorInvalidValue;
+    l.p[i] = terms[i];
+  }
+  l.n = n;
+  hipLaunchKernelGGL(sum_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, l, divisor, out);
   return (int)hipGetLastError();
 }
 

@@ -186,16 +186,54 @@ def bicubic4(x):
     return out
 
 
+_L1_WORKSPACES = {}
+
+
+def _l1_workspace(device):
+    """Zero-initialised once per (device, stream): it carries the kernel's self-resetting ticket."""
+    lib = hip_lib.load()
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    ws = _L1_WORKSPACES.get(key)
+    if ws is None:
+        ws = torch.zeros(int(lib.larva_l1_workspace_floats()), device=device, dtype=torch.float32)
+        _L1_WORKSPACES[key] = ws
+    return ws
+
+
 def l1_fwd(a, b):
-    """mean |a - b| as a 0-d device tensor."""
+    """mean |a - b| as a 0-d device tensor (one launch)."""
     lib = hip_lib.load()
     _chk(a, "a")
     _chk(b, "b", a.shape)
-    ws = torch.empty(int(lib.larva_l1_workspace_floats()), device=a.device, dtype=torch.float32)
+    ws = _l1_workspace(a.device)
     loss = torch.empty((), device=a.device, dtype=torch.float32)
     hip_lib.check(lib.larva_l1_fwd(a.data_ptr(), b.data_ptr(), a.numel(), ws.data_ptr(), loss.data_ptr(), _stream()),
                   "larva_l1_fwd")
     return loss
+
+
+def l1_bwd_unshuffle4(a, b, gout):
+    """Gradient of mean|a - b| w.r.t. a, written as [N][16C][H][W] (pixel-unshuffled)."""
+    lib = hip_lib.load()
+    _chk(a, "a")
+    _chk(b, "b", a.shape)
+    _chk(gout, "gout", ())
+    N, C, HH, WW = (int(v) for v in a.shape)
+    if HH % 4 or WW % 4:
+        raise RuntimeError("larvanet_amd: spatial dims must be divisible by 4")
+    out = torch.empty((N, 16 * C, HH // 4, WW // 4), device=a.device, dtype=torch.float32)
+    hip_lib.check(lib.larva_l1_bwd_unshuffle4(a.data_ptr(), b.data_ptr(), gout.data_ptr(), out.data_ptr(), N, C,
+                                              HH // 4, WW // 4, _stream()), "larva_l1_bwd_unshuffle4")
+    return out
+
+
+def sum_scalars(terms, divisor):
+    lib = hip_lib.load()
+    ptrs = [_chk(t, "term", ()) for t in terms]
+    out = torch.empty((), device=terms[0].device, dtype=torch.float32)
+    hip_lib.check(lib.larva_sum_scalars(hip_lib.ptr_array(ptrs), len(ptrs), float(divisor), out.data_ptr(), _stream()),
+                  "larva_sum_scalars")
+    return out
 
 
 def l1_bwd(a, b, gout):

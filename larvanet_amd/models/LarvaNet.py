@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .. import dist as ldist
 from .. import kernels as K
-from ..autograd import BodyFn, HeadFn, L1LossFn, LegFn, PackedConv, SideStreams, pack_all
+from ..autograd import BodyFn, ExitFn, HeadFn, L1LossFn, LegFn, MeanTermsFn, PackedConv, SideStreams, pack_all
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
 from .base import BaseModel
 
@@ -253,17 +253,26 @@ class LarvaNet(BaseModel):
             self.scheduler = self._make_scheduler()
 
     # ------------------------------------------------------------------ training
+    def _exit_fused(self, leg, fea, base, truth_tensor):
+        """leg(fea, base) and loss_fn(out, truth) as one autograd node (ExitFn) when loss_fn is
+        the stock L1Loss; otherwise the two separate calls of the reference."""
+        if isinstance(self.loss_fn, L1Loss) and isinstance(leg, LarvaLeg):
+            for pc in leg._pcs:
+                pc.refresh()
+            c1, c2 = leg.recon_block[0], leg.recon_block[2]
+            return ExitFn.apply(fea.contiguous(), base.contiguous(), truth_tensor.contiguous(), leg._pcs,
+                                c1.weight, c1.bias, c2.weight, c2.bias)
+        out = leg(fea, base)
+        return out, self.loss_fn(out, truth_tensor)
+
     def _exit(self, leg, fea, base, truth_tensor):
         """One exit (leg + its L1 term); on the `leg` side stream when side streams are active, so
         that it overlaps the next body (forward) and the previous body's backward."""
         if not SideStreams.active:
-            out = leg(fea, base)
-            return out, self.loss_fn(out, truth_tensor)
-        main = torch.cuda.current_stream()
+            return self._exit_fused(leg, fea, base, truth_tensor)
         side = SideStreams.fork("leg", fea, base, truth_tensor)
         with torch.cuda.stream(side):
-            out = leg(fea, base)
-            term = self.loss_fn(out, truth_tensor)
+            out, term = self._exit_fused(leg, fea, base, truth_tensor)
         SideStreams.keep(out, term)
         self._pending_exit_sync = True
         return out, term
@@ -287,10 +296,7 @@ class LarvaNet(BaseModel):
             out, term = self._exit(body.leg, fea, base, truth_tensor)
             terms.append(term)
         self._sync_exits()
-        loss = 0
-        for term in terms:
-            loss = loss + term
-        return loss / self.args.num_modules, out
+        return MeanTermsFn.apply(*terms), out
 
     # hipGraph path: one step issues ~330 short kernels; launched one by one from Python the GPU
     # idles between them, so forward + backward are captured once per batch shape and replayed.

@@ -11,7 +11,7 @@ state_dict adds tail.merge_conv.{weight,bias} and tail.recon_block.{0,2}.{weight
 import torch
 import torch.nn as nn
 
-from ..autograd import LegFn, MergeFn, PackedConv
+from ..autograd import LegFn, MeanTermsFn, MergeFn, PackedConv
 from . import LarvaNet as V1
 from .LarvaNet import NUM_FILTERS, _conv, _require_hip, init_conv
 
@@ -107,10 +107,7 @@ class LarvaNet(V1.LarvaNet):
         out = net.tail(feats, base)
         terms.append(self.loss_fn(out, truth_tensor))
         self._sync_exits()
-        loss = 0
-        for term in terms:
-            loss = loss + term
-        return loss / (self.args.num_modules + 1), out
+        return MeanTermsFn.apply(*terms), out
 
     def restore(self, ckpt_path, target=None):
         """Only keys present in this network are taken (V1 checkpoints warm-start V2),

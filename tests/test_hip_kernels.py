@@ -290,3 +290,24 @@ def test_invalid_arguments_are_rejected(hip_device):
         K.conv3x3(x, fwd, 48, relu=True, res0=x)  # fusion that is not compiled
     with pytest.raises(RuntimeError):
         K.conv3x3(x[:, :, :, ::2], fwd, 48)  # non-contiguous
+
+
+def test_l1_bwd_unshuffle_and_sum_scalars(hip_device):
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(21)
+    a = (rng.random((2, 3, 24, 32)) * 255).astype(np.float32)
+    b = (rng.random((2, 3, 24, 32)) * 255).astype(np.float32)
+    b.ravel()[::5] = a.ravel()[::5]
+    g = torch.tensor(0.25, device=hip_device)
+    got = K.l1_bwd_unshuffle4(_dev(a, hip_device), _dev(b, hip_device), g)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), R.pixel_unshuffle(R.l1_grad(a, b, 0.25), 4))
+    terms = [torch.tensor(v, device=hip_device) for v in (1.5, 2.25, 3.0)]
+    s = K.sum_scalars(terms, 3.0)
+    torch.cuda.synchronize()
+    assert float(s) == np.float32(np.float32(np.float32(1.5) + np.float32(2.25)) + np.float32(3.0)) / np.float32(3.0)
+    # repeated single-launch L1 forward: the self-resetting ticket must survive many calls
+    x, y = _dev(a, hip_device), _dev(b, hip_device)
+    vals = [float(K.l1_fwd(x, y)) for _ in range(5)]
+    assert len(set(vals)) == 1 and abs(vals[0] - R.l1_mean(a, b)) < 1e-5 * R.l1_mean(a, b)
