@@ -105,6 +105,14 @@ int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* 
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                      long long n, void* stream);
 
+/* ---- device-resident patch sampler ----------------------------------------------------------
+ * Crop + np.rot90(k) + horizontal flip + uint8->float of a training batch from a dataset held
+ * in HBM (dataloaders/div2k_train_loader.py:72-98 and the H2D copy of train_larva.py:123-124).
+ * data: uint8 CHW images at data + offsets[i], (H, W) = hw[2i], hw[2i+1]; draws[b] =
+ * {image, x, y, k, flip}; crop origin (y*mult, x*mult), size P x P; out [B][3][P][P] float. */
+int larva_gather_patches(const unsigned char* data, const long long* offsets, const int* hw,
+                         const int* draws, float* out, int B, int P, int mult, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -247,6 +247,41 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-resident patch sampler: crop + rot90 + horizontal flip + uint8 -> float of one training
+// batch, straight out of a dataset kept in HBM (replaces the host loop of
+// dataloaders/div2k_train_loader.py:72-98 and the H2D copy of train_larva.py:123-124).
+// draws[b] = {image, x, y, k, flip} (k = number of counter-clockwise quarter turns, np.rot90);
+// the crop starts at (y*mult, x*mult) and is P x P pixels; images are uint8 CHW at
+// data + offsets[image] with (H, W) = hw[2*image .. +1].
+//   rot90^k then flip:  out[c][i][j] = crop[c][si][sj],  j' = flip ? P-1-j : j,
+//     k%4==0: (si,sj) = (i, j')   1: (j', P-1-i)   2: (P-1-i, P-1-j')   3: (P-1-j', i)
+// ---------------------------------------------------------------------------------------------
+__global__ void gather_patches_kernel(const unsigned char* __restrict__ data,
+                                      const long long* __restrict__ offsets, const int* __restrict__ hw,
+                                      const int* __restrict__ draws, float* __restrict__ out, int B, int P,
+                                      int mult) {
+  const long long total = (long long)B * 3 * P * P;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % P);
+    long long t = idx / P;
+    const int i = (int)(t % P); t /= P;
+    const int c = (int)(t % 3);
+    const int b = (int)(t / 3);
+    const int* d = draws + 5 * b;
+    const int img = d[0], x0 = d[1] * mult, y0 = d[2] * mult, k = d[3] & 3, flip = d[4];
+    const int H = hw[2 * img], W = hw[2 * img + 1];
+    const int jj = flip ? P - 1 - j : j;
+    int si, sj;
+    if (k == 0) { si = i; sj = jj; }
+    else if (k == 1) { si = jj; sj = P - 1 - i; }
+    else if (k == 2) { si = P - 1 - i; sj = P - 1 - jj; }
+    else { si = P - 1 - jj; sj = i; }
+    out[idx] = (float)data[offsets[img] + ((long long)c * H + (y0 + si)) * W + (x0 + sj)];
+  }
+}
+
 static inline int grid_for(long long work, int block) {
   long long g = (work + block - 1) / block;
   if (g > 2048) g = 2048;
@@ -334,6 +369,15 @@ int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* 
   if (!p || !g || !m || !v || !step_lr || n <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                      step_lr, beta1, beta2, eps, weight_decay, grad_scale, n);
+  return (int)hipGetLastError();
+}
+
+// out[b][c][i][j] (float) = augmented P x P crop of image draws[b][0]; see gather_patches_kernel.
+int larva_gather_patches(const unsigned char* data, const long long* offsets, const int* hw,
+                         const int* draws, float* out, int B, int P, int mult, void* stream) {
+  if (!data || !offsets || !hw || !draws || !out || B <= 0 || P <= 0 || mult <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_patches_kernel, dim3(grid_for((long long)B * 3 * P * P, 256)), dim3(256), 0,
+                     (hipStream_t)stream, data, offsets, hw, draws, out, B, P, mult);
   return (int)hipGetLastError();
 }
 

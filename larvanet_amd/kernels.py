@@ -269,3 +269,18 @@ def adamw_step(p, g, m, v, step_lr, beta1, beta2, eps, weight_decay, grad_scale=
     hip_lib.check(lib.larva_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), step_lr.data_ptr(),
                                        beta1, beta2, eps, weight_decay, grad_scale, n, _stream()),
                   "larva_adamw_step")
+
+
+def gather_patches(data, offsets, hw, draws, batch, patch, mult):
+    """Augmented float patches [batch][3][patch][patch] from a uint8 dataset resident on the device."""
+    lib = hip_lib.load()
+    for t, name, dt in ((data, "data", torch.uint8), (offsets, "offsets", torch.int64), (hw, "hw", torch.int32),
+                        (draws, "draws", torch.int32)):
+        if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+            raise RuntimeError("larvanet_amd: %s must be a contiguous %s tensor on the HIP device" % (name, dt))
+    if tuple(draws.shape) != (batch, 5):
+        raise RuntimeError("larvanet_amd: draws must be [batch][5]")
+    out = torch.empty((batch, 3, patch, patch), device=data.device, dtype=torch.float32)
+    hip_lib.check(lib.larva_gather_patches(data.data_ptr(), offsets.data_ptr(), hw.data_ptr(), draws.data_ptr(),
+                                           out.data_ptr(), batch, patch, mult, _stream()), "larva_gather_patches")
+    return out

@@ -114,17 +114,23 @@ def main(argv=None):
             scale = model.get_next_train_scale()
             summary = writers[scale] if model.global_step % args.summary_freq == 0 else None
             t0 = time.time()
-            if loader.is_threaded:
-                input_list, truth_list = loader.get_queue_data(scale=scale)
+            if getattr(loader, "is_device", False):
+                # dataset resident in HBM: the batch is cut, augmented and converted on the GPU
+                input_tensor, truth_tensor = loader.get_device_batch(batch_size=args.batch_size, scale=scale,
+                                                                     input_patch_size=args.input_patch_size)
+                t1 = time.time()
             else:
-                input_list, truth_list = loader.get_patch_batch(batch_size=args.batch_size, scale=scale,
-                                                                input_patch_size=args.input_patch_size)
-            t1 = time.time()
-            # rot90/flip produce negative-stride views: one contiguous host array, one H2D copy
-            input_tensor = torch.as_tensor(np.ascontiguousarray(np.stack(input_list), dtype=np.float32),
-                                           device=model.device)
-            truth_tensor = torch.as_tensor(np.ascontiguousarray(np.stack(truth_list), dtype=np.float32),
-                                           device=model.device)
+                if loader.is_threaded:
+                    input_list, truth_list = loader.get_queue_data(scale=scale)
+                else:
+                    input_list, truth_list = loader.get_patch_batch(batch_size=args.batch_size, scale=scale,
+                                                                    input_patch_size=args.input_patch_size)
+                t1 = time.time()
+                # rot90/flip produce negative-stride views: one contiguous host array, one H2D copy
+                input_tensor = torch.as_tensor(np.ascontiguousarray(np.stack(input_list), dtype=np.float32),
+                                               device=model.device)
+                truth_tensor = torch.as_tensor(np.ascontiguousarray(np.stack(truth_list), dtype=np.float32),
+                                               device=model.device)
             t2 = time.time()
             loss = model.train_step_larva(args=args, val_dataloader=val_loader, input_tensor=input_tensor,
                                           truth_tensor=truth_tensor, summary=summary)

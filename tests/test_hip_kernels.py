@@ -311,3 +311,30 @@ def test_l1_bwd_unshuffle_and_sum_scalars(hip_device):
     x, y = _dev(a, hip_device), _dev(b, hip_device)
     vals = [float(K.l1_fwd(x, y)) for _ in range(5)]
     assert len(set(vals)) == 1 and abs(vals[0] - R.l1_mean(a, b)) < 1e-5 * R.l1_mean(a, b)
+
+
+def test_gather_patches_matches_numpy_crop_rot_flip(hip_device):
+    """Device-resident sampler: every (k, flip) combination against np.rot90 / [::-1]."""
+    from larvanet_amd.dataloaders import device_patch_loader as D
+    ld = D.create_loader()
+    ld.parse_args(["--device_source=synthetic_loader", "--synthetic_images=3", "--synthetic_lr_size=20", "--data_seed=4"])
+    ld.prepare([4])
+    p = 8
+    draws = []
+    for img in range(3):
+        for k in (1, 2, 3, 4):
+            for flip in (0, 1):
+                h, w = ld.shapes[img]
+                draws.append((img, (img * 3 + k) % (w - p), (k * 2 + flip) % (h - p), k, flip))
+    draws = np.array(draws, np.int32)
+    x, y = ld.get_device_batch(len(draws), 4, p, draws=draws)
+    torch.cuda.synchronize()
+    x, y = x.cpu().numpy(), y.cpu().numpy()
+    for b, d in enumerate(draws):
+        lr, hr, _ = ld.get_image_pair(int(d[0]), 4)
+        a_ref, b_ref = D.apply_draw_numpy(d, lr, hr, 4, p)
+        assert np.array_equal(x[b], a_ref), d
+        assert np.array_equal(y[b], b_ref), d
+    # seeded draw streams reproduce, and feed train-shaped batches
+    x1, y1 = ld.get_device_batch(4, 4, p)
+    assert tuple(x1.shape) == (4, 3, p, p) and tuple(y1.shape) == (4, 3, 4 * p, 4 * p) and x1.dtype == torch.float32

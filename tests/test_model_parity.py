@@ -183,3 +183,26 @@ def test_v2_restore_takes_matching_keys_only(hip_device, tmp_path):
     v2.restore(path)
     assert torch.equal(v2.model.head.feature_extraction.weight.cpu(), v1.model.head.feature_extraction.weight.cpu())
     assert torch.equal(v2.model.tail.merge_conv.weight.cpu(), tail_before)
+
+
+def test_early_exit_plugin_matches_staged_exits(hip_device, golden):
+    """models/LarvaLeg.py: --leg=k returns exit k; k = 0 the bicubic base alone."""
+    g = golden("f1_m2b2_forward.npz")
+    x = [g["x"][0], g["x"][1]]
+    for leg, ref in ((0, g["base"]), (1, g["exit_0"]), (2, g["exit_1"])):
+        m = _model("LarvaLeg", ["--num_modules=2", "--num_blocks=2,2", "--leg=%d" % leg])
+        out = m.upscale(x, 4)
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-3)
+
+
+def test_device_resident_training_and_runtime_probe(hip_device, tmp_path, capsys):
+    from larvanet_amd import runtime, train_larva
+    model = train_larva.main([
+        "--model=LarvaNet", "--dataloader=device_patch_loader", "--device_source=synthetic_loader",
+        "--val_dataloader=synthetic_loader", "--train_path", str(tmp_path), "--max_steps=3", "--batch_size=4",
+        "--input_patch_size=12", "--num_modules=1", "--num_blocks=1", "--synthetic_images=3",
+        "--synthetic_lr_size=20", "--data_seed=1"])
+    assert model.global_step == 3
+    res = runtime.main(["--model=LarvaNet", "--dataloader=synthetic_loader", "--num_modules=1", "--num_blocks=1",
+                        "--synthetic_images=2", "--synthetic_lr_size=20"])
+    assert res[4] > 0
