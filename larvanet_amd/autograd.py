@@ -85,10 +85,13 @@ class PackedConv:
     gradients (inference) they are cached until the weight's storage/version moves or
     invalidate() is called (restore / load_state_dict / optimizer step do)."""
 
-    __slots__ = ("weight", "bias", "cin_pad", "slices", "_key", "_packs", "_bufs", "_prepacked")
+    __slots__ = ("weight", "bias", "cin_pad", "slices", "_key", "_packs", "_bufs", "_prepacked", "grad_inplace")
 
     def __init__(self, weight, bias, cin_pad=None, slices=None):
         self.weight, self.bias, self.cin_pad = weight, bias, cin_pad
+        # True once a GradBucket owns weight.grad / bias.grad: the wgrad kernels then write the
+        # gradients there directly and the autograd nodes return None for them.
+        self.grad_inplace = False
         self.slices = slices  # list of (cin_off, cin) for a conv over concatenated inputs, or None
         self._key = None
         self._packs = None
@@ -157,6 +160,42 @@ def pack_all(pcs):
         pc._prepacked = True
 
 
+class GradBucket:
+    """All parameter gradients of a network as views of ONE flat fp32 buffer: the weight-gradient
+    kernels write straight into it, the data-parallel all-reduce is a single collective over it
+    (no flatten / unflatten copies), and the optimizer sees ordinary p.grad tensors.
+    Gradients are OVERWRITTEN by every backward (the reference zeroes them before each backward,
+    models/LarvaNet.py:112-113, so the result is the same); zero_grad(set_to_none=True) would
+    detach the views and must not be used while a bucket is attached."""
+
+    def __init__(self, module, pcs):
+        params = [p for p in module.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in params)
+        dev = params[0].device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        self._pairs = []
+        for p in params:
+            view = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = view
+            self._pairs.append((p, view))
+            off += p.numel()
+        owned = {id(p) for p in params}
+        for pc in pcs:
+            pc.grad_inplace = id(pc.weight) in owned and id(pc.bias) in owned
+
+    def intact(self, module=None):
+        """False if somebody replaced or dropped a .grad (then fall back to autograd's own)."""
+        return all(p.grad is view for p, view in self._pairs)
+
+
+def _targets(pc):
+    """(dw, db) destinations of a conv's gradients: the bucket views, or None = allocate."""
+    if pc is not None and pc.grad_inplace and pc.weight.grad is not None and pc.bias.grad is not None:
+        return pc.weight.grad, pc.bias.grad
+    return None, None
+
+
 def _splits(njobs):
     return max(1, _WGRAD_WORKGROUPS // njobs)
 
@@ -168,12 +207,15 @@ def _wgrad(jobs, cout, cin):
     side = None
     if SideStreams.active and SideStreams.wgrad_on_side:
         side = SideStreams.fork("wgrad", *[t for j in jobs for t in (j[0], j[1])])
+    jobs = list(jobs)
     ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
     out, batch = [], []
     with ctx:
-        for (dy, x, wshape, cin_off, cin_valid, dw_shared) in jobs:
+        for job in jobs:
+            (dy, x, wshape, cin_off, cin_valid, dw_shared) = job[:6]
+            db_shared = job[6] if len(job) > 6 else None
             dw = dw_shared if dw_shared is not None else torch.empty(wshape, device=dy.device, dtype=torch.float32)
-            db = torch.empty((cout,), device=dy.device, dtype=torch.float32)
+            db = db_shared if db_shared is not None else torch.empty((cout,), device=dy.device, dtype=torch.float32)
             batch.append({"dy": dy, "x": x, "dw": dw, "db": db, "cin_off": cin_off, "cin_valid": cin_valid})
             out.append((dw, db))
         for i in range(0, len(batch), 16):
@@ -205,6 +247,7 @@ class HeadFn(torch.autograd.Function):
         out = K.conv3x3(x16, fwd, int(weight.shape[0]), bias=bias.detach())
         ctx.save_for_backward(x16)
         ctx.wshape = tuple(weight.shape)
+        ctx.pc = pc
         return out
 
     @staticmethod
@@ -212,7 +255,10 @@ class HeadFn(torch.autograd.Function):
         (x16,) = ctx.saved_tensors
         dy = dy.contiguous()
         cout, cin = ctx.wshape[0], ctx.wshape[1]
-        (dw, db), = _wgrad([(dy, x16, ctx.wshape, 0, cin, None)], cout, 16)
+        tw, tb = _targets(ctx.pc)
+        (dw, db), = _wgrad([(dy, x16, ctx.wshape, 0, cin, tw, tb)], cout, 16)
+        if tw is not None:
+            return None, None, None, None
         return None, dw, db, None
 
 
@@ -262,16 +308,16 @@ class BodyFn(torch.autograd.Function):
             (_, bw1), = pcs[2 * j].get()
             (_, bw2), = pcs[2 * j + 1].get()
             dh = K.conv3x3(g, bw2, c, mask=h_j)
-            jobs[2 * j + 1] = (g, h_j, ctx.wshape, 0, c, None)
-            jobs[2 * j] = (dh, fea_j, ctx.wshape, 0, c, None)
+            jobs[2 * j + 1] = (g, h_j, ctx.wshape, 0, c) + _targets(pcs[2 * j + 1])
+            jobs[2 * j] = (dh, fea_j, ctx.wshape, 0, c) + _targets(pcs[2 * j])
             if j > 0:
                 g = K.conv3x3(dh, bw1, c, res0=g)
             else:
                 dx = K.conv3x3(dh, bw1, c, res0=g, res1=dy)
         grads = _wgrad(jobs, c, c)
         flat = []
-        for (dw, db) in grads:
-            flat += [dw, db]
+        for pc, (dw, db) in zip(pcs, grads):
+            flat += [None, None] if _targets(pc)[0] is not None else [dw, db]
         return (dx, None) + tuple(flat)
 
 
@@ -301,7 +347,12 @@ class LegFn(torch.autograd.Function):
         dyl = K.pixel_unshuffle4(dout.contiguous())
         dh = K.conv3x3(dyl, bw2, c, mask=h)
         dfea = K.conv3x3(dh, bw1, c)
-        (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c, None), (dyl, h, ctx.wshape, 0, c, None)], c, c)
+        (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0]),
+                                         (dyl, h, ctx.wshape, 0, c) + _targets(pcs[1])], c, c)
+        if _targets(pcs[0])[0] is not None:
+            dw1 = db1 = None
+        if _targets(pcs[1])[0] is not None:
+            dw2 = db2 = None
         # base comes from a parameter-free interpolation of the network input: no gradient
         return dfea, None, None, dw1, db1, dw2, db2
 
@@ -337,7 +388,12 @@ class ExitFn(torch.autograd.Function):
         dyl = K.l1_bwd_unshuffle4(out, truth, gterm.contiguous())
         dh = K.conv3x3(dyl, bw2, c, mask=h)
         dfea = K.conv3x3(dh, bw1, c)
-        (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c, None), (dyl, h, ctx.wshape, 0, c, None)], c, c)
+        (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0]),
+                                         (dyl, h, ctx.wshape, 0, c) + _targets(pcs[1])], c, c)
+        if _targets(pcs[0])[0] is not None:
+            dw1 = db1 = None
+        if _targets(pcs[1])[0] is not None:
+            dw2 = db2 = None
         return dfea, None, None, None, dw1, db1, dw2, db2
 
 
@@ -378,10 +434,13 @@ class MergeFn(torch.autograd.Function):
         cout = ctx.wshape[0]
         c = int(feats[0].shape[1])
         dfeats = [K.conv3x3(dy, packs[1 + i][1], c) for i in range(len(feats))]
-        dw = torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
-        jobs = [(dy, f, ctx.wshape, i * c, c, dw) for i, f in enumerate(feats)]
+        tw, tb = _targets(ctx.pc)
+        dw = tw if tw is not None else torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
+        jobs = [(dy, f, ctx.wshape, i * c, c, dw, tb if i == 0 else None) for i, f in enumerate(feats)]
         res = _wgrad(jobs, cout, c)
         db = res[0][1]
+        if tw is not None:
+            return (None, None, None) + tuple(dfeats)
         return (None, dw, db) + tuple(dfeats)
 
 

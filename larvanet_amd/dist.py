@@ -57,10 +57,15 @@ def broadcast_parameters(module, src=0):
         t.copy_(synced)
 
 
-def allreduce_gradients(module):
-    """Mean of the gradients over ranks through one flat bucket (sum all-reduce, then 1/world)."""
+def allreduce_gradients(module, bucket=None):
+    """Mean of the gradients over ranks as ONE collective.  With a GradBucket the gradients already
+    live in one flat buffer (no flatten / unflatten copies); otherwise they are flattened here."""
     ws = world_size()
     if ws == 1:
+        return
+    if bucket is not None and bucket.intact(module):
+        td.all_reduce(bucket.flat, op=td.ReduceOp.SUM)
+        bucket.flat.mul_(1.0 / ws)
         return
     grads = [p.grad for p in module.parameters() if p.grad is not None]
     if not grads:

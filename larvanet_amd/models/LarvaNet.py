@@ -19,7 +19,8 @@ import torch.nn as nn
 
 from .. import dist as ldist
 from .. import kernels as K
-from ..autograd import BodyFn, ExitFn, HeadFn, L1LossFn, LegFn, MeanTermsFn, PackedConv, SideStreams, pack_all
+from ..autograd import (BodyFn, ExitFn, GradBucket, HeadFn, L1LossFn, LegFn, MeanTermsFn, PackedConv, SideStreams,
+                        pack_all)
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
 from .base import BaseModel
 
@@ -251,6 +252,8 @@ class LarvaNet(BaseModel):
             params = [p for p in self.model.parameters() if p.requires_grad]
             self.optim = torch.optim.AdamW(params, lr=self.args.lr, fused=self.device.type == "cuda")
             self.scheduler = self._make_scheduler()
+            # one flat gradient buffer: wgrad kernels write into it, one all-reduce covers it
+            self.grad_bucket = GradBucket(self.model, self.model.packed_convs()) if self.device.type == "cuda" else None
 
     # ------------------------------------------------------------------ training
     def _exit_fused(self, leg, fea, base, truth_tensor):
@@ -310,19 +313,33 @@ class LarvaNet(BaseModel):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):  # warm-up outside capture (lazy kernel attributes, allocator pools)
-                self.optim.zero_grad(set_to_none=True)
+                self._zero_grad()
                 with SideStreams.scope() if self.use_side_streams else _NoScope():
                     loss, _ = self._exit_losses(self._static_in, self._static_truth)
                     loss.backward()
         torch.cuda.current_stream().wait_stream(side)
-        self.optim.zero_grad(set_to_none=True)
+        self._zero_grad()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: a process-group watchdog thread must not abort the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             with SideStreams.scope() if self.use_side_streams else _NoScope():
                 loss, out = self._exit_losses(self._static_in, self._static_truth)
                 loss.backward()
         self._graph, self._graph_loss, self._graph_out = graph, loss, out
         self._graph_shape = self._graph_key(input_tensor, truth_tensor)
+
+    def _zero_grad(self):
+        """optim.zero_grad() of the reference (models/LarvaNet.py:112).  With the flat gradient
+        bucket every backward overwrites the gradients in place, so nothing has to be cleared
+        (and set_to_none would detach the bucket views)."""
+        bucket = getattr(self, "grad_bucket", None)
+        if bucket is not None and bucket.intact(self.model):
+            return
+        if bucket is not None:  # somebody replaced a .grad: stop writing in place
+            for pc in self.model.packed_convs():
+                pc.grad_inplace = False
+            self.grad_bucket = None
+        self.optim.zero_grad(set_to_none=True)
 
     def _forward_backward(self, input_tensor, truth_tensor):
         """loss and gradients of one batch (models/LarvaNet.py:101-113)."""
@@ -333,7 +350,7 @@ class LarvaNet(BaseModel):
             self._static_truth.copy_(truth_tensor)
             self._graph.replay()  # gradients are overwritten in place: no zero_grad needed
             return self._graph_loss, self._graph_out
-        self.optim.zero_grad()
+        self._zero_grad()
         with SideStreams.scope() if self.use_side_streams else _NoScope():
             loss, out = self._exit_losses(input_tensor, truth_tensor)
             loss.backward()
@@ -344,7 +361,7 @@ class LarvaNet(BaseModel):
         self.temp_volume += self.volume_per_step
 
         loss, out = self._forward_backward(input_tensor, truth_tensor)
-        ldist.allreduce_gradients(self.model)  # mean over ranks; no-op for a single process
+        ldist.allreduce_gradients(self.model, getattr(self, "grad_bucket", None))  # mean over ranks
         self.optim.step()
         self.model.invalidate_packed_weights()  # the kernel-layout weight images are now stale
 
