@@ -37,10 +37,13 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
     if use_gpu:
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % torch.cuda.device_count())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    td.init_process_group(backend=backend or ("nccl" if use_gpu else "gloo"))
+    # LARVA_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    # (RCCL refuses two ranks on one device)
+    backend = backend or os.environ.get("LARVA_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+    td.init_process_group(backend=backend)
     return rank(), world_size()
 
 
