@@ -105,6 +105,10 @@ int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* 
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                      long long n, void* stream);
 
+int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float grad_scale, long long n,
+                          void* stream);
+
 /* ---- device-resident patch sampler ----------------------------------------------------------
  * Crop + np.rot90(k) + horizontal flip + uint8->float of a training batch from a dataset held
  * in HBM (dataloaders/div2k_train_loader.py:72-98 and the H2D copy of train_larva.py:123-124).

@@ -225,9 +225,10 @@ __global__ void pixel_unshuffle4_kernel(const float* __restrict__ in, float* __r
 // {step count as float, lr} on the device so that a captured graph can be replayed.
 // ---------------------------------------------------------------------------------------------
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                             float* __restrict__ v, const float* __restrict__ step_lr, float beta1,
-                             float beta2, float eps, float wd, float gscale, long long n) {
-  const float step = step_lr[0], lr = step_lr[1];
+                             float* __restrict__ v, const float* __restrict__ step_lr, float step_h,
+                             float lr_h, float beta1, float beta2, float eps, float wd, float gscale,
+                             long long n) {
+  const float step = step_lr ? step_lr[0] : step_h, lr = step_lr ? step_lr[1] : lr_h;
   const float bc1 = 1.f - powf(beta1, step);
   const float bc2 = 1.f - powf(beta2, step);
   const float step_size = lr / bc1;
@@ -368,7 +369,17 @@ int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* 
                      void* stream) {
   if (!p || !g || !m || !v || !step_lr || n <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     step_lr, beta1, beta2, eps, weight_decay, grad_scale, n);
+                     step_lr, 0.f, 0.f, beta1, beta2, eps, weight_decay, grad_scale, n);
+  return (int)hipGetLastError();
+}
+
+// Same update with the step count (1-based) and learning rate passed from the host.
+int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float grad_scale, long long n,
+                          void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (const float*)nullptr, (float)step, lr, beta1, beta2, eps, weight_decay, grad_scale, n);
   return (int)hipGetLastError();
 }
 

@@ -284,3 +284,14 @@ def gather_patches(data, offsets, hw, draws, batch, patch, mult):
     hip_lib.check(lib.larva_gather_patches(data.data_ptr(), offsets.data_ptr(), hw.data_ptr(), draws.data_ptr(),
                                            out.data_ptr(), batch, patch, mult, _stream()), "larva_gather_patches")
     return out
+
+
+def adamw_step_host(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    """One AdamW step over flat buffers, step count and learning rate given by the host."""
+    lib = hip_lib.load()
+    n = p.numel()
+    for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, name, (n,))
+    hip_lib.check(lib.larva_adamw_step_host(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), int(step),
+                                            float(lr), beta1, beta2, eps, weight_decay, grad_scale, n, _stream()),
+                  "larva_adamw_step_host")

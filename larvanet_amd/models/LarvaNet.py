@@ -21,6 +21,7 @@ from .. import dist as ldist
 from .. import kernels as K
 from ..autograd import (BodyFn, ExitFn, GradBucket, HeadFn, L1LossFn, LegFn, MeanTermsFn, PackedConv, SideStreams,
                         pack_all)
+from ..optim import FlatAdamW, flatten_parameters
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
 from .base import BaseModel
 
@@ -250,10 +251,17 @@ class LarvaNet(BaseModel):
         if is_training:
             self.loss_fn = L1Loss()
             params = [p for p in self.model.parameters() if p.requires_grad]
-            self.optim = torch.optim.AdamW(params, lr=self.args.lr, fused=self.device.type == "cuda")
+            if self.device.type == "cuda":
+                # flat buffers: the wgrad kernels write every gradient into one bucket (one
+                # all-reduce covers it) and AdamW is one launch over parameters / moments
+                flat = flatten_parameters(self.model)
+                self.model.invalidate_packed_weights()
+                self.grad_bucket = GradBucket(self.model, self.model.packed_convs())
+                self.optim = FlatAdamW(params, flat, self.grad_bucket, lr=self.args.lr)
+            else:
+                self.grad_bucket = None
+                self.optim = torch.optim.AdamW(params, lr=self.args.lr)
             self.scheduler = self._make_scheduler()
-            # one flat gradient buffer: wgrad kernels write into it, one all-reduce covers it
-            self.grad_bucket = GradBucket(self.model, self.model.packed_convs()) if self.device.type == "cuda" else None
 
     # ------------------------------------------------------------------ training
     def _exit_fused(self, leg, fea, base, truth_tensor):

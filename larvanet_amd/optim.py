@@ -1,0 +1,72 @@
+"""AdamW for the flat-buffer layout: a torch.optim.AdamW (so `.param_groups[0]['lr']`,
+ReduceLROnPlateau, state_dict() keep working exactly as with the reference's optimizer,
+models/LarvaNet.py:86-92) whose step() is ONE HIP launch over the flat parameter / gradient /
+moment buffers instead of a multi-tensor pass over 82 tensors.  If the parameters or gradients
+are not (or no longer) contiguous views of the flat buffers it falls back to torch's own step()."""
+import torch
+
+from . import kernels as K
+
+
+def flatten_parameters(module):
+    """Re-seat every trainable parameter as a view of one flat fp32 buffer (same values, same
+    nn.Parameter objects, same state_dict keys). Returns the flat buffer."""
+    params = [p for p in module.parameters() if p.requires_grad]
+    flat = torch.empty(sum(p.numel() for p in params), device=params[0].device, dtype=torch.float32)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            view = flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            off += p.numel()
+    return flat
+
+
+class FlatAdamW(torch.optim.AdamW):
+    def __init__(self, params, flat_params, grad_bucket, lr=1e-3, **kw):
+        params = list(params)
+        super().__init__(params, lr=lr, **kw)
+        self._flat_p = flat_params
+        self._bucket = grad_bucket
+        self._m = torch.zeros_like(flat_params)
+        self._v = torch.zeros_like(flat_params)
+        self._t = 0
+        self._plist = params
+
+    def _flat_ok(self):
+        if self._flat_p is None or self._bucket is None or not self._bucket.intact():
+            return False
+        off = 0
+        base = self._flat_p.data_ptr()
+        for p in self._plist:
+            if p.data_ptr() != base + 4 * off:
+                return False
+            off += p.numel()
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None or len(self.param_groups) != 1 or not self._flat_ok():
+            return self._fallback_step(closure)
+        g = self.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize"):
+            return self._fallback_step(closure)
+        self._t += 1
+        b1, b2 = g["betas"]
+        K.adamw_step_host(self._flat_p, self._bucket.flat, self._m, self._v, self._t, float(g["lr"]), b1, b2,
+                          g["eps"], g["weight_decay"])
+        return None
+
+    def _fallback_step(self, closure):
+        # hand the moments over to torch's per-tensor state once, then stay on torch's path
+        if self._t > 0 and not self.state:
+            off = 0
+            for p in self._plist:
+                n = p.numel()
+                self.state[p] = {"step": torch.tensor(float(self._t)),
+                                 "exp_avg": self._m[off:off + n].view_as(p).clone(),
+                                 "exp_avg_sq": self._v[off:off + n].view_as(p).clone()}
+                off += n
+        self._flat_p = None
+        return super().step(closure)
