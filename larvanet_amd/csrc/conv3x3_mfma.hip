@@ -29,7 +29,7 @@
 
 // Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
 // bit 0 = skip the MFMA blocks, bit 1 = skip the global->LDS staging, bit 2 = skip the
-// epilogue's global traffic, bit 3 = return at kernel entry.
+// epilogue's global traffic, bit 3 = return at kernel entry, bit 4 = plain (not non-temporal) output stores.
 #ifndef LARVA_DIAG
 #define LARVA_DIAG 0
 #endif
@@ -414,7 +414,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
         f32x4 v = acc[c][p] + bias[c];
         if constexpr (EPI == kEpiShuffleBase) v += basev[c][p];
-        if (y < a.H && x < a.W) *reinterpret_cast<f32x4*>(a.out + idx) = v;
+        if (y < a.H && x < a.W) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
       }
   } else {
     const size_t plane = (size_t)a.H * a.W;
@@ -450,7 +450,10 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
             if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
             if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
             if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
-            a.out[idx0 + r * plane] = o;
+            // non-temporal: the 7 MB store burst of the 256 workgroups drains faster (-0.7 us per
+            // launch measured); the lines still stay in the XCD's L2 for the next layer
+            if constexpr ((LARVA_DIAG & 16) != 0) a.out[idx0 + r * plane] = o;
+            else __builtin_nontemporal_store(o, &a.out[idx0 + r * plane]);
           }
         }
       }

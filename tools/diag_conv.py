@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "_diag")
 SRC = os.path.join(ROOT, "larvanet_amd", "csrc", "conv3x3_mfma.hip")
 VARIANTS = {0: "full kernel", 1: "no MFMA", 2: "no staging loads", 4: "no epilogue traffic", 3: "no MFMA, no staging",
-            6: "MFMA only", 7: "roles + barriers only", 8: "empty launch"}
+            6: "MFMA only", 7: "roles + barriers only", 8: "empty launch", 16: "plain output stores"}
 
 
 def build():
