@@ -1,3 +1,9 @@
+// EXPERIMENTAL VARIANT of wgrad3x3_mfma.hip (same math, same partial-image format), selected
+// with LARVA_WGRAD=dma: 1-row tiles streamed by LDS-DMA into a 2-stage ring, <= 256 registers
+// and 86 KiB LDS so that it can share a CU with a conv workgroup.  Alone it is slower than the
+// register-staged kernel (3x halo re-read of x makes it bandwidth-bound: 127 vs 81 us per
+// 8-layer batch); kept to measure whether sharing CUs with the dgrad chain pays.
+//
 // Weight / bias gradient of the 3x3 convolutions (the autograd backward of nn.Conv2d at
 // models/LarvaNet.py:210-212, 227, 256-258 and models/LarvaNetV2.py:318-323) for gfx950:
 //
@@ -20,6 +26,7 @@
 #include "larva_common.h"
 
 namespace larva {
+namespace dma {
 
 constexpr int kMaxJobs = 16;
 
@@ -257,7 +264,7 @@ __device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, 
 // 2 waves/SIMD launch bound: <= 256 registers, so a conv workgroup (72 KiB LDS, < 128 VGPRs)
 // fits on the same CU beside this one (86 KiB LDS at 48 channels).
 template <int COUT, int CIN, bool VEC>
-__global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(WgradBatch b) {
+__global__ __launch_bounds__(256, (VEC && COUT * CIN <= 48 * 48) ? 2 : 1) void wgrad3x3_kernel(WgradBatch b) {
   using C = WgCfg<COUT, CIN, VEC>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WgradJob& j = b.job[blockIdx.y];
@@ -348,23 +355,20 @@ static hipError_t launch_wgrad(const WgradBatch& b, int njobs, int splits, hipSt
   return hipGetLastError();
 }
 
+}  // namespace dma
 }  // namespace larva
 
 using namespace larva;
+using namespace larva::dma;
 
 extern "C" {
-
-// Floats of partial-image workspace one job needs for `splits` workgroups.
-long long larva_wgrad_partial_floats(int cout, int cin, int splits) {
-  return (long long)splits * ((long long)(cin / 16) * 9 * (cout / 16) * 256 + cout);
-}
 
 // Weight + bias gradients of `njobs` (<= 16) same-shape 3x3 convolutions in two launches.
 // Job i: dy[i] [N][cout][H][W], x[i] [N][cin][H][W] -> partial[i] (workspace of
 // larva_wgrad_partial_floats floats) -> dw[i] [cout][w_cin_total[i]][3][3] at input-channel
 // offset cin_off[i] (only the first cin_valid[i] channels are written; the rest of `cin` is
 // zero padding of x), db[i] [cout] (may be null).  Gradients are OVERWRITTEN, not accumulated.
-int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* const* partial,
+int larva_conv3x3_wgrad_dma(const float* const* dy, const float* const* x, float* const* partial,
                         float* const* dw, float* const* db, const int* cin_off,
                         const int* cin_valid, const int* w_cin_total, int njobs, int splits,
                         int N, int cout, int cin, int H, int W, void* stream) {
