@@ -55,6 +55,14 @@ int larva_conv3x3_fwd(const float* const* src, int n_src, int cin_per_src, const
                       const float* base, float* out, int N, int cout, int H, int W, int relu,
                       int mode, void* stream);
 
+/* Same, for operands whose rows are `pitch` >= W floats apart (src, res0, res1, mask, mode-0
+ * out); columns [W, pitch) of the inputs must be zero and are written as zero.  Lets a width that
+ * is not a multiple of 4 (DIV2K x4 LR images are 510 wide) take the 16-byte staging path. */
+int larva_conv3x3_fwd_pitched(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                              const float* bias, const float* res0, const float* res1, const float* mask,
+                              const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                              int relu, int mode, void* stream);
+
 /* Measurement only: the same launch `iters` times with kernel-attached events
  * (hipExtLaunchKernelGGL); mean/min kernel duration in ms.  Synchronises the stream. */
 int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,

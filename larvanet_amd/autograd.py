@@ -17,6 +17,35 @@ from . import kernels as K
 _WGRAD_WORKGROUPS = 256
 
 
+class PaddedWidth:
+    """Inference on images whose width W is not a multiple of 4 (DIV2K x4 LR images are 510 wide):
+    inside `with PaddedWidth(W):` every LR-resolution activation is allocated with its rows padded
+    to P = W rounded up to 4 and columns [W, P) kept at zero, so the convs keep their 16-byte
+    LDS-DMA staging path instead of the scalar-load fallback.  Forward only."""
+
+    current = None
+
+    def __init__(self, w):
+        self.w = int(w)
+
+    def __enter__(self):
+        self._prev = PaddedWidth.current
+        PaddedWidth.current = self.w
+        return self
+
+    def __exit__(self, *exc):
+        PaddedWidth.current = self._prev
+        return False
+
+    @staticmethod
+    def pitch_of(w):
+        return (int(w) + 3) // 4 * 4
+
+
+def _lw():
+    return PaddedWidth.current
+
+
 class SideStreams:
     """Concurrency inside one training step.  A conv launch keeps the matrix pipes busy only
     about half of its duration (tile staging, the store burst and the launch floor are exposed),
@@ -241,10 +270,11 @@ class HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, pc):
         N, C, H, W = x.shape
-        x16 = torch.zeros((N, 16, H, W), device=x.device, dtype=torch.float32)
-        x16[:, :C] = x
+        P = PaddedWidth.pitch_of(W) if _lw() is not None else W
+        x16 = torch.zeros((N, 16, H, P), device=x.device, dtype=torch.float32)
+        x16[:, :C, :, :W] = x
         (fwd, _), = pc.get()
-        out = K.conv3x3(x16, fwd, int(weight.shape[0]), bias=bias.detach())
+        out = K.conv3x3(x16, fwd, int(weight.shape[0]), bias=bias.detach(), logical_w=_lw())
         ctx.save_for_backward(x16)
         ctx.wshape = tuple(weight.shape)
         ctx.pc = pc
@@ -277,11 +307,11 @@ class BodyFn(torch.autograd.Function):
             (f1, _), = pcs[2 * j].get()
             (f2, _), = pcs[2 * j + 1].get()
             c = int(w1.shape[0])
-            h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True)
+            h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True, logical_w=_lw())
             if j == nb - 1:
-                nxt = K.conv3x3(h, f2, c, bias=b2.detach(), res0=fea, res1=x)
+                nxt = K.conv3x3(h, f2, c, bias=b2.detach(), res0=fea, res1=x, logical_w=_lw())
             else:
-                nxt = K.conv3x3(h, f2, c, bias=b2.detach(), res0=fea)
+                nxt = K.conv3x3(h, f2, c, bias=b2.detach(), res0=fea, logical_w=_lw())
             keep.append(h)
             if j < nb - 1:
                 keep.append(nxt)
@@ -330,8 +360,8 @@ class LegFn(torch.autograd.Function):
         (f1, _), = pcs[0].get()
         (f2, _), = pcs[1].get()
         c = int(w1.shape[0])
-        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True)
-        out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base)
+        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True, logical_w=_lw())
+        out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base, logical_w=_lw())
         ctx.save_for_backward(fea, h)
         ctx.pcs = pcs
         ctx.wshape = tuple(w1.shape)
@@ -420,7 +450,7 @@ class MergeFn(torch.autograd.Function):
     def forward(ctx, pc, weight, bias, *feats):
         packs = pc.get()
         cout = int(weight.shape[0])
-        out = K.conv3x3(list(feats), packs[0][0], cout, bias=bias.detach())
+        out = K.conv3x3(list(feats), packs[0][0], cout, bias=bias.detach(), logical_w=_lw())
         ctx.save_for_backward(*feats)
         ctx.pc = pc
         ctx.wshape = tuple(weight.shape)

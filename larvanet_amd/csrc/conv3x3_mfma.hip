@@ -56,6 +56,8 @@ struct ConvArgs {
   int cin_per_src;            // multiple of 8
   int n_chunks;               // total input channels / 8
   int N, H, W;
+  int pitch;                  // row stride (floats) of every [..][H][W] tensor above; >= W.  Columns
+                              // [W, pitch) of the inputs hold zeros and are written as zeros.
   int tiles_x, tiles_y;
 };
 
@@ -128,7 +130,7 @@ __device__ __forceinline__ void make_plan(const ConvArgs& a, int wave, int lane,
     const int q = rem - r * (kRS / 4);
     const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
     const bool in_ok = ci < kCh && r < kHaloRows && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const int in_off = (ci * a.H + gy) * a.W + gx;
+    const int in_off = (ci * a.H + gy) * a.pitch + gx;
     // weight piece
     const int ws = (p - C::IN_PIECES) * 64 + lane;
     const bool w_ok = ws * 4 < C::W_USED;
@@ -151,7 +153,7 @@ __device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int 
   const int s_idx = c0 / a.cin_per_src;
   const int c_in_src = c0 - s_idx * a.cin_per_src;
   ChunkSrc cs;
-  cs.img = a.src[s_idx] + ((size_t)n * a.cin_per_src + c_in_src) * ((size_t)a.H * a.W);
+  cs.img = a.src[s_idx] + ((size_t)n * a.cin_per_src + c_in_src) * ((size_t)a.H * a.pitch);
   cs.wgt = a.wpk + (size_t)chunk * C::W_USED;
   return cs;
 }
@@ -183,7 +185,7 @@ template <int COUT>
 __device__ __forceinline__ void reg_load(const ConvArgs& a, const ChunkSrc& cs, int y0, int x0, int tid,
                                          RegStaging<COUT>& st) {
   using C = ConvCfg<COUT>;
-  const size_t plane = (size_t)a.H * a.W;
+  const size_t plane = (size_t)a.H * a.pitch;
 #pragma unroll
   for (int i = 0; i < C::RIN_ITERS; ++i) {
     const int s = min(tid + i * 256, C::RIN_SLOTS - 1);
@@ -193,7 +195,7 @@ __device__ __forceinline__ void reg_load(const ConvArgs& a, const ChunkSrc& cs, 
     const int q = rem - r * (kRS / 4);
     const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
     const bool row_ok = gy >= 0 && gy < a.H;
-    const float* row = cs.img + (size_t)ci * plane + (size_t)min(max(gy, 0), a.H - 1) * a.W;
+    const float* row = cs.img + (size_t)ci * plane + (size_t)min(max(gy, 0), a.H - 1) * a.pitch;
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -417,7 +419,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         if (y < a.H && x < a.W) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
       }
   } else {
-    const size_t plane = (size_t)a.H * a.W;
+    const size_t plane = (size_t)a.H * a.pitch;
     constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1) ? 1 : (EPI == kEpiRes2 ? 2 : 0);
     f32x4 aux[NAUX > 0 ? NAUX : 1][NCT][NPG];
 #pragma unroll
@@ -426,7 +428,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       for (int p = 0; p < NPG; ++p) {
         const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
         const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
-        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.W + x;
+        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if constexpr (EPI == kEpiMask) aux[0][c][p][r] = a.mask[idx0 + r * plane];
@@ -440,9 +442,10 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       for (int p = 0; p < NPG; ++p) {
         const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
         const int y = y0 + prow, x = x0 + pcol * 16 + lr;
-        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.W + x;
+        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
         const f32x4 v = acc[c][p] + bias[c];
-        if (y < a.H && x < a.W) {
+        if (y < a.H && x < a.pitch) {
+          const bool real = x < a.W;  // columns [W, pitch) are kept at zero for the next layer
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float o = v[r];
@@ -450,6 +453,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
             if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
             if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
             if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
+            o = real ? o : 0.f;
             // non-temporal: the 7 MB store burst of the 256 workgroups drains faster (-0.7 us per
             // launch measured); the lines still stay in the XCD's L2 for the next layer
             if constexpr ((LARVA_DIAG & 16) != 0) a.out[idx0 + r * plane] = o;
@@ -636,15 +640,17 @@ int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout,
 // [N][cout/16][4H][4W]).  Stream-ordered, never allocates or synchronises.
 static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                          const float* bias, const float* res0, const float* res1, const float* mask,
-                         const float* base, float* out, int N, int cout, int H, int W, int relu,
+                         const float* base, float* out, int N, int cout, int H, int W, int pitch, int relu,
                          int mode, void* stream, const LaunchTiming* tm) {
+  if (pitch == 0) pitch = W;
+  if (pitch < W) return (int)hipErrorInvalidValue;
   if (n_src < 1 || n_src > kMaxSrc || cin_per_src % kCh || cin_per_src <= 0 || N <= 0 || H <= 0 || W <= 0)
     return (int)hipErrorInvalidValue;
   if (mode != 0 && mode != 1) return (int)hipErrorInvalidValue;
-  if ((long long)cin_per_src * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;  // 32-bit lane offsets
+  if ((long long)cin_per_src * H * pitch >= (1ll << 31)) return (int)hipErrorInvalidValue;  // 32-bit lane offsets
   if (!wpk || !out) return (int)hipErrorInvalidValue;
   ConvArgs a{};
-  bool aligned = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(wpk) & 15) == 0);
+  bool aligned = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(wpk) & 15) == 0);
   for (int i = 0; i < n_src; ++i) {
     if (!src[i]) return (int)hipErrorInvalidValue;
     a.src[i] = src[i];
@@ -654,8 +660,8 @@ static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, co
   a.out = out;
   a.cin_per_src = cin_per_src;
   a.n_chunks = n_src * cin_per_src / kCh;
-  a.N = N; a.H = H; a.W = W;
-  a.tiles_x = (W + kTileCols - 1) / kTileCols;
+  a.N = N; a.H = H; a.W = W; a.pitch = pitch;
+  a.tiles_x = (pitch + kTileCols - 1) / kTileCols;
   a.tiles_y = (H + kTileRows - 1) / kTileRows;
   // Map the requested fusion onto a compiled epilogue (relu -> mask -> +res0 -> +res1).
   int epi;
@@ -689,8 +695,20 @@ int larva_conv3x3_fwd(const float* const* src, int n_src, int cin_per_src, const
                       const float* bias, const float* res0, const float* res1, const float* mask,
                       const float* base, float* out, int N, int cout, int H, int W, int relu,
                       int mode, void* stream) {
-  return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, relu,
+  return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, 0, relu,
                        mode, stream, nullptr);
+}
+
+// Same, for tensors whose rows are `pitch` >= W floats apart (every [..][H][W] operand: src,
+// res0, res1, mask and the mode-0 output).  Columns [W, pitch) of the inputs must hold zeros and
+// are written as zeros, so a width that is not a multiple of 4 can still use the 16-byte
+// LDS-DMA staging path (pitch = W rounded up to 4).  The pixel-shuffle output stays [..][4H][4W].
+int larva_conv3x3_fwd_pitched(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                              const float* bias, const float* res0, const float* res1, const float* mask,
+                              const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                              int relu, int mode, void* stream) {
+  return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch,
+                       relu, mode, stream, nullptr);
 }
 
 // Measurement only (synchronises; not capturable): runs the same launch `iters` times with
@@ -709,7 +727,7 @@ int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src,
   float best = 1e30f;
   int rc = 0;
   for (int i = 0; i < iters && rc == 0; ++i) {
-    rc = conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, relu,
+    rc = conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, 0, relu,
                        mode, stream, &tm);
     if (rc) break;
     e = hipEventSynchronize(tm.stop);

@@ -88,11 +88,13 @@ def pack_weights_batch(jobs):
 
 
 def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=None,
-            shuffle=False, base=None, out=None):
-    """Fused 3x3 conv over the channel concatenation of `srcs` (list of [N][c][H][W]).
+            shuffle=False, base=None, out=None, logical_w=None):
+    """Fused 3x3 conv over the channel concatenation of `srcs` (list of [N][c][H][P]).
 
-    shuffle=False: returns [N][cout][H][W]; shuffle=True: returns PixelShuffle(4) layout
-    [N][cout/16][4H][4W] (+ base)."""
+    shuffle=False: returns [N][cout][H][P]; shuffle=True: returns PixelShuffle(4) layout
+    [N][cout/16][4H][4W] (+ base).  logical_w: the image is W = logical_w <= P columns wide and
+    the tensors' rows are padded to the pitch P (columns [W, P) hold zeros) -- lets widths that
+    are not a multiple of 4 use the 16-byte staging path."""
     lib = hip_lib.load()
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
@@ -100,21 +102,24 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
         raise RuntimeError("larvanet_amd: 1..8 source tensors")
     if cout not in _SUPPORTED_COUT:
         raise RuntimeError("larvanet_amd: cout must be one of %s" % (_SUPPORTED_COUT,))
-    N, cps, H, W = (int(v) for v in srcs[0].shape)
+    N, cps, H, P = (int(v) for v in srcs[0].shape)
+    W = P if logical_w is None else int(logical_w)
+    if not 0 < W <= P:
+        raise RuntimeError("larvanet_amd: logical width %d does not fit the row pitch %d" % (W, P))
     if cps % 8:
         raise RuntimeError("larvanet_amd: input channels per tensor must be a multiple of 8")
-    ptrs = [_chk(s, "src[%d]" % i, (N, cps, H, W)) for i, s in enumerate(srcs)]
+    ptrs = [_chk(s, "src[%d]" % i, (N, cps, H, P)) for i, s in enumerate(srcs)]
     cin = cps * len(srcs)
     _chk(wpk, "wpk", (packed_weight_floats(cout, cin),))
-    full = (N, cout, H, W)
+    full = (N, cout, H, P)
     hr = (N, cout // 16, 4 * H, 4 * W)
     if out is None:
         out = torch.empty(hr if shuffle else full, device=srcs[0].device, dtype=torch.float32)
     _chk(out, "out", hr if shuffle else full)
-    code = lib.larva_conv3x3_fwd(
+    code = lib.larva_conv3x3_fwd_pitched(
         hip_lib.ptr_array(ptrs), len(srcs), cps, wpk.data_ptr(), _opt(bias, "bias", (cout,)),
         _opt(res0, "res0", full), _opt(res1, "res1", full), _opt(mask, "mask", full),
-        _opt(base, "base", hr), out.data_ptr(), N, cout, H, W, 1 if relu else 0, 1 if shuffle else 0, _stream())
+        _opt(base, "base", hr), out.data_ptr(), N, cout, H, W, P, 1 if relu else 0, 1 if shuffle else 0, _stream())
     hip_lib.check(code, "larva_conv3x3_fwd")
     return out
 

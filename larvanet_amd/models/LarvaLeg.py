@@ -24,10 +24,11 @@ class LarvaNetModule(V1.LarvaNetModule):
         base = self.base(x)
         if self.leg == 0:
             return base
-        fea = self.head(x)
-        for i in range(self.leg):
-            fea = getattr(self, "body_%d" % i)(fea)
-        return getattr(self, "body_%d" % (self.leg - 1)).leg(fea, base)
+        with self.width_scope(x):
+            fea = self.head(x)
+            for i in range(self.leg):
+                fea = getattr(self, "body_%d" % i)(fea)
+            return getattr(self, "body_%d" % (self.leg - 1)).leg(fea, base)
 
 
 class LarvaNet(V1.LarvaNet):

@@ -19,8 +19,8 @@ import torch.nn as nn
 
 from .. import dist as ldist
 from .. import kernels as K
-from ..autograd import (BodyFn, ExitFn, GradBucket, HeadFn, L1LossFn, LegFn, MeanTermsFn, PackedConv, SideStreams,
-                        pack_all)
+from ..autograd import (BodyFn, ExitFn, GradBucket, HeadFn, L1LossFn, LegFn, MeanTermsFn, PackedConv, PaddedWidth,
+                        SideStreams, pack_all)
 from ..optim import FlatAdamW, flatten_parameters
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
 from .base import BaseModel
@@ -183,12 +183,20 @@ class LarvaNetModule(nn.Module):
         with torch.no_grad():
             return K.bicubic4(x.detach().contiguous())
 
+    def width_scope(self, x):
+        """Row-padded activations for inference on widths that are not a multiple of 4."""
+        w = int(x.shape[-1])
+        if w % 4 and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return PaddedWidth(w)
+        return _NoScope()
+
     def forward(self, x):
-        fea = self.head(x)
-        for i in range(self.len):
-            fea = getattr(self, "body_%d" % i)(fea)
-        base = self.base(x)
-        return getattr(self, "body_%d" % (self.len - 1)).leg(fea, base)
+        with self.width_scope(x):
+            fea = self.head(x)
+            for i in range(self.len):
+                fea = getattr(self, "body_%d" % i)(fea)
+            base = self.base(x)
+            return getattr(self, "body_%d" % (self.len - 1)).leg(fea, base)
 
 
 class LarvaNet(BaseModel):

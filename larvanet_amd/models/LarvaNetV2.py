@@ -65,8 +65,9 @@ class LarvaNetModule(V1.LarvaNetModule):
         return feats
 
     def forward(self, x):
-        feats = self.features(x)
-        return self.tail(feats, self.base(x))
+        with self.width_scope(x):
+            feats = self.features(x)
+            return self.tail(feats, self.base(x))
 
 
 class LarvaNet(V1.LarvaNet):

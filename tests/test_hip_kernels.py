@@ -338,3 +338,38 @@ def test_gather_patches_matches_numpy_crop_rot_flip(hip_device):
     # seeded draw streams reproduce, and feed train-shaped batches
     x1, y1 = ld.get_device_batch(4, 4, p)
     assert tuple(x1.shape) == (4, 3, p, p) and tuple(y1.shape) == (4, 3, 4 * p, 4 * p) and x1.dtype == torch.float32
+
+
+@pytest.mark.parametrize("W,P", [(13, 16), (50, 52), (26, 28), (47, 48)])
+def test_conv3x3_row_pitch(hip_device, W, P):
+    """Rows padded to a pitch (columns [W, P) zero): same result as the unpadded conv, and the
+    pad columns of the output are written as zeros so that layers can be chained."""
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(W * 7 + P)
+    N, C, H = 2, 48, 7
+    x = _rand(rng, (N, C, H, W), 20.0)
+    w = _rand(rng, (C, C, 3, 3), 0.05)
+    b = _rand(rng, (C,), 1.0)
+    r0 = _rand(rng, (N, C, H, W), 20.0)
+    ref1 = np.maximum(R.conv3x3(x, w, b), 0)
+    ref2 = R.conv3x3(ref1, w, b) + r0
+
+    def pad(a):
+        out = np.zeros(a.shape[:-1] + (P,), np.float32)
+        out[..., :W] = a
+        return out
+
+    fwd, _ = K.pack_weights(_dev(w, hip_device))
+    bd = _dev(b, hip_device)
+    h = K.conv3x3(_dev(pad(x), hip_device), fwd, C, bias=bd, relu=True, logical_w=W)
+    y = K.conv3x3(h, fwd, C, bias=bd, res0=_dev(pad(r0), hip_device), logical_w=W)
+    torch.cuda.synchronize()
+    hn, yn = h.cpu().numpy(), y.cpu().numpy()
+    assert not hn[..., W:].any() and not yn[..., W:].any()
+    _report("pitched conv+relu", hn[..., :W], ref1, 2e-5)
+    _report("pitched chained conv+res", yn[..., :W], ref2, 2e-5)
+    base = _rand(rng, (N, 3, 4 * H, 4 * W), 50.0)
+    t = K.conv3x3(h, fwd, C, bias=bd, shuffle=True, base=_dev(base, hip_device), logical_w=W)
+    torch.cuda.synchronize()
+    _report("pitched tail", t.cpu().numpy(), R.pixel_shuffle(R.conv3x3(ref1, w, b), 4) + base, 2e-5)
