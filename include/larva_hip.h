@@ -132,6 +132,12 @@ int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step
 int larva_gather_patches(const unsigned char* data, const long long* offsets, const int* hw,
                          const int* draws, float* out, int B, int P, int mult, void* stream);
 
+/* ---- validation metric on the device (validate.py:17-27) --------------------------------------
+ * acc[0] += sum (truth_u8 - clip(rint(out), 0, 255))^2 over out [C][H][W] float against truth
+ * [C][TH][TW] uint8 cropped top-left; exact integer.  Caller zeroes acc. */
+int larva_sqerr_u8(const float* out, const unsigned char* truth, int C, int H, int W, int TH, int TW,
+                   unsigned long long* acc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -283,6 +283,33 @@ __global__ void gather_patches_kernel(const unsigned char* __restrict__ data,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Validation metric on the device (validate.py:17-27): the output image is converted with
+// clip(round-half-to-even(x), 0, 255) and compared with the uint8 truth cropped top-left to the
+// output size; sum of squared differences as an exact 64-bit integer (order-independent).
+// out: [C][H][W] float, truth: [C][TH][TW] uint8 with TH >= H, TW >= W.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqerr_u8_kernel(const float* __restrict__ out,
+                                                       const unsigned char* __restrict__ truth, int C, int H,
+                                                       int W, int TH, int TW,
+                                                       unsigned long long* __restrict__ acc) {
+  const long long total = (long long)C * H * W;
+  unsigned long long s = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const long long t = i / W;
+    const int y = (int)(t % H);
+    const int c = (int)(t / H);
+    const float q = fminf(fmaxf(rintf(out[i]), 0.f), 255.f);
+    const int d = (int)truth[((size_t)c * TH + y) * TW + x] - (int)q;
+    s += (unsigned long long)(d * d);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+}
+
 static inline int grid_for(long long work, int block) {
   long long g = (work + block - 1) / block;
   if (g > 2048) g = 2048;
@@ -389,6 +416,16 @@ int larva_gather_patches(const unsigned char* data, const long long* offsets, co
   if (!data || !offsets || !hw || !draws || !out || B <= 0 || P <= 0 || mult <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(gather_patches_kernel, dim3(grid_for((long long)B * 3 * P * P, 256)), dim3(256), 0,
                      (hipStream_t)stream, data, offsets, hw, draws, out, B, P, mult);
+  return (int)hipGetLastError();
+}
+
+// acc[0] += sum over the C x H x W output of (truth_u8 - clip(rint(out), 0, 255))^2; the caller
+// zeroes acc.  PSNR = 10 log10(255^2 * C*H*W / acc).
+int larva_sqerr_u8(const float* out, const unsigned char* truth, int C, int H, int W, int TH, int TW,
+                   unsigned long long* acc, void* stream) {
+  if (!out || !truth || !acc || C <= 0 || H <= 0 || W <= 0 || TH < H || TW < W) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sqerr_u8_kernel, dim3(grid_for((long long)C * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                     out, truth, C, H, W, TH, TW, acc);
   return (int)hipGetLastError();
 }
 

@@ -58,6 +58,8 @@ SIGNATURES = {
                                              ctypes.c_float, ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p]),
     "larva_gather_patches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_sqerr_u8": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "larva_adamw_step": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p]),

@@ -304,3 +304,24 @@ def adamw_step_host(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_
     hip_lib.check(lib.larva_adamw_step_host(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), int(step),
                                             float(lr), beta1, beta2, eps, weight_decay, grad_scale, n, _stream()),
                   "larva_adamw_step_host")
+
+
+def psnr_u8(out_chw, truth_u8):
+    """RGB PSNR of validate.py:17-27 computed on the device: out_chw float [C][H][W] (device),
+    truth_u8 uint8 [C][TH][TW] (device), truth cropped top-left to the output size.  Returns a float
+    (one 8-byte read-back instead of the whole HR image)."""
+    import math
+    lib = hip_lib.load()
+    _chk(out_chw, "out")
+    if not truth_u8.is_cuda or truth_u8.dtype != torch.uint8 or not truth_u8.is_contiguous():
+        raise RuntimeError("larvanet_amd: truth must be a contiguous uint8 tensor on the HIP device")
+    C, H, W = (int(v) for v in out_chw.shape)
+    TC, TH, TW = (int(v) for v in truth_u8.shape)
+    if TC != C or TH < H or TW < W:
+        raise RuntimeError("larvanet_amd: truth image smaller than the output")
+    acc = torch.zeros(1, device=out_chw.device, dtype=torch.int64)
+    hip_lib.check(lib.larva_sqerr_u8(out_chw.data_ptr(), truth_u8.data_ptr(), C, H, W, TH, TW, acc.data_ptr(),
+                                     _stream()), "larva_sqerr_u8")
+    sq = int(acc.item())
+    mse = sq / float(C * H * W)
+    return float("inf") if mse == 0 else 10.0 * math.log10(255.0 ** 2 / mse)

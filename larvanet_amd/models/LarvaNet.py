@@ -392,6 +392,8 @@ class LarvaNet(BaseModel):
             self.validate_for_train(args, val_dataloader)
             if ldist.is_main():
                 self.save(base_path=args.train_path)
+                if getattr(args, "save_train_state", False):
+                    self.save_training_state(base_path=args.train_path)
                 print(f"saved a model checkpoint at volume {self.total_volume/1e9:.0f}G")
             if summary is not None:
                 self._write_summary(summary, loss, input_tensor, out, truth_tensor)
@@ -419,14 +421,24 @@ class LarvaNet(BaseModel):
         with torch.no_grad():
             for image_index in range(ldist.rank(), num_images, ldist.world_size()):
                 input_image, truth_image, _ = dataloader.get_image_pair(image_index=image_index, scale=4)
-                output_image = image_to_uint8(self.upscale(input_list=[input_image], scale=4)[0])
-                truth_image = fit_truth_image_size(output_image=output_image, truth_image=image_to_uint8(truth_image))
-                psnr_sum += image_psnr(output_image=output_image, truth_image=truth_image)
+                psnr_sum += self.image_psnr(input_image, truth_image)
         average_psnr = ldist.allreduce_scalar_sum(psnr_sum, self.device) / max(num_images, 1)
         print(f"step {self.global_step}, volume {self.total_volume/1e9:.0f}G,"
               f" psnr={average_psnr:.8f}, lr = {self.get_lr():.8f}")
         self.scheduler.step(average_psnr)
         return average_psnr
+
+    def image_psnr(self, input_image, truth_image):
+        """PSNR of one validation pair under the validate.py protocol (uint8 round/clip, truth
+        cropped top-left, all RGB pixels).  On a HIP device the conversion and the squared error
+        run in one kernel and only 8 bytes come back; the numbers equal the host protocol's."""
+        if self.device.type == "cuda":
+            out = self.model(self._to_input_tensor([input_image]))[0].contiguous()
+            truth8 = torch.from_numpy(np.ascontiguousarray(image_to_uint8(truth_image))).to(self.device)
+            return K.psnr_u8(out, truth8)
+        output_image = image_to_uint8(self.upscale(input_list=[input_image], scale=4)[0])
+        truth8 = fit_truth_image_size(output_image=output_image, truth_image=image_to_uint8(truth_image))
+        return float(image_psnr(output_image=output_image, truth_image=truth8))
 
     # ------------------------------------------------------------------ inference
     def _to_input_tensor(self, input_list):
@@ -454,6 +466,29 @@ class LarvaNet(BaseModel):
     def restore(self, ckpt_path, target=None):
         self.model.load_state_dict(torch.load(ckpt_path, map_location=self.device))
         self.model.invalidate_packed_weights()
+
+    def save_training_state(self, base_path):
+        """Optimizer moments, LR-scheduler state, step / volume counters and RNG states next to
+        the reference-compatible weight file (the reference can only resume weights + --global_step,
+        models/LarvaNet.py:183-188, train_larva.py:43-47,81-83)."""
+        path = os.path.join(base_path, "train_state_step%d.pth" % self.global_step)
+        opt = self.optim.training_state() if hasattr(self.optim, "training_state") else \
+            {"flat": False, "torch": self.optim.state_dict()}
+        torch.save({"global_step": self.global_step, "total_volume": self.total_volume,
+                    "temp_volume": self.temp_volume, "optimizer": opt, "scheduler": self.scheduler.state_dict(),
+                    "torch_rng": torch.get_rng_state(), "numpy_rng": np.random.get_state()}, path)
+        return path
+
+    def restore_training_state(self, path):
+        st = torch.load(path, map_location="cpu", weights_only=False)
+        self.global_step, self.total_volume, self.temp_volume = st["global_step"], st["total_volume"], st["temp_volume"]
+        if hasattr(self.optim, "load_training_state"):
+            self.optim.load_training_state(st["optimizer"])
+        else:
+            self.optim.load_state_dict(st["optimizer"]["torch"])
+        self.scheduler.load_state_dict(st["scheduler"])
+        torch.set_rng_state(st["torch_rng"])
+        np.random.set_state(st["numpy_rng"])
 
     def get_model(self):
         return self.model

@@ -58,6 +58,25 @@ class FlatAdamW(torch.optim.AdamW):
                           g["eps"], g["weight_decay"])
         return None
 
+    def training_state(self):
+        """Everything needed to continue training bit-for-bit (the reference saves weights only)."""
+        if self._flat_p is not None:
+            return {"flat": True, "t": self._t, "m": self._m.detach().cpu().clone(), "v": self._v.detach().cpu().clone(),
+                    "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        return {"flat": False, "torch": super().state_dict()}
+
+    def load_training_state(self, st):
+        if st.get("flat") and self._flat_p is not None:
+            self._t = int(st["t"])
+            self._m.copy_(st["m"].to(self._m.device))
+            self._v.copy_(st["v"].to(self._v.device))
+            for g, saved in zip(self.param_groups, st["param_groups"]):
+                g.update(saved)
+        elif not st.get("flat"):
+            super().load_state_dict(st["torch"])
+        else:
+            raise RuntimeError("larvanet_amd: flat optimizer state cannot be loaded into a per-tensor optimizer")
+
     def _fallback_step(self, closure):
         # hand the moments over to torch's per-tensor state once, then stay on torch's path
         if self._t > 0 and not self.state:

@@ -63,6 +63,9 @@ def build_parser():
     p.add_argument("--restore_target", type=str)
     p.add_argument("--global_step", type=int, default=0)
     p.add_argument("--async_loss", action="store_true", help="do not read the loss back every step")
+    p.add_argument("--save_train_state", action="store_true",
+                   help="also save optimizer / scheduler / counters / RNG with every checkpoint")
+    p.add_argument("--resume_state", type=str, help="train_state_step*.pth to continue from (with --restore_path)")
     return p
 
 
@@ -93,6 +96,9 @@ def main(argv=None):
     if args.restore_path is not None:
         model.restore(ckpt_path=args.restore_path, target=args.restore_target)
         print("restored the model")
+    if args.resume_state is not None:
+        model.restore_training_state(args.resume_state)
+        print("restored the training state at step %d" % model.global_step)
 
     writers = {s: (make_summary_writer(os.path.join(args.train_path, "x%d" % s)) if rank == 0 else _NullSummary())
                for s in scales}

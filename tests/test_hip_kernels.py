@@ -373,3 +373,18 @@ def test_conv3x3_row_pitch(hip_device, W, P):
     t = K.conv3x3(h, fwd, C, bias=bd, shuffle=True, base=_dev(base, hip_device), logical_w=W)
     torch.cuda.synchronize()
     _report("pitched tail", t.cpu().numpy(), R.pixel_shuffle(R.conv3x3(ref1, w, b), 4) + base, 2e-5)
+
+
+def test_device_psnr_matches_validate_protocol(hip_device, golden):
+    from larvanet_amd import kernels as K, metrics
+    g = golden("f7_validate_helpers.npz")
+    # the .5 / clip cases of the fixture, as a 3x2x4 "image" against an arbitrary uint8 truth
+    img = g["img"]
+    truth = np.random.RandomState(1).randint(0, 256, size=(3, 5, 6)).astype(np.uint8)
+    got = K.psnr_u8(_dev(img, hip_device), torch.from_numpy(truth).to(hip_device))
+    o8 = metrics.image_to_uint8(img)
+    ref = float(metrics.image_psnr(o8, metrics.fit_truth_image_size(o8, truth)))
+    assert abs(got - ref) < 1e-4, (got, ref)
+    o = g["o_img"].astype(np.float32) + 0.25
+    got2 = K.psnr_u8(_dev(o, hip_device), torch.from_numpy(g["t_big"]).to(hip_device))
+    assert abs(got2 - float(g["psnr"])) < 1e-4

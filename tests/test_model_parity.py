@@ -206,3 +206,25 @@ def test_device_resident_training_and_runtime_probe(hip_device, tmp_path, capsys
     res = runtime.main(["--model=LarvaNet", "--dataloader=synthetic_loader", "--num_modules=1", "--num_blocks=1",
                         "--synthetic_images=2", "--synthetic_lr_size=20"])
     assert res[4] > 0
+
+
+def test_training_state_resume_is_bit_exact(hip_device, tmp_path):
+    """weights + optimizer moments + scheduler + counters: 2 steps, save, 2 more == 4 straight."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(2, 3, 12, 12, generator=g) * 255).to(hip_device)
+    t = (torch.rand(2, 3, 48, 48, generator=g) * 255).to(hip_device)
+    args = types.SimpleNamespace(train_path=str(tmp_path))
+    val = FakeValLoader(7)
+    a = _model("LarvaNet", ["--num_modules=1", "--num_blocks=2"], training=True, seed=2)
+    la = [a.train_step_larva(args, val, x, t) for _ in range(4)]
+    b = _model("LarvaNet", ["--num_modules=1", "--num_blocks=2"], training=True, seed=2)
+    lb = [b.train_step_larva(args, val, x, t) for _ in range(2)]
+    wpath, spath = b.save(str(tmp_path)), b.save_training_state(str(tmp_path))
+    c = _model("LarvaNet", ["--num_modules=1", "--num_blocks=2"], training=True, seed=99)
+    c.restore(wpath)
+    c.restore_training_state(spath)
+    assert c.global_step == 2
+    lc = [c.train_step_larva(args, val, x, t) for _ in range(2)]
+    assert lb + lc == la
+    for k, v in a.model.state_dict().items():
+        assert torch.equal(v, c.model.state_dict()[k]), k
