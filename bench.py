@@ -209,6 +209,10 @@ def main():
     value = world * HR_PIX_PER_BATCH / (ms_per_step * 1e-3) / 1e6
 
     if rank != 0:
+        if world > 1:
+            import torch.distributed as td
+            td.barrier()  # rank 0 finishes its extra single-GPU measurements, then everybody leaves together
+            td.destroy_process_group()
         return
 
     # inference forward (extra information)
@@ -239,7 +243,11 @@ def main():
     }
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as td
+        td.barrier()
+        td.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -363,7 +363,14 @@ class LarvaNet(BaseModel):
         """loss and gradients of one batch (models/LarvaNet.py:101-113)."""
         if self.use_hip_graph and input_tensor.is_cuda:
             if getattr(self, "_graph_shape", None) != self._graph_key(input_tensor, truth_tensor):
-                self._capture_step(input_tensor, truth_tensor)
+                try:
+                    self._capture_step(input_tensor, truth_tensor)
+                except Exception as e:  # capture is an optimisation: fall back to plain launches
+                    print("WARNING: hipGraph capture failed (%s: %s); continuing with eager launches"
+                          % (type(e).__name__, e))
+                    self.use_hip_graph = False
+                    torch.cuda.synchronize()
+                    return self._forward_backward(input_tensor, truth_tensor)
             self._static_in.copy_(input_tensor)
             self._static_truth.copy_(truth_tensor)
             self._graph.replay()  # gradients are overwritten in place: no zero_grad needed
