@@ -96,8 +96,7 @@ int larva_conv3x3_wgrad_dma(const float* const* dy, const float* const* x, float
 int larva_bicubic4_fwd(const float* in, float* out, int N, int C, int H, int W, void* stream);
 
 /* ---- L1 loss ---------------------------------------------------------------------------------
- * nn.L1Loss() forward/backward, models/LarvaNet.py:85,108,113.  Pointers 16-byte aligned.  The
- * forward workspace (larva_l1_workspace_floats() floats) must be zero-filled once at allocation. */
+ * nn.L1Loss() forward/backward, models/LarvaNet.py:85,108,113.  Pointers 16-byte aligned. */
 int larva_l1_workspace_floats(void);
 int larva_l1_fwd(const float* a, const float* b, long long numel, float* partial, float* loss,
                  void* stream);
