@@ -406,10 +406,13 @@ class ExitFn(torch.autograd.Function):
         ctx.pcs = pcs
         ctx.wshape = tuple(w1.shape)
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)  # no 7 MB zero gradient for the non-differentiable image output
         return out, term
 
     @staticmethod
     def backward(ctx, _dout, gterm):
+        if gterm is None:
+            return (None,) * 8
         fea, h, out, truth = ctx.saved_tensors
         pcs = ctx.pcs
         c = ctx.wshape[0]
