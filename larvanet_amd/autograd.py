@@ -9,6 +9,8 @@ Backward structure of one residual block  y = x + conv2(relu(conv1(x)))  given g
     dW2, db2 = wgrad(g, h);  dW1, db1 = wgrad(dh, x)
 All weight gradients of a module are computed by ONE batched launch at the end of its backward.
 """
+import os
+
 import torch
 
 from . import kernels as K
@@ -229,13 +231,79 @@ def _splits(njobs):
     return max(1, _WGRAD_WORKGROUPS // njobs)
 
 
-def _wgrad(jobs, cout, cin):
-    """jobs: list of (dy, x, weight shape, cin_off, cin_valid, shared dw or None) ->
-    list of (dw, db) fresh tensors.  Inside a SideStreams scope the launches go to the wgrad
-    side stream (the results are first needed by the optimizer, after the scope's join)."""
+class DeferredWgrad:
+    """Weight gradients are never on the critical path of backward, and their cost has a part
+    that scales with the number of WORKGROUPS launched, not with the work: every workgroup writes
+    one partial image (83 KB at 48x48 channels) that the fixed-order reduction reads back.  One
+    launch per autograd node (8 layers x 32 workgroups, 2 x 128 for a leg) means ~2000 partial
+    images = 340 MB of extra traffic per step.  Inside `with StepScope(...)` the layers whose
+    gradient is written in place (GradBucket) are therefore only QUEUED during backward and issued
+    when the scope ends: all layers of one kernel shape in as few launches as the job table
+    allows, each launch ~256 workgroups = one per CU.  Only in-place targets are deferred: a
+    tensor handed back to autograd must be complete when backward() returns it."""
+
+    active = False
+    jobs_per_launch = int(os.environ.get("LARVA_WGRAD_JOBS", "32"))
+    _pending = {}   # (cout, cin) -> list of jobs (they keep dy / x / targets alive)
+
+    @classmethod
+    def push(cls, cout, cin, jobs):
+        cls._pending.setdefault((cout, cin), []).extend(jobs)
+
+    @classmethod
+    def flush(cls):
+        pending, cls._pending = cls._pending, {}
+        cap = max(1, min(cls.jobs_per_launch, K.max_wgrad_jobs()))
+        for (cout, cin), jobs in pending.items():
+            launches = -(-len(jobs) // cap)
+            per = -(-len(jobs) // launches)  # even chunks: 40 layers -> 20 + 20, not 32 + 8
+            for i in range(0, len(jobs), per):
+                chunk = jobs[i:i + per]
+                K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
+
+    @classmethod
+    def drop(cls):
+        cls._pending = {}
+
+
+class StepScope:
+    """The plugin's forward+backward of one batch: optional side streams, deferred wgrad.
+    Leaving the scope joins the side streams and issues the queued weight gradients, so they are
+    complete on the current stream afterwards (also as the tail of a hipGraph capture)."""
+
+    def __init__(self, side_streams=False, defer_wgrad=True):
+        self.side_streams = side_streams
+        self.defer_wgrad = defer_wgrad
+
+    def __enter__(self):
+        gpu = torch.cuda.is_available()
+        SideStreams.active = bool(self.side_streams) and gpu
+        DeferredWgrad.active = bool(self.defer_wgrad) and gpu
+        DeferredWgrad.drop()
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        try:
+            if SideStreams.active:
+                SideStreams.join()
+            if exc_type is None:
+                DeferredWgrad.flush()
+        finally:
+            DeferredWgrad.drop()
+            SideStreams.active = False
+            DeferredWgrad.active = False
+        return False
+
+
+def _wgrad(jobs, cout, cin, inplace=False):
+    """jobs: list of (dy, x, weight shape, cin_off, cin_valid, shared dw or None[, shared db]) ->
+    list of (dw, db).  inplace: every dw/db that matters is a GradBucket view, so the whole
+    job may be deferred to the end of the StepScope.  Inside a SideStreams scope with
+    wgrad_on_side the launches go to the wgrad side stream."""
     side = None
     if SideStreams.active and SideStreams.wgrad_on_side:
         side = SideStreams.fork("wgrad", *[t for j in jobs for t in (j[0], j[1])])
+    defer = inplace and DeferredWgrad.active and side is None
     jobs = list(jobs)
     ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
     out, batch = [], []
@@ -244,9 +312,16 @@ def _wgrad(jobs, cout, cin):
             (dy, x, wshape, cin_off, cin_valid, dw_shared) = job[:6]
             db_shared = job[6] if len(job) > 6 else None
             dw = dw_shared if dw_shared is not None else torch.empty(wshape, device=dy.device, dtype=torch.float32)
-            db = db_shared if db_shared is not None else torch.empty((cout,), device=dy.device, dtype=torch.float32)
+            if db_shared is not None or not defer:
+                db = db_shared if db_shared is not None else torch.empty((cout,), device=dy.device,
+                                                                         dtype=torch.float32)
+            else:
+                db = None  # in-place mode and nobody wants this bias gradient
             batch.append({"dy": dy, "x": x, "dw": dw, "db": db, "cin_off": cin_off, "cin_valid": cin_valid})
             out.append((dw, db))
+        if defer:
+            DeferredWgrad.push(cout, cin, batch)
+            batch = []
         for i in range(0, len(batch), 16):
             chunk = batch[i:i + 16]
             parts = K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
@@ -286,7 +361,7 @@ class HeadFn(torch.autograd.Function):
         dy = dy.contiguous()
         cout, cin = ctx.wshape[0], ctx.wshape[1]
         tw, tb = _targets(ctx.pc)
-        (dw, db), = _wgrad([(dy, x16, ctx.wshape, 0, cin, tw, tb)], cout, 16)
+        (dw, db), = _wgrad([(dy, x16, ctx.wshape, 0, cin, tw, tb)], cout, 16, inplace=tw is not None)
         if tw is not None:
             return None, None, None, None
         return None, dw, db, None
@@ -344,7 +419,7 @@ class BodyFn(torch.autograd.Function):
                 g = K.conv3x3(dh, bw1, c, res0=g)
             else:
                 dx = K.conv3x3(dh, bw1, c, res0=g, res1=dy)
-        grads = _wgrad(jobs, c, c)
+        grads = _wgrad(jobs, c, c, inplace=all(_targets(pc)[0] is not None for pc in pcs))
         flat = []
         for pc, (dw, db) in zip(pcs, grads):
             flat += [None, None] if _targets(pc)[0] is not None else [dw, db]
@@ -378,7 +453,8 @@ class LegFn(torch.autograd.Function):
         dh = K.conv3x3(dyl, bw2, c, mask=h)
         dfea = K.conv3x3(dh, bw1, c)
         (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0]),
-                                         (dyl, h, ctx.wshape, 0, c) + _targets(pcs[1])], c, c)
+                                         (dyl, h, ctx.wshape, 0, c) + _targets(pcs[1])], c, c,
+                                        inplace=all(_targets(pc)[0] is not None for pc in pcs))
         if _targets(pcs[0])[0] is not None:
             dw1 = db1 = None
         if _targets(pcs[1])[0] is not None:
@@ -422,7 +498,8 @@ class ExitFn(torch.autograd.Function):
         dh = K.conv3x3(dyl, bw2, c, mask=h)
         dfea = K.conv3x3(dh, bw1, c)
         (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0]),
-                                         (dyl, h, ctx.wshape, 0, c) + _targets(pcs[1])], c, c)
+                                         (dyl, h, ctx.wshape, 0, c) + _targets(pcs[1])], c, c,
+                                        inplace=all(_targets(pc)[0] is not None for pc in pcs))
         if _targets(pcs[0])[0] is not None:
             dw1 = db1 = None
         if _targets(pcs[1])[0] is not None:
@@ -470,7 +547,7 @@ class MergeFn(torch.autograd.Function):
         tw, tb = _targets(ctx.pc)
         dw = tw if tw is not None else torch.empty(ctx.wshape, device=dy.device, dtype=torch.float32)
         jobs = [(dy, f, ctx.wshape, i * c, c, dw, tb if i == 0 else None) for i, f in enumerate(feats)]
-        res = _wgrad(jobs, cout, c)
+        res = _wgrad(jobs, cout, c, inplace=tw is not None)
         db = res[0][1]
         if tw is not None:
             return (None, None, None) + tuple(dfeats)

@@ -25,7 +25,7 @@
 
 namespace larva {
 
-constexpr int kMaxJobs = 16;
+constexpr int kMaxJobs = 32;
 
 struct WgradJob {
   const float* dy;   // [N][COUT][H][W]
@@ -286,11 +286,13 @@ struct ReduceJob {
   int cin_off;           // first input channel of this job inside dw
   int cin_valid;         // channels of this job that exist in dw (3 for the head, else CIN)
   int w_cin_total;
+  int splits;            // partial images of this job
 };
 
+constexpr int kMaxReduceJobs = 64;
+
 struct ReduceBatch {
-  ReduceJob job[kMaxJobs];
-  int splits;
+  ReduceJob job[kMaxReduceJobs];
   int cout, cin;  // kernel shape of every job in the batch
 };
 
@@ -305,14 +307,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceBatch rb) {
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   const float* p = j.partial + i;
   int k = 0;
-  for (; k + 8 <= rb.splits; k += 8) {
+  for (; k + 8 <= j.splits; k += 8) {
     f32x4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + u) * pf);
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += v[u];
   }
-  for (; k < rb.splits; ++k) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * pf);
+  for (; k < j.splits; ++k) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * pf);
   if (i < n_w) {
     const int lane = (i >> 2) & 63;
     const int t = i >> 8;
@@ -361,26 +363,22 @@ long long larva_wgrad_partial_floats(int cout, int cin, int splits) {
   return (long long)splits * ((long long)(cin / 16) * 9 * (cout / 16) * 256 + cout);
 }
 
-// Weight + bias gradients of `njobs` (<= 16) same-shape 3x3 convolutions in two launches.
-// Job i: dy[i] [N][cout][H][W], x[i] [N][cin][H][W] -> partial[i] (workspace of
-// larva_wgrad_partial_floats floats) -> dw[i] [cout][w_cin_total[i]][3][3] at input-channel
-// offset cin_off[i] (only the first cin_valid[i] channels are written; the rest of `cin` is
-// zero padding of x), db[i] [cout] (may be null).  Gradients are OVERWRITTEN, not accumulated.
-int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* const* partial,
-                        float* const* dw, float* const* db, const int* cin_off,
-                        const int* cin_valid, const int* w_cin_total, int njobs, int splits,
-                        int N, int cout, int cin, int H, int W, void* stream) {
+// Phase 1: partial images.  njobs (<= 32) same-shape layers in one launch; job i reads dy[i]
+// [N][cout][H][W] and x[i] [N][cin][H][W] and writes `splits` partial images to partial[i]
+// (larva_wgrad_partial_floats(cout, cin, splits) floats).  Returns the number of partial images
+// actually written per job in *splits_used (splits clamped to the number of tiles).
+int larva_conv3x3_wgrad_partial(const float* const* dy, const float* const* x, float* const* partial,
+                                int njobs, int splits, int N, int cout, int cin, int H, int W,
+                                int* splits_used, void* stream) {
   if (njobs < 1 || njobs > kMaxJobs || splits < 1 || N <= 0 || H <= 0 || W <= 0)
     return (int)hipErrorInvalidValue;
   WgradBatch b{};
-  ReduceBatch rb{};
   bool aligned = (W % 4 == 0);
   for (int i = 0; i < njobs; ++i) {
-    if (!dy[i] || !x[i] || !partial[i] || !dw[i]) return (int)hipErrorInvalidValue;
+    if (!dy[i] || !x[i] || !partial[i]) return (int)hipErrorInvalidValue;
     b.job[i] = WgradJob{dy[i], x[i], partial[i]};
     aligned = aligned && ((reinterpret_cast<uintptr_t>(dy[i]) & 15) == 0) &&
               ((reinterpret_cast<uintptr_t>(x[i]) & 15) == 0);
-    rb.job[i] = ReduceJob{partial[i], dw[i], db ? db[i] : nullptr, cin_off[i], cin_valid[i], w_cin_total[i]};
   }
   b.N = N; b.H = H; b.W = W;
   b.tiles_x = (W + kTileCols - 1) / kTileCols;
@@ -388,7 +386,7 @@ int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* co
   b.vec_ok = aligned ? 1 : 0;
   const int total = N * b.tiles_x * b.tiles_y;
   if (splits > total) splits = total;
-  rb.splits = splits; rb.cout = cout; rb.cin = cin;
+  if (splits_used) *splits_used = splits;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   if (cout == 48 && cin == 48) e = launch_wgrad<48, 48>(b, njobs, splits, s);
@@ -396,10 +394,43 @@ int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* co
   else if (cout == 32 && cin == 32) e = launch_wgrad<32, 32>(b, njobs, splits, s);
   else if (cout == 64 && cin == 64) e = launch_wgrad<64, 64>(b, njobs, splits, s);
   else return (int)hipErrorInvalidValue;
-  if (e != hipSuccess) return (int)e;
+  return (int)e;
+}
+
+// Phase 2: fixed-order sum of the partial images of njobs (<= 64) same-shape layers -- possibly
+// produced by several phase-1 launches, each with its own split count -- into PyTorch-layout
+// gradients: dw[i] [cout][w_cin_total[i]][3][3] at input-channel offset cin_off[i] (the first
+// cin_valid[i] channels are written; the rest of `cin` is zero padding of x), db[i] [cout] (may
+// be null).  Gradients are OVERWRITTEN, not accumulated.  One launch: a training step reduces
+// all of its layers at the end of backward instead of once per module.
+int larva_wgrad_reduce(const float* const* partial, float* const* dw, float* const* db,
+                       const int* cin_off, const int* cin_valid, const int* w_cin_total,
+                       const int* splits, int njobs, int cout, int cin, void* stream) {
+  if (njobs < 1 || njobs > kMaxReduceJobs || cout % 16 || cin % 16) return (int)hipErrorInvalidValue;
+  ReduceBatch rb{};
+  for (int i = 0; i < njobs; ++i) {
+    if (!partial[i] || !dw[i] || splits[i] < 1) return (int)hipErrorInvalidValue;
+    rb.job[i] = ReduceJob{partial[i], dw[i], db ? db[i] : nullptr, cin_off[i], cin_valid[i], w_cin_total[i],
+                          splits[i]};
+  }
+  rb.cout = cout; rb.cin = cin;
   const int pf = (cin / 16) * 9 * (cout / 16) * 256 + cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((pf / 4 + 255) / 256, njobs), dim3(256), 0, s, rb);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((pf / 4 + 255) / 256, njobs), dim3(256), 0, (hipStream_t)stream,
+                     rb);
   return (int)hipGetLastError();
+}
+
+// Both phases for njobs (<= 32) layers.
+int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* const* partial,
+                        float* const* dw, float* const* db, const int* cin_off,
+                        const int* cin_valid, const int* w_cin_total, int njobs, int splits,
+                        int N, int cout, int cin, int H, int W, void* stream) {
+  int used = 0;
+  int rc = larva_conv3x3_wgrad_partial(dy, x, partial, njobs, splits, N, cout, cin, H, W, &used, stream);
+  if (rc) return rc;
+  int sp[kMaxJobs];
+  for (int i = 0; i < njobs; ++i) sp[i] = used;
+  return larva_wgrad_reduce(partial, dw, db, cin_off, cin_valid, w_cin_total, sp, njobs, cout, cin, stream);
 }
 
 }  // extern "C"

@@ -38,6 +38,11 @@ SIGNATURES = {
     "larva_conv3x3_wgrad": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_conv3x3_wgrad_partial": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   _c_int_p, ctypes.c_void_p]),
+    "larva_wgrad_reduce": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_conv3x3_wgrad_dma": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

@@ -2,11 +2,12 @@
 every byte of arithmetic happens in liblarva_hip.so.  Each wrapper validates what the kernel and
 its grid assume (device, dtype, contiguity, shapes) before launching.
 """
+import ctypes
+import os
+
 import torch
 
 from . import hip_lib
-
-import os
 
 _SUPPORTED_COUT = (32, 48, 64)
 _WGRAD_VARIANT = os.environ.get("LARVA_WGRAD", "reg")  # "dma": experimental LDS-DMA variant
@@ -145,12 +146,16 @@ def wgrad_partial_floats(cout, cin, splits):
     return int(hip_lib.load().larva_wgrad_partial_floats(cout, cin, splits))
 
 
+def max_wgrad_jobs():
+    return 16 if _WGRAD_VARIANT == "dma" else 32
+
+
 def conv3x3_wgrad(jobs, cout, cin, splits):
-    """jobs: list (<= 16) of dicts {dy, x, dw, db (or None), cin_off, cin_valid}; dw/db are
+    """jobs: list (<= max_wgrad_jobs()) of dicts {dy, x, dw, db (or None), cin_off, cin_valid}; dw/db are
     overwritten.  All jobs share (N, cout, cin, H, W)."""
     lib = hip_lib.load()
-    if not 1 <= len(jobs) <= 16:
-        raise RuntimeError("larvanet_amd: 1..16 wgrad jobs per call")
+    if not 1 <= len(jobs) <= max_wgrad_jobs():
+        raise RuntimeError("larvanet_amd: 1..%d wgrad jobs per call" % max_wgrad_jobs())
     N, _, H, W = (int(v) for v in jobs[0]["dy"].shape)
     dys, xs, parts, dws, dbs, offs, valids, totals, keep = [], [], [], [], [], [], [], [], []
     nfl = wgrad_partial_floats(cout, cin, splits)
@@ -184,6 +189,58 @@ def conv3x3_wgrad(jobs, cout, cin, splits):
         len(jobs), splits, N, cout, cin, H, W, _stream())
     hip_lib.check(code, "larva_conv3x3_wgrad")
     return keep
+
+
+def conv3x3_wgrad_partial(jobs, cout, cin, splits):
+    """Phase 1 only: jobs (<= 32 dicts {dy, x}) -> (partial tensors, splits actually used).
+    Feed them to wgrad_reduce later (the partials must stay alive until then)."""
+    lib = hip_lib.load()
+    if not 1 <= len(jobs) <= 32:
+        raise RuntimeError("larvanet_amd: 1..32 wgrad jobs per call")
+    N, _, H, W = (int(v) for v in jobs[0]["dy"].shape)
+    splits = max(1, min(int(splits), N * ((H + 2) // 3) * ((W + 47) // 48)))  # the library's clamp
+    nfl = wgrad_partial_floats(cout, cin, splits)
+    dys = [_chk(j["dy"], "dy", (N, cout, H, W)) for j in jobs]
+    xs = [_chk(j["x"], "x", (N, cin, H, W)) for j in jobs]
+    parts = [torch.empty(nfl, device=jobs[0]["dy"].device, dtype=torch.float32) for _ in jobs]
+    used = ctypes.c_int(0)
+    code = lib.larva_conv3x3_wgrad_partial(
+        hip_lib.ptr_array(dys), hip_lib.ptr_array(xs), hip_lib.ptr_array([p.data_ptr() for p in parts]),
+        len(jobs), splits, N, cout, cin, H, W, ctypes.byref(used), _stream())
+    hip_lib.check(code, "larva_conv3x3_wgrad_partial")
+    return parts, int(used.value)
+
+
+def wgrad_reduce(jobs, cout, cin):
+    """Phase 2: jobs (<= 64 dicts {partial, splits, dw, db (or None), cin_off, cin_valid}) of one
+    kernel shape, reduced in ONE launch; dw/db are overwritten."""
+    lib = hip_lib.load()
+    if not 1 <= len(jobs) <= 64:
+        raise RuntimeError("larvanet_amd: 1..64 reduce jobs per call")
+    parts, dws, dbs, offs, valids, totals, splits = [], [], [], [], [], [], []
+    for j in jobs:
+        dw = j["dw"]
+        _chk(dw, "dw")
+        if dw.dim() != 4 or int(dw.shape[0]) != cout or tuple(dw.shape[2:]) != (3, 3):
+            raise RuntimeError("larvanet_amd: dw must be [cout][cin_total][3][3]")
+        total = int(dw.shape[1])
+        off = int(j.get("cin_off", 0))
+        valid = int(j.get("cin_valid", cin))
+        if off < 0 or valid < 1 or valid > cin or off + valid > total:
+            raise RuntimeError("larvanet_amd: wgrad channel slice out of range")
+        sp = int(j["splits"])
+        parts.append(_chk(j["partial"], "partial", (wgrad_partial_floats(cout, cin, sp),)))
+        dws.append(dw.data_ptr())
+        dbs.append(_opt(j.get("db"), "db", (cout,)))
+        offs.append(off)
+        valids.append(valid)
+        totals.append(total)
+        splits.append(sp)
+    code = lib.larva_wgrad_reduce(
+        hip_lib.ptr_array(parts), hip_lib.ptr_array(dws), hip_lib.ptr_array(dbs), hip_lib.int_array(offs),
+        hip_lib.int_array(valids), hip_lib.int_array(totals), hip_lib.int_array(splits), len(jobs), cout, cin,
+        _stream())
+    hip_lib.check(code, "larva_wgrad_reduce")
 
 
 def bicubic4(x):

@@ -20,7 +20,7 @@ import torch.nn as nn
 from .. import dist as ldist
 from .. import kernels as K
 from ..autograd import (BodyFn, ExitFn, GradBucket, HeadFn, L1LossFn, LegFn, MeanTermsFn, PackedConv, PaddedWidth,
-                        SideStreams, pack_all)
+                        SideStreams, StepScope, pack_all)
 from ..optim import FlatAdamW, flatten_parameters
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
 from .base import BaseModel
@@ -212,6 +212,8 @@ class LarvaNet(BaseModel):
         # Exits on a side stream: measured neutral-to-negative on MI355X at batch 16 (same-box A/B:
         # 2.36 ms without, 2.36 / 2.45 ms with, depending on the wgrad variant) -- opt-in.
         self.use_side_streams = os.environ.get("LARVA_SIDE_STREAMS", "0") != "0"
+        # weight gradients of all layers in a few large launches at the end of backward
+        self.defer_wgrad = os.environ.get("LARVA_DEFER_WGRAD", "1") != "0"
 
     # ------------------------------------------------------------------ flags
     def _add_args(self, parser):
@@ -332,7 +334,7 @@ class LarvaNet(BaseModel):
         with torch.cuda.stream(side):
             for _ in range(2):  # warm-up outside capture (lazy kernel attributes, allocator pools)
                 self._zero_grad()
-                with SideStreams.scope() if self.use_side_streams else _NoScope():
+                with StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad):
                     loss, _ = self._exit_losses(self._static_in, self._static_truth)
                     loss.backward()
         torch.cuda.current_stream().wait_stream(side)
@@ -340,7 +342,7 @@ class LarvaNet(BaseModel):
         graph = torch.cuda.CUDAGraph()
         # thread_local: a process-group watchdog thread must not abort the capture
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            with SideStreams.scope() if self.use_side_streams else _NoScope():
+            with StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad):
                 loss, out = self._exit_losses(self._static_in, self._static_truth)
                 loss.backward()
         self._graph, self._graph_loss, self._graph_out = graph, loss, out
@@ -376,7 +378,7 @@ class LarvaNet(BaseModel):
             self._graph.replay()  # gradients are overwritten in place: no zero_grad needed
             return self._graph_loss, self._graph_out
         self._zero_grad()
-        with SideStreams.scope() if self.use_side_streams else _NoScope():
+        with StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad):
             loss, out = self._exit_losses(input_tensor, truth_tensor)
             loss.backward()
         return loss, out

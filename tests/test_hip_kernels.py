@@ -193,6 +193,31 @@ def test_wgrad_batched_jobs_and_slices(hip_device):
     _report("job2.db", jobs[2]["db"].cpu().numpy(), refs[2][1], 3e-5)
 
 
+def test_wgrad_split_phases_match_the_fused_call(hip_device):
+    """partial launches with different split counts + ONE reduce launch == per-batch fused calls."""
+    from larvanet_amd import kernels as K
+    rng = np.random.default_rng(31)
+    groups = []
+    for njobs, splits in ((3, 4), (1, 16), (2, 1000)):  # 1000 > tiles: clamped by the library
+        jobs = [{"dy": _dev(_rand(rng, (2, 48, 9, 52), 1e-3), hip_device),
+                 "x": _dev(_rand(rng, (2, 48, 9, 52), 20.0), hip_device)} for _ in range(njobs)]
+        groups.append((jobs, splits))
+    fused, queued = [], []
+    for jobs, splits in groups:
+        ref = [dict(j, dw=torch.empty((48, 48, 3, 3), device=hip_device), db=torch.empty(48, device=hip_device))
+               for j in jobs]
+        K.conv3x3_wgrad(ref, 48, 48, splits)
+        fused += ref
+        parts, used = K.conv3x3_wgrad_partial(jobs, 48, 48, splits)
+        assert 1 <= used <= splits
+        queued += [{"partial": p, "splits": used, "dw": torch.empty((48, 48, 3, 3), device=hip_device),
+                    "db": torch.empty(48, device=hip_device)} for p in parts]
+    K.wgrad_reduce(queued, 48, 48)
+    torch.cuda.synchronize()
+    for a, b in zip(fused, queued):
+        assert torch.equal(a["dw"], b["dw"]) and torch.equal(a["db"], b["db"])
+
+
 def test_wgrad_is_deterministic(hip_device):
     from larvanet_amd import kernels as K
     rng = np.random.default_rng(5)
