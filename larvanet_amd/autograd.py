@@ -219,6 +219,17 @@ class GradBucket:
         """False if somebody replaced or dropped a .grad (then fall back to autograd's own)."""
         return all(p.grad is view for p, view in self._pairs)
 
+    def span(self, tensors):
+        """[lo, hi) in floats of the part of the flat buffer that `tensors` (views of it) cover."""
+        base = self.flat.data_ptr()
+        lo, hi = self.flat.numel(), 0
+        for t in tensors:
+            off = (t.data_ptr() - base) // 4
+            if off < 0 or off + t.numel() > self.flat.numel():
+                return None
+            lo, hi = min(lo, off), max(hi, off + t.numel())
+        return (lo, hi) if hi > lo else None
+
 
 def _targets(pc):
     """(dw, db) destinations of a conv's gradients: the bucket views, or None = allocate."""
@@ -250,20 +261,58 @@ class DeferredWgrad:
     def push(cls, cout, cin, jobs):
         cls._pending.setdefault((cout, cin), []).extend(jobs)
 
+    _late = []      # launches held back by a split flush: [(cout, cin, jobs)]
+
     @classmethod
-    def flush(cls):
+    def _launches(cls):
         pending, cls._pending = cls._pending, {}
         cap = max(1, min(cls.jobs_per_launch, K.max_wgrad_jobs()))
+        out = []
         for (cout, cin), jobs in pending.items():
+            # from the end of the gradient bucket downwards (= roughly the order backward produced
+            # them): a split flush then completes a contiguous suffix of the bucket first
+            jobs = sorted(jobs, key=lambda j: -j["dw"].data_ptr())
             launches = -(-len(jobs) // cap)
             per = -(-len(jobs) // launches)  # even chunks: 40 layers -> 20 + 20, not 32 + 8
-            for i in range(0, len(jobs), per):
-                chunk = jobs[i:i + per]
-                K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
+            out += [(cout, cin, jobs[i:i + per]) for i in range(0, len(jobs), per)]
+        out.sort(key=lambda l: -max(j["dw"].data_ptr() for j in l[2]))
+        return out
+
+    @staticmethod
+    def _issue(launches):
+        for cout, cin, chunk in launches:
+            K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
+
+    @classmethod
+    def flush(cls, split=False):
+        """Issue the queued layers.  split: only the first half of the launches (the layers
+        backward reached first = the END of the flat gradient bucket) goes out now; the rest
+        waits for flush_late(), so that a data-parallel caller can start all-reducing the first
+        half while the second is still being computed.  Returns the tensors the issued launches
+        write (dw, db ...) when split, else None."""
+        launches = cls._launches()
+        n_early = len(launches) // 2 if split else len(launches)
+        if split and n_early == 0:
+            n_early = len(launches)
+        cls._issue(launches[:n_early])
+        cls._late = launches[n_early:]
+        if not split:
+            return None
+        return [t for _, _, chunk in launches[:n_early] for j in chunk for t in (j["dw"], j["db"]) if t is not None]
+
+    @classmethod
+    def late_targets(cls):
+        return [t for _, _, chunk in cls._late for j in chunk for t in (j["dw"], j["db"]) if t is not None]
+
+    @classmethod
+    def flush_late(cls):
+        late, cls._late = cls._late, []
+        cls._issue(late)
 
     @classmethod
     def drop(cls):
         cls._pending = {}
+        cls._late = []
 
 
 class StepScope:
@@ -271,9 +320,11 @@ class StepScope:
     Leaving the scope joins the side streams and issues the queued weight gradients, so they are
     complete on the current stream afterwards (also as the tail of a hipGraph capture)."""
 
-    def __init__(self, side_streams=False, defer_wgrad=True):
+    def __init__(self, side_streams=False, defer_wgrad=True, split_flush=False):
         self.side_streams = side_streams
         self.defer_wgrad = defer_wgrad
+        self.split_flush = split_flush
+        self.early_targets = None   # split flush: tensors complete when the scope ends
 
     def __enter__(self):
         gpu = torch.cuda.is_available()
@@ -287,9 +338,11 @@ class StepScope:
             if SideStreams.active:
                 SideStreams.join()
             if exc_type is None:
-                DeferredWgrad.flush()
+                self.early_targets = DeferredWgrad.flush(split=self.split_flush)
+            else:
+                DeferredWgrad.drop()
         finally:
-            DeferredWgrad.drop()
+            DeferredWgrad._pending = {}
             SideStreams.active = False
             DeferredWgrad.active = False
         return False

@@ -60,6 +60,13 @@ def broadcast_parameters(module, src=0):
         t.copy_(synced)
 
 
+def allreduce_sum(t, async_op=False):
+    """In-place sum over ranks of a (slice of a) flat buffer; async_op -> the Work handle."""
+    if world_size() == 1:
+        return None
+    return td.all_reduce(t, op=td.ReduceOp.SUM, async_op=async_op)
+
+
 def allreduce_gradients(module, bucket=None):
     """Mean of the gradients over ranks as ONE collective.  With a GradBucket the gradients already
     live in one flat buffer (no flatten / unflatten copies); otherwise they are flattened here."""

@@ -214,6 +214,8 @@ class LarvaNet(BaseModel):
         self.use_side_streams = os.environ.get("LARVA_SIDE_STREAMS", "0") != "0"
         # weight gradients of all layers in a few large launches at the end of backward
         self.defer_wgrad = os.environ.get("LARVA_DEFER_WGRAD", "1") != "0"
+        # data parallel: all-reduce the first half of the bucket beside the second half's wgrad kernels
+        self.overlap_allreduce = os.environ.get("LARVA_OVERLAP_ALLREDUCE", "1") != "0"
 
     # ------------------------------------------------------------------ flags
     def _add_args(self, parser):
@@ -326,7 +328,33 @@ class LarvaNet(BaseModel):
     def _graph_key(self, input_tensor, truth_tensor):
         return (tuple(input_tensor.shape), tuple(truth_tensor.shape), str(input_tensor.device))
 
+    def _scope(self):
+        return StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad,
+                         split_flush=self._split_backward())
+
+    def _split_backward(self):
+        """Data parallel with in-place gradients: backward ends in two halves so that the
+        all-reduce of the first overlaps the weight-gradient kernels of the second."""
+        bucket = getattr(self, "grad_bucket", None)
+        return (self.overlap_allreduce and self.defer_wgrad and ldist.world_size() > 1
+                and bucket is not None and bucket.intact(self.model))
+
+    def _note_early(self, scope):
+        """Where the gradients that are complete after the first half live in the flat bucket:
+        self._early_lo = first float of that suffix, or None = no overlap (one collective)."""
+        self._early_lo = None
+        from ..autograd import DeferredWgrad
+        bucket = getattr(self, "grad_bucket", None)
+        if not scope.split_flush or bucket is None or not scope.early_targets:
+            return
+        early, late = bucket.span(scope.early_targets), bucket.span(DeferredWgrad.late_targets())
+        if early is None or late is None:
+            return
+        if early[1] == bucket.flat.numel() and late[1] <= early[0]:
+            self._early_lo = early[0]
+
     def _capture_step(self, input_tensor, truth_tensor):
+        from ..autograd import DeferredWgrad
         self._static_in = input_tensor.clone()
         self._static_truth = truth_tensor.clone()
         side = torch.cuda.Stream()
@@ -334,17 +362,25 @@ class LarvaNet(BaseModel):
         with torch.cuda.stream(side):
             for _ in range(2):  # warm-up outside capture (lazy kernel attributes, allocator pools)
                 self._zero_grad()
-                with StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad):
+                with self._scope():
                     loss, _ = self._exit_losses(self._static_in, self._static_truth)
                     loss.backward()
+                DeferredWgrad.flush_late()
         torch.cuda.current_stream().wait_stream(side)
         self._zero_grad()
         graph = torch.cuda.CUDAGraph()
         # thread_local: a process-group watchdog thread must not abort the capture
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            with StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad):
+            with self._scope() as scope:
                 loss, out = self._exit_losses(self._static_in, self._static_truth)
                 loss.backward()
+        self._note_early(scope)
+        self._graph_late = None
+        if DeferredWgrad._late:  # second half of a split backward: its own graph, same memory pool
+            late = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(late, pool=graph.pool(), capture_error_mode="thread_local"):
+                DeferredWgrad.flush_late()
+            self._graph_late = late
         self._graph, self._graph_loss, self._graph_out = graph, loss, out
         self._graph_shape = self._graph_key(input_tensor, truth_tensor)
 
@@ -376,19 +412,51 @@ class LarvaNet(BaseModel):
             self._static_in.copy_(input_tensor)
             self._static_truth.copy_(truth_tensor)
             self._graph.replay()  # gradients are overwritten in place: no zero_grad needed
+            self._late = self._graph_late.replay if self._graph_late is not None else None
             return self._graph_loss, self._graph_out
+        from ..autograd import DeferredWgrad
         self._zero_grad()
-        with StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad):
+        with self._scope() as scope:
             loss, out = self._exit_losses(input_tensor, truth_tensor)
             loss.backward()
+        self._note_early(scope)
+        self._late = DeferredWgrad.flush_late if DeferredWgrad._late else None
         return loss, out
+
+    def _finish_backward(self):
+        """Second half of a split backward + the data-parallel mean of the gradients
+        (one flat bucket; the all-reduce of the half that is already complete runs on
+        RCCL's stream beside the remaining weight-gradient kernels).  The 1/world_size of the
+        mean is applied inside the optimizer kernel (FlatAdamW.grad_scale)."""
+        late, self._late = getattr(self, "_late", None), None
+        ws = ldist.world_size()
+        bucket = getattr(self, "grad_bucket", None)
+        if ws == 1 or bucket is None or not bucket.intact(self.model):
+            if late is not None:
+                late()
+            ldist.allreduce_gradients(self.model, None)
+            return
+        lo = getattr(self, "_early_lo", None)
+        if late is None or lo is None or lo <= 0:
+            if late is not None:
+                late()
+            ldist.allreduce_sum(bucket.flat)
+        else:
+            work = ldist.allreduce_sum(bucket.flat[lo:], async_op=True)
+            late()
+            ldist.allreduce_sum(bucket.flat[:lo])
+            work.wait()
+        if isinstance(self.optim, FlatAdamW):
+            self.optim.grad_scale = 1.0 / ws
+        else:
+            bucket.flat.mul_(1.0 / ws)
 
     def train_step_larva(self, args, val_dataloader, input_tensor, truth_tensor, summary=None):
         self.global_step += 1
         self.temp_volume += self.volume_per_step
 
         loss, out = self._forward_backward(input_tensor, truth_tensor)
-        ldist.allreduce_gradients(self.model, getattr(self, "grad_bucket", None))  # mean over ranks
+        self._finish_backward()  # rest of a split backward + mean of the gradients over ranks
         self.optim.step()
         self.model.invalidate_packed_weights()  # the kernel-layout weight images are now stale
 

@@ -33,6 +33,7 @@ class FlatAdamW(torch.optim.AdamW):
         self._v = torch.zeros_like(flat_params)
         self._t = 0
         self._plist = params
+        self.grad_scale = 1.0   # gradients are multiplied by this inside the step (1/world_size: mean over ranks)
 
     def _flat_ok(self):
         if self._flat_p is None or self._bucket is None or not self._bucket.intact():
@@ -55,7 +56,7 @@ class FlatAdamW(torch.optim.AdamW):
         self._t += 1
         b1, b2 = g["betas"]
         K.adamw_step_host(self._flat_p, self._bucket.flat, self._m, self._v, self._t, float(g["lr"]), b1, b2,
-                          g["eps"], g["weight_decay"])
+                          g["eps"], g["weight_decay"], self.grad_scale)
         return None
 
     def training_state(self):
@@ -78,6 +79,10 @@ class FlatAdamW(torch.optim.AdamW):
             raise RuntimeError("larvanet_amd: flat optimizer state cannot be loaded into a per-tensor optimizer")
 
     def _fallback_step(self, closure):
+        if self.grad_scale != 1.0:
+            for p in self._plist:
+                if p.grad is not None:
+                    p.grad.mul_(self.grad_scale)
         # hand the moments over to torch's per-tensor state once, then stay on torch's path
         if self._t > 0 and not self.state:
             off = 0

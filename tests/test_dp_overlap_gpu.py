@@ -1,0 +1,95 @@
+"""Data-parallel training step with the split backward: two ranks share the one GPU of the test
+box (gloo carries the collectives, the kernels are the HIP ones), and the step whose all-reduce
+overlaps the second half of the weight-gradient kernels must train exactly like the step that
+reduces the whole bucket at the end -- eager launches and hipGraph replay alike."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Val:
+    def get_num_images(self):
+        return 1
+
+    def get_image_pair(self, image_index, scale):
+        rng = np.random.RandomState(3)
+        return (rng.randint(0, 256, size=(3, 8, 12)).astype(np.float32),
+                rng.randint(0, 256, size=(3, 32, 48)).astype(np.float32), "v")
+
+
+def _worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LARVA_DIST_BACKEND": "gloo"})
+    try:
+        import torch.distributed as td
+        from larvanet_amd import dist as ldist
+        from larvanet_amd.autograd import DeferredWgrad
+        from larvanet_amd.models import LarvaNet as L
+        ldist.init_from_env(backend="gloo")
+        dev = torch.device("cuda", 0)
+        DeferredWgrad.jobs_per_launch = 4  # a small network still ends backward in several launches
+        g = torch.Generator().manual_seed(50 + rank)  # every rank trains on its own patches
+        x = (torch.rand(2, 3, 12, 16, generator=g) * 255).to(dev)
+        t = (torch.rand(2, 3, 48, 64, generator=g) * 255).to(dev)
+        args = types.SimpleNamespace(train_path="/tmp")
+        out = {}
+        for mode in ("whole", "overlap_eager", "overlap_graph"):
+            m = L.create_model()
+            m.parse_args(["--num_modules=2", "--num_blocks=2,1"])
+            torch.manual_seed(7)
+            m.prepare(is_training=True, scales=[4])
+            m.overlap_allreduce = mode != "whole"
+            m.use_hip_graph = mode == "overlap_graph"
+            losses = [m.train_step_larva(args, _Val(), x, t) for _ in range(3)]
+            out[mode] = {"losses": losses, "split_at": getattr(m, "_early_lo", None),
+                         "graph": bool(m.use_hip_graph),
+                         "sd": {k: v.cpu().numpy().copy() for k, v in m.model.state_dict().items()}}
+        torch.cuda.synchronize()
+        q.put((rank, None, out))
+        td.destroy_process_group()
+    except Exception as e:  # hand the failure to the parent instead of hanging its queue
+        import traceback
+        q.put((rank, "%s\n%s" % (e, traceback.format_exc()), None))
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_overlapped_allreduce_trains_like_one_collective(hip_device):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, _ in res:
+        assert err is None, "rank %d: %s" % (rank, err)
+    (_, _, a), (_, _, b) = res
+    assert a["whole"]["split_at"] is None
+    for mode in ("overlap_eager", "overlap_graph"):
+        assert a[mode]["split_at"] and a[mode]["split_at"] > 0, "backward was not split: nothing overlapped"
+    assert a["overlap_graph"]["graph"], "hipGraph capture of the split backward fell back to eager launches"
+    for mode in a:
+        # ranks hold identical weights after training on different patches (mean of the gradients) ...
+        for k in a[mode]["sd"]:
+            assert np.array_equal(a[mode]["sd"][k], b[mode]["sd"][k]), (mode, k)
+        # ... and the overlapped schedule is the same arithmetic as the single collective
+        for k in a[mode]["sd"]:
+            assert np.array_equal(a[mode]["sd"][k], a["whole"]["sd"][k]), (mode, k)
+    assert a["whole"]["losses"] != b["whole"]["losses"]  # the ranks did see different data

@@ -162,7 +162,7 @@ def test_deferred_wgrad_trains_like_per_node_wgrad(hip_device, name, flags):
         m.defer_wgrad = defer
         loss, _ = m._forward_backward(x, t)
         torch.cuda.synchronize()
-        results.append((float(loss), {k: p.grad.cpu().numpy().copy() for k, p in m.model.named_parameters()}))
+        results.append((float(loss.detach()), {k: p.grad.cpu().numpy().copy() for k, p in m.model.named_parameters()}))
     assert results[0][0] == results[1][0]  # the forward pass does not depend on the mode
     for k, ga in results[0][1].items():
         gb = results[1][1][k]
