@@ -72,7 +72,7 @@ int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src,
 
 /* ---- weight / bias gradient ---------------------------------------------------------------
  * Replaces autograd's conv weight/bias gradient for the call sites above (loss.backward(),
- * models/LarvaNet.py:113).  njobs (<= 32) same-shape layers per call; job i reads dy[i]
+ * models/LarvaNet.py:113).  njobs (<= 64) same-shape layers per call; job i reads dy[i]
  * [N][cout][H][W] and x[i] [N][cin][H][W], uses partial[i] (larva_wgrad_partial_floats()
  * floats) as workspace and OVERWRITES dw[i] ([cout][w_cin_total[i]][3][3], channels
  * [cin_off[i], cin_off[i]+cin_valid[i])) and db[i] ([cout], may be NULL).
@@ -83,7 +83,7 @@ int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* co
                         const int* cin_valid, const int* w_cin_total, int njobs, int splits,
                         int N, int cout, int cin, int H, int W, void* stream);
 
-/* The two phases separately: partial images for njobs (<= 32) layers, and the fixed-order
+/* The two phases separately: partial images for njobs (<= 64) layers, and the fixed-order
  * reduction of up to 64 layers' partial images (each with its own split count) in one launch. */
 int larva_conv3x3_wgrad_partial(const float* const* dy, const float* const* x, float* const* partial,
                                 int njobs, int splits, int N, int cout, int cin, int H, int W,

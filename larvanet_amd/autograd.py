@@ -272,9 +272,9 @@ class DeferredWgrad:
             # from the end of the gradient bucket downwards (= roughly the order backward produced
             # them): a split flush then completes a contiguous suffix of the bucket first
             jobs = sorted(jobs, key=lambda j: -j["dw"].data_ptr())
-            launches = -(-len(jobs) // cap)
-            per = -(-len(jobs) // launches)  # even chunks: 40 layers -> 20 + 20, not 32 + 8
-            out += [(cout, cin, jobs[i:i + per]) for i in range(0, len(jobs), per)]
+            # full launches of `cap` layers, then the rest: 40 layers -> 32 x 8 workgroups + 8 x 32
+            # workgroups, both exactly one workgroup per CU (20 + 20 would leave 16 CUs idle twice)
+            out += [(cout, cin, jobs[i:i + cap]) for i in range(0, len(jobs), cap)]
         out.sort(key=lambda l: -max(j["dw"].data_ptr() for j in l[2]))
         return out
 
@@ -291,9 +291,7 @@ class DeferredWgrad:
         half while the second is still being computed.  Returns the tensors the issued launches
         write (dw, db ...) when split, else None."""
         launches = cls._launches()
-        n_early = len(launches) // 2 if split else len(launches)
-        if split and n_early == 0:
-            n_early = len(launches)
+        n_early = max(1, len(launches) // 2) if split else len(launches)
         cls._issue(launches[:n_early])
         cls._late = launches[n_early:]
         if not split:

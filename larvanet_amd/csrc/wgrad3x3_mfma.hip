@@ -23,9 +23,22 @@
 // Roofline: fp32 MFMA, 2*9*Cin*Cout FLOP per pixel (same as the forward conv).
 #include "larva_common.h"
 
+#include <stdlib.h>
+
+#include <type_traits>
+
+// Timing-only ablations of the pipelined kernel (tools/diag_wgrad.py): 1 no MFMA, 2 no staging
+// (loads + LDS writes of the next tile), 4 no operand reads, 8 no bias sums, 16 no LDS writes,
+// 32 no address arithmetic, 64 no global loads, 128 (with 16) wait for the loads without writing.  Results are wrong
+// by construction when nonzero.
+#ifndef WG_DIAG
+#define WG_DIAG 0
+#endif
+
+
 namespace larva {
 
-constexpr int kMaxJobs = 32;
+constexpr int kMaxJobs = 64;
 
 struct WgradJob {
   const float* dy;   // [N][COUT][H][W]
@@ -258,6 +271,323 @@ __device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pipelined variant (16-byte staging path, 48x48 channels): the tile run is double-buffered in
+// LDS and ALL staging work for tile t+1 -- address arithmetic, global loads, LDS writes -- is
+// spread over the 36 k-steps of tile t.  With one wave per SIMD the matrix pipe idles whenever
+// the wave issues anything else for longer than an MFMA's shadow: a v_mfma_f32_16x16x4_f32
+// occupies the pipe for 32 cycles and the vector issue port for 8 of them, so ~24 cycles of other
+// instructions per MFMA are free and every cycle beyond that is lost (measured: the same work
+// lumped between MFMA blocks cost 15.2 us per tile against 10.9 us for the MFMAs alone).  So
+// each k-step is laid out as "gaps" of one MFMA + at most a handful of filler instructions:
+//     gaps 0..7     one LDS read of the NEXT k-step's operands each
+//     gaps 8..11    address + bounds arithmetic of staging slot KS of the next tile (4 VALU each)
+//     gap  12 + w   its global load (out-of-image slots read a zero page instead), w = wave
+//     gap  16 + w   LDS write of slot KS-LAG, loaded LAG k-steps earlier
+// (sched_group_barrier pipeline; no VALU accumulation anywhere: db is an MFMA against ones).
+// One workgroup barrier per tile.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float g_wg_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int COUT, int CIN>
+struct WgPipe {
+  using C = WgCfg<COUT, CIN>;
+  static constexpr int BUF_FLOATS = C::DY_FLOATS + C::X_FLOATS;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_FLOATS * sizeof(float);
+  static constexpr int NSLOT = C::DY_ITERS + C::X_ITERS;
+#ifdef WG_LAG
+  static constexpr int LAG = WG_LAG;   // experiment: load -> LDS-write distance in k-steps
+#else
+  // k-steps between a slot's global load and its LDS write (~0.35 us each).  Longer only costs
+  // registers: at 15 the allocator starts shuttling values through AGPRs (v_accvgpr_* in the loop).
+  static constexpr int LAG = 6;
+#endif
+  static constexpr int MIN_GAPS = C::CT * (C::NB / 4);          // MFMAs per k-step of the lightest wave
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NSLOT + LAG <= 36 && MIN_GAPS >= 17;
+};
+
+// Per-thread, tile-invariant description of staging slot I: element offset of its 16 bytes
+// relative to the image base at tile origin (0, 0); its float index inside an LDS tile buffer
+// packed with its row / column inside the tile.
+template <int COUT, int CIN>
+struct PipeGeom {
+  int goff[WgPipe<COUT, CIN>::NSLOT];
+  int pos[WgPipe<COUT, CIN>::NSLOT];   // LDS float index | r << 16 | 4q << 20 | unused << 30
+};
+
+template <int COUT, int CIN, int I>
+__device__ __forceinline__ void pipe_geom_slot(PipeGeom<COUT, CIN>& g, int tid, int plane, int W) {
+  using C = WgCfg<COUT, CIN>;
+  if constexpr (I < C::DY_ITERS) {
+    int s = tid + I * 256;
+    const bool live = s < C::DY_SLOTS;
+    s = live ? s : 0;
+    const int co = s / (kTileRows * 12);
+    const int rem = s - co * (kTileRows * 12);
+    const int r = rem / 12;
+    const int q = rem - r * 12;
+    g.goff[I] = co * plane + r * W + 4 * q;
+    g.pos[I] = (co * C::PSD + r * kTileCols + 4 * q) | (r << 16) | ((4 * q) << 20) | (live ? 0 : (1 << 30));
+  } else {
+    int s = tid + (I - C::DY_ITERS) * 256;
+    const bool live = s < C::X_SLOTS;
+    s = live ? s : 0;
+    const int ci = s / (kHaloRows * 14);
+    const int rem = s - ci * (kHaloRows * 14);
+    const int r = rem / 14;
+    const int q = rem - r * 14;
+    g.goff[I] = ci * plane + (r - 1) * W + 4 * q - 4;
+    g.pos[I] = (C::DY_FLOATS + ci * C::PSX + r * kRS + 4 * q) | (r << 16) | ((4 * q) << 20) | (live ? 0 : (1 << 30));
+  }
+}
+
+template <int COUT, int CIN, int I>
+__device__ __forceinline__ void pipe_geom_all(PipeGeom<COUT, CIN>& g, int tid, int plane, int W) {
+  if constexpr (I < WgPipe<COUT, CIN>::NSLOT) {
+    pipe_geom_slot<COUT, CIN, I>(g, tid, plane, W);
+    pipe_geom_all<COUT, CIN, I + 1>(g, tid, plane, W);
+  }
+}
+
+struct PipeTile {   // wave-uniform: the tile being staged
+  const float* dyimg;   // image n of dy
+  const float* ximg;    // image n of x
+  int y0, x0, org;      // org = y0 * W + x0
+};
+
+// Staging slot I, first half: row / column of the slot in the image.
+template <int COUT, int CIN, int I>
+__device__ __forceinline__ void pipe_addr_a(const PipeGeom<COUT, CIN>& g, const PipeTile& t, int& gy, int& gx) {
+  using C = WgCfg<COUT, CIN>;
+  constexpr int dy0 = (I < C::DY_ITERS) ? 0 : -1, dx0 = (I < C::DY_ITERS) ? 0 : -4;
+  gy = t.y0 + dy0 + ((g.pos[I] >> 16) & 0xf);
+  gx = t.x0 + dx0 + (g.pos[I] >> 20);   // an unused slot gets a huge column: out of range below
+}
+
+// Second half: the address (zero page when the slot lies outside the image) -- as an integer,
+// so that the select is two v_cndmask and not a branch.
+template <int COUT, int CIN, int I>
+__device__ __forceinline__ uint64_t pipe_addr_b(const PipeGeom<COUT, CIN>& g, const PipeTile& t,
+                                                const WgradBatch& b, int gy, int gx) {
+  using C = WgCfg<COUT, CIN>;
+  const bool ok = (unsigned)gy < (unsigned)b.H && (unsigned)gx < (unsigned)b.W;
+  const float* img = (I < C::DY_ITERS) ? t.dyimg : t.ximg;
+  const uint64_t real = reinterpret_cast<uint64_t>(img + (g.goff[I] + t.org));
+  const uint64_t zero = reinterpret_cast<uint64_t>(&g_wg_zero_page[0]);
+  return ok ? real : zero;
+}
+
+template <int COUT, int CIN, int I>
+__device__ __forceinline__ void pipe_lds_write(const PipeGeom<COUT, CIN>& g, float* buf, f32x4 v) {
+  using C = WgCfg<COUT, CIN>;
+  constexpr int slots = (I < C::DY_ITERS) ? C::DY_SLOTS : C::X_SLOTS;
+  constexpr int i = (I < C::DY_ITERS) ? I : I - C::DY_ITERS;
+  if constexpr (i * 256 + 255 < slots) {
+    lds_store4(buf + (g.pos[I] & 0xffff), v);
+  } else {  // only some threads own a slot in the last round
+    if (!(g.pos[I] >> 30)) lds_store4(buf + (g.pos[I] & 0xffff), v);
+  }
+}
+
+template <int COUT, int CIN, int NBW>
+struct PipeCtx {
+  const WgradBatch& b;
+  const PipeGeom<COUT, CIN>& g;
+  PipeTile next;
+  const float* a_base;
+  const float* b_base;
+  float* nxt;
+  f32x4 (&stage)[WgPipe<COUT, CIN>::NSLOT];
+  float (&av)[2][COUT / 16];
+  float (&bv)[2][NBW];
+  f32x4 (&acc)[COUT / 16][NBW];
+  f32x4 (&bacc)[COUT / 16];   // BIAS wave: rows = co, every column = sum over pixels of dy
+};
+
+// k-step KS of the pipelined tile loop: one scheduling region holding the step's MFMAs, the
+// operand reads of step KS+1, the address arithmetic + global load of staging slot KS and the LDS
+// write of slot KS-LAG; the sched_group_barrier sequence at the end tells the scheduler how to
+// lay them out (one MFMA, then at most ~24 issue cycles of the rest, repeat).
+// On the BIAS wave (the one with the fewest (ci group, tap) operands) db rides on the matrix pipe
+// too: CT extra MFMAs per k-step against an all-ones B operand, so that no wave issues VALU adds
+// and all four carry the same number of MFMAs.
+template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS>
+__device__ __forceinline__ void pipe_kstep(PipeCtx<COUT, CIN, NBW>& x) {
+  using C = WgCfg<COUT, CIN>;
+  using P = WgPipe<COUT, CIN>;
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (KS + 1 < 36 && !(WG_DIAG & 4))
+    wg_read<COUT, CIN, B0, NBW>(x.a_base, x.b_base, KS + 1, x.av[(KS + 1) & 1], x.bv[(KS + 1) & 1]);
+  if constexpr (KS < P::NSLOT && !(WG_DIAG & 2)) {
+    int gy, gx;
+    uint64_t addr;
+    if constexpr (WG_DIAG & 32) {
+      addr = reinterpret_cast<uint64_t>(&g_wg_zero_page[0]);
+    } else {
+      pipe_addr_a<COUT, CIN, KS>(x.g, x.next, gy, gx);
+      addr = pipe_addr_b<COUT, CIN, KS>(x.g, x.next, x.b, gy, gx);
+    }
+    if constexpr (WG_DIAG & 64) x.stage[KS] = f32x4{(float)(addr & 7), 0.f, 0.f, 0.f};
+    else x.stage[KS] = *reinterpret_cast<const f32x4*>(addr);
+  }
+  constexpr bool kWrites = KS >= P::LAG && KS - P::LAG < P::NSLOT;
+  if constexpr (kWrites && !(WG_DIAG & 2) && !(WG_DIAG & 16))
+    pipe_lds_write<COUT, CIN, KS - P::LAG>(x.g, x.nxt, x.stage[KS - P::LAG]);
+  if constexpr (kWrites && (WG_DIAG & 128)) asm volatile("" ::"v"(x.stage[KS - P::LAG]));  // wait, no write
+#pragma unroll
+  for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) {
+      if constexpr (!(WG_DIAG & 1))
+        x.acc[c][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.av[KS & 1][c], x.bv[KS & 1][k], x.acc[c][k], 0, 0, 0);
+      else
+        x.acc[c][k][0] += x.av[KS & 1][c] * x.bv[KS & 1][k];
+    }
+  if constexpr (BIAS && !(WG_DIAG & 8)) {
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c)
+      x.bacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.av[KS & 1][c], 1.0f, x.bacc[c], 0, 0, 0);
+  }
+  // masks: 0x8 MFMA, 0x2 VALU, 0x20 VMEM read, 0x100 DS read, 0x200 DS write
+  constexpr int NMF = C::CT * NBW + (BIAS ? C::CT : 0);
+#pragma unroll
+  for (int m = 0; m < NMF; ++m) {
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+    // same-box A/B of four layouts (reads doubled up, write first, no stagger) and of LAG 3..15:
+    // all within 1.5 % of each other, 12.5 us per tile against 11.1 us for the MFMAs alone
+    if (m < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    else if (m < 12) __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+    else if (m == 12 + WV) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+    else if (m == 16 + WV) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS>
+__device__ __forceinline__ void pipe_ksteps(PipeCtx<COUT, CIN, NBW>& x) {
+  if constexpr (KS < 36) {
+    pipe_kstep<COUT, CIN, B0, NBW, BIAS, WV, KS>(x);
+    pipe_ksteps<COUT, CIN, B0, NBW, BIAS, WV, KS + 1>(x);
+  }
+}
+
+template <int COUT, int CIN, int I>
+__device__ __forceinline__ void pipe_first_tile(const WgradBatch& b, const PipeGeom<COUT, CIN>& g, const PipeTile& t,
+                                                float* buf) {
+  if constexpr (I < WgPipe<COUT, CIN>::NSLOT) {
+    int gy, gx;
+    pipe_addr_a<COUT, CIN, I>(g, t, gy, gx);
+    const uint64_t addr = pipe_addr_b<COUT, CIN, I>(g, t, b, gy, gx);
+    pipe_lds_write<COUT, CIN, I>(g, buf, *reinterpret_cast<const f32x4*>(addr));
+    pipe_first_tile<COUT, CIN, I + 1>(b, g, t, buf);
+  }
+}
+
+template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV>
+__device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob& j, float* smem, int split,
+                                             int splits, int tid) {
+  using C = WgCfg<COUT, CIN>;
+  using P = WgPipe<COUT, CIN>;
+  const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+
+  f32x4 acc[C::CT][NBW];
+#pragma unroll
+  for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) acc[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bacc[C::CT];
+#pragma unroll
+  for (int c = 0; c < C::CT; ++c) bacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int total = b.N * b.tiles_x * b.tiles_y;
+  // (64-bit divisions run on the vector ALU: bring the wave-uniform results back to SGPRs)
+  const int t_begin = __builtin_amdgcn_readfirstlane((int)(((long long)total * split) / splits));
+  const int t_end = __builtin_amdgcn_readfirstlane((int)(((long long)total * (split + 1)) / splits));
+  const int plane = b.H * b.W;
+
+  PipeGeom<COUT, CIN> geom;
+  pipe_geom_all<COUT, CIN, 0>(geom, tid, plane, b.W);
+
+  int tx = __builtin_amdgcn_readfirstlane(t_begin % b.tiles_x);
+  int ty = __builtin_amdgcn_readfirstlane((t_begin / b.tiles_x) % b.tiles_y);
+  int n = __builtin_amdgcn_readfirstlane(t_begin / (b.tiles_x * b.tiles_y));
+  auto tile_at = [&]() {
+    PipeTile t;
+    t.dyimg = j.dy + (size_t)n * COUT * plane;
+    t.ximg = j.x + (size_t)n * CIN * plane;
+    t.y0 = ty * kTileRows;
+    t.x0 = tx * kTileCols;
+    t.org = t.y0 * b.W + t.x0;
+    return t;
+  };
+  if (t_begin < t_end) pipe_first_tile<COUT, CIN, 0>(b, geom, tile_at(), smem);
+  __syncthreads();
+
+  f32x4 stage[P::NSLOT];
+  float av[2][C::CT], bv[2][NBW];
+  int par = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    // the next tile (the last tile stages itself once more into the idle buffer: keeps the loop
+    // free of branches, nobody reads that copy)
+    if (t + 1 < t_end) {
+      if (++tx == b.tiles_x) {
+        tx = 0;
+        if (++ty == b.tiles_y) {
+          ty = 0;
+          ++n;
+        }
+      }
+    }
+    float* cur = smem + par * P::BUF_FLOATS;
+    PipeCtx<COUT, CIN, NBW> x{b, geom, tile_at(), cur + lr * C::PSD + lq, cur + C::DY_FLOATS + lr * C::PSX + lq + 3,
+                              smem + (par ^ 1) * P::BUF_FLOATS, stage, av, bv, acc, bacc};
+    wg_read<COUT, CIN, B0, NBW>(x.a_base, x.b_base, 0, av[0], bv[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    pipe_ksteps<COUT, CIN, B0, NBW, BIAS, WV, 0>(x);
+    // pin the accumulators to AGPRs across the loop edge: left alone, the allocator carries them
+    // in VGPRs there and re-copies all of them (v_accvgpr_write x 96) at the top of every tile
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c) {
+#pragma unroll
+      for (int k = 0; k < NBW; ++k) asm volatile("" : "+a"(acc[c][k]));
+      if constexpr (BIAS) asm volatile("" : "+a"(bacc[c]));
+    }
+    __syncthreads();  // tile t fully read, tile t+1 fully written
+    par ^= 1;
+  }
+
+  float* part = j.partial + (size_t)split * C::PARTIAL_FLOATS;
+#pragma unroll
+  for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+    for (int k = 0; k < NBW; ++k)
+      *reinterpret_cast<f32x4*>(part + (((B0 + k) * C::CT + c) * 64 + lane) * 4) = acc[c][k];
+  if constexpr (BIAS) {  // column 0 of the bias accumulators: lane 16*lq holds co = 16c + 4lq + r
+    if (lr == 0) {
+#pragma unroll
+      for (int c = 0; c < C::CT; ++c)
+        *reinterpret_cast<f32x4*>(part + C::NB * C::CT * 256 + c * 16 + 4 * lq) = bacc[c];
+    }
+  }
+}
+
+template <int COUT, int CIN>
+__global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_kernel(WgradBatch b) {
+  using C = WgCfg<COUT, CIN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const WgradJob& j = b.job[blockIdx.y];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x, splits = gridDim.x;
+  constexpr int NB = C::NB;
+  constexpr int W0 = (NB + 3) / 4, W1 = (NB + 2) / 4, W2 = (NB + 1) / 4, W3 = NB / 4;
+  // the bias sums ride on the last wave: it owns the fewest (ci group, tap) operands
+  if (wave == 0) wg_role_pipe<COUT, CIN, 0, W0, false, 0>(b, j, smem, split, splits, tid);
+  else if (wave == 1) wg_role_pipe<COUT, CIN, W0, W1, false, 1>(b, j, smem, split, splits, tid);
+  else if (wave == 2) wg_role_pipe<COUT, CIN, W0 + W1, W2, false, 2>(b, j, smem, split, splits, tid);
+  else wg_role_pipe<COUT, CIN, W0 + W1 + W2, W3, true, 3>(b, j, smem, split, splits, tid);
+}
+
 template <int COUT, int CIN, bool VEC>
 __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(WgradBatch b) {
   using C = WgCfg<COUT, CIN>;
@@ -332,9 +662,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceBatch rb) {
   }
 }
 
+static bool wgrad_use_pipe() {
+  static const bool on = [] {
+    const char* e = getenv("LARVA_WGRAD_PIPE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 template <int COUT, int CIN>
 static hipError_t launch_wgrad(const WgradBatch& b, int njobs, int splits, hipStream_t stream) {
   using C = WgCfg<COUT, CIN>;
+  using P = WgPipe<COUT, CIN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, true>),
@@ -343,7 +682,18 @@ static hipError_t launch_wgrad(const WgradBatch& b, int njobs, int splits, hipSt
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) return e;
+    if constexpr (P::FITS) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_pipe_kernel<COUT, CIN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::LDS_BYTES);
+      if (e != hipSuccess) return e;
+    }
     attr_set = true;
+  }
+  if constexpr (P::FITS) {
+    if (b.vec_ok && wgrad_use_pipe()) {
+      hipLaunchKernelGGL((wgrad3x3_pipe_kernel<COUT, CIN>), dim3(splits, njobs), dim3(256), P::LDS_BYTES, stream, b);
+      return hipGetLastError();
+    }
   }
   if (b.vec_ok)
     hipLaunchKernelGGL((wgrad3x3_kernel<COUT, CIN, true>), dim3(splits, njobs), dim3(256), C::LDS_BYTES, stream, b);
@@ -363,7 +713,7 @@ long long larva_wgrad_partial_floats(int cout, int cin, int splits) {
   return (long long)splits * ((long long)(cin / 16) * 9 * (cout / 16) * 256 + cout);
 }
 
-// Phase 1: partial images.  njobs (<= 32) same-shape layers in one launch; job i reads dy[i]
+// Phase 1: partial images.  njobs (<= 64) same-shape layers in one launch; job i reads dy[i]
 // [N][cout][H][W] and x[i] [N][cin][H][W] and writes `splits` partial images to partial[i]
 // (larva_wgrad_partial_floats(cout, cin, splits) floats).  Returns the number of partial images
 // actually written per job in *splits_used (splits clamped to the number of tiles).
@@ -420,7 +770,7 @@ int larva_wgrad_reduce(const float* const* partial, float* const* dw, float* con
   return (int)hipGetLastError();
 }
 
-// Both phases for njobs (<= 32) layers.
+// Both phases for njobs (<= 64) layers.
 int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* const* partial,
                         float* const* dw, float* const* db, const int* cin_off,
                         const int* cin_valid, const int* w_cin_total, int njobs, int splits,

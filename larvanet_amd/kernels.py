@@ -147,7 +147,7 @@ def wgrad_partial_floats(cout, cin, splits):
 
 
 def max_wgrad_jobs():
-    return 16 if _WGRAD_VARIANT == "dma" else 32
+    return 16 if _WGRAD_VARIANT == "dma" else 64
 
 
 def conv3x3_wgrad(jobs, cout, cin, splits):
@@ -192,11 +192,11 @@ def conv3x3_wgrad(jobs, cout, cin, splits):
 
 
 def conv3x3_wgrad_partial(jobs, cout, cin, splits):
-    """Phase 1 only: jobs (<= 32 dicts {dy, x}) -> (partial tensors, splits actually used).
+    """Phase 1 only: jobs (<= 64 dicts {dy, x}) -> (partial tensors, splits actually used).
     Feed them to wgrad_reduce later (the partials must stay alive until then)."""
     lib = hip_lib.load()
-    if not 1 <= len(jobs) <= 32:
-        raise RuntimeError("larvanet_amd: 1..32 wgrad jobs per call")
+    if not 1 <= len(jobs) <= 64:
+        raise RuntimeError("larvanet_amd: 1..64 wgrad jobs per call")
     N, _, H, W = (int(v) for v in jobs[0]["dy"].shape)
     splits = max(1, min(int(splits), N * ((H + 2) // 3) * ((W + 47) // 48)))  # the library's clamp
     nfl = wgrad_partial_floats(cout, cin, splits)
