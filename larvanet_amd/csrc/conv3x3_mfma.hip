@@ -30,6 +30,9 @@
 // Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
 // bit 0 = skip the MFMA blocks, bit 1 = skip the global->LDS staging, bit 2 = skip the
 // epilogue's global traffic, bit 3 = return at kernel entry, bit 4 = plain (not non-temporal) output stores.
+#ifndef LARVA_SHADOW
+#define LARVA_SHADOW 1   // 0: operand reads in a block in front of each k-step's MFMAs (A/B timing)
+#endif
 #ifndef LARVA_DIAG
 #define LARVA_DIAG 0
 #endif
@@ -253,6 +256,17 @@ __device__ __forceinline__ void read_operands(const float* a_base, const float* 
   }
 }
 
+// Issue order of one k-step: MFMA, its share of the NRD operand reads (0x100 = DS read), MFMA, ...
+template <int NMF, int NRD, int M>
+__device__ __forceinline__ void shadow_groups() {
+  if constexpr (M < NMF) {
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+    constexpr int share = (NRD + NMF - 1 - M) / NMF;
+    if constexpr (share > 0) __builtin_amdgcn_sched_group_barrier(0x100, share, 0);
+    shadow_groups<NMF, NRD, M + 1>();
+  }
+}
+
 // One chunk of K (8 channels x 9 taps = 18 k-steps) for a wave that owns cout groups
 // [ct0, ct0+NCT) and pixel groups [PG0, PG0+NPG) of the tile.  One wave per SIMD means nobody
 // else hides the LDS latency, so the operands of step s+1 are read while step s multiplies
@@ -272,6 +286,29 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
   read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, 0, av[0], bv[0]);
 #pragma unroll
   for (int step = 0; step < C::STEPS; ++step) {
+#if LARVA_SHADOW
+    // One scheduling region per k-step.  A v_mfma_f32_16x16x4_f32 keeps the matrix pipe busy for
+    // 32 cycles but the wave's issue port for only 8 of them: ~24 cycles of other instructions
+    // per MFMA are free, everything issued OUTSIDE such a shadow idles the pipe (one wave per
+    // SIMD).  So the operand reads of step s+1 are dealt out one or two per MFMA of step s
+    // instead of in a block in front of them, and the LDS-DMA piece follows the first MFMA.
+    __builtin_amdgcn_sched_barrier(0);
+    if (step + 1 < C::STEPS)
+      read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+    constexpr int NMF = NCT * NPG;
+    constexpr int NRD = NCT + NPG;
+#pragma unroll
+    for (int m = 0; m < NMF; ++m) {
+      acc[m / NPG][m % NPG] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][m / NPG], bv[step & 1][m % NPG],
+                                                                  acc[m / NPG][m % NPG], 0, 0, 0);
+      if constexpr (PREFETCH) {
+        if (m == 0 && step % kEvery == 0 && step / kEvery < C::NPW)
+          dma_piece<COUT>(pl, step / kEvery, wave, nxt_img, nxt_wgt, nxt_stage);
+      }
+    }
+    shadow_groups<NMF, NRD, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+#else
     if (step + 1 < C::STEPS)
       read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
     if constexpr (PREFETCH) {
@@ -287,6 +324,7 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
       for (int p = 0; p < NPG; ++p)
         acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][c], bv[step & 1][p], acc[c][p], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 

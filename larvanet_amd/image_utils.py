@@ -28,3 +28,35 @@ def stitch_quadrants(parts, input_shape, scale, overlap_size):
 def upscale_with_chop_forward(model, input_image, scale, overlap_size):
     parts = [model.upscale(input_list=[q], scale=scale)[0] for q in split_quadrants(input_image, overlap_size)]
     return stitch_quadrants(parts, input_image.shape, scale, overlap_size)
+
+
+def band_rows(height, world):
+    """Rows [r0, r1) of each of `world` contiguous bands of an image `height` rows tall (balanced,
+    empty bands when world > height)."""
+    return [((height * r) // world, (height * (r + 1)) // world) for r in range(world)]
+
+
+def upscale_band(model, input_image, scale, r0, r1, halo):
+    """Output rows [scale*r0, scale*r1) of model.upscale(input_image), computed from the input rows
+    [r0 - halo, r1 + halo) only.  EXACT (bit for bit) when `halo` >= the network's receptive halo
+    (model.receptive_halo()): the cut edges see zero padding / clamped bicubic taps instead of the
+    neighbouring rows, but that only reaches `halo` rows into the sub-image, and exactly those rows
+    are dropped; true image borders stay borders.  SURVEY 8e row 3 (the reference itself only has
+    the approximate 2x2 chop_forward, utils/image_utils.py:30-66)."""
+    height = input_image.shape[1]
+    if r1 <= r0:
+        return np.zeros((input_image.shape[0], 0, input_image.shape[2] * scale), np.float32)
+    lo, hi = max(0, r0 - halo), min(height, r1 + halo)
+    out = model.upscale(input_list=[np.ascontiguousarray(input_image[:, lo:hi, :])], scale=scale)[0]
+    return out[:, (r0 - lo) * scale:(r1 - lo) * scale, :]
+
+
+def upscale_banded(model, input_image, scale, rank, world, gather, halo=None):
+    """One image split into `world` row bands, band r computed by rank r, `gather(obj)` = every
+    rank's object in rank order (larvanet_amd.dist.gather_objects).  Every rank returns the whole
+    output image.  Latency mode: each rank also recomputes 2 * halo rows, so 8 GPUs on a 339-row
+    image do 113 rows each instead of 339, not 42."""
+    halo = model.receptive_halo() if halo is None else halo
+    r0, r1 = band_rows(input_image.shape[1], world)[rank]
+    mine = upscale_band(model, input_image, scale, r0, r1, halo)
+    return np.concatenate(gather(mine), axis=1)

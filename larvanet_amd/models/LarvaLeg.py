@@ -39,6 +39,10 @@ class LarvaNet(V1.LarvaNet):
         _V2Wrapper._add_args(self, parser)
         parser.add_argument("--leg", type=int, default=4, help="The early exit leg number, starts at 1.")
 
+    def receptive_halo(self):
+        k = self.args.leg
+        return 2 if k == 0 else 1 + 2 * sum(V1.parse_num_blocks(self.args)[:k]) + 2
+
     def _make_scheduler(self):
         return torch.optim.lr_scheduler.ReduceLROnPlateau(
             self.optim, mode="max", factor=self.args.lr_decay, patience=self.args.patience,

@@ -527,6 +527,13 @@ class LarvaNet(BaseModel):
         with torch.no_grad():
             return self.model(self._to_input_tensor(input_list)).detach().cpu().numpy()
 
+    def receptive_halo(self):
+        """LR pixels beyond an output pixel's own LR pixel that can influence it: one per 3x3
+        convolution on the deepest path (head + 2 per residual block + 2 in the leg; the bicubic
+        base needs 2).  Sub-images cut with this halo reproduce the full image exactly
+        (image_utils.upscale_band)."""
+        return 1 + 2 * sum(parse_num_blocks(self.args)) + 2
+
     def test(self, input_list):
         return self.model(self._to_input_tensor(input_list))
 

@@ -110,6 +110,10 @@ class LarvaNet(V1.LarvaNet):
         self._sync_exits()
         return MeanTermsFn.apply(*terms), out
 
+    def receptive_halo(self):
+        # head + bodies + merge conv + the tail's two convs
+        return 1 + 2 * sum(V1.parse_num_blocks(self.args)) + 1 + 2
+
     def restore(self, ckpt_path, target=None):
         """Only keys present in this network are taken (V1 checkpoints warm-start V2),
         models/LarvaNetV2.py:196-206."""

@@ -36,6 +36,9 @@ def build_parser():
     p.add_argument("--save_path", type=str)
     p.add_argument("--chop_forward", action="store_true")
     p.add_argument("--chop_overlap_size", type=int, default=20)
+    p.add_argument("--band_gpus", action="store_true",
+                   help="latency mode under torchrun: every image is cut into one row band per rank "
+                        "(exact: halo = the network's receptive field) instead of image i -> rank i mod world")
     return p
 
 
@@ -67,10 +70,14 @@ def main(argv=None):
     for scale in scales:
         mine = []
         with torch.no_grad():
-            for index in range(rank, num_images, world):
+            for index in (range(num_images) if args.band_gpus else range(rank, num_images, world)):
                 lr, hr, name = loader.get_image_pair(image_index=index, scale=scale)
                 t0 = time.perf_counter()
-                if args.chop_forward:
+                if args.band_gpus:
+                    out = image_utils.upscale_banded(model, lr, scale, rank, world, ldist.gather_objects)
+                    if rank != 0:  # every rank holds the image now; rank 0 scores and saves it
+                        continue
+                elif args.chop_forward:
                     out = image_utils.upscale_with_chop_forward(model=model, input_image=lr, scale=scale,
                                                                 overlap_size=args.chop_overlap_size)
                 else:

@@ -93,3 +93,45 @@ def test_two_ranks_overlapped_allreduce_trains_like_one_collective(hip_device):
         for k in a[mode]["sd"]:
             assert np.array_equal(a[mode]["sd"][k], a["whole"]["sd"][k]), (mode, k)
     assert a["whole"]["losses"] != b["whole"]["losses"]  # the ranks did see different data
+
+
+def _band_worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LARVA_DIST_BACKEND": "gloo"})
+    try:
+        import torch.distributed as td
+        from larvanet_amd import validate
+        torch.manual_seed(0)
+        res = validate.main(_VALIDATE_ARGS + ["--band_gpus"])
+        q.put((rank, None, res))
+        td.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, "%s\n%s" % (e, traceback.format_exc()), None))
+
+
+_VALIDATE_ARGS = ["--model=LarvaNet", "--dataloader=synthetic_loader", "--num_modules=2", "--num_blocks=1,1",
+                  "--synthetic_images=2", "--synthetic_lr_size=33", "--synthetic_uint8"]
+
+
+@pytest.mark.timeout(600)
+def test_validate_with_one_row_band_per_rank_scores_like_one_gpu(hip_device):
+    """validate.py --band_gpus on 2 ranks (each computes half of every image + halo) gives the PSNR
+    of the plain single-process run exactly."""
+    from larvanet_amd import validate
+    torch.manual_seed(0)
+    plain = validate.main(list(_VALIDATE_ARGS))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, _ in res:
+        assert err is None, "rank %d: %s" % (rank, err)
+    banded = res[0][2]
+    assert [r[:2] for r in banded[4]["per_image"]] == [r[:2] for r in plain[4]["per_image"]]
+    assert res[1][2][4]["per_image"] == banded[4]["per_image"]  # gathered on every rank

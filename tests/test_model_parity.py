@@ -251,3 +251,26 @@ def test_training_state_resume_is_bit_exact(hip_device, tmp_path):
     assert lb + lc == la
     for k, v in a.model.state_dict().items():
         assert torch.equal(v, c.model.state_dict()[k]), k
+
+
+@pytest.mark.parametrize("name,flags,halo", [("LarvaNet", ["--num_modules=2", "--num_blocks=2,1"], 9),
+                                             ("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,2"], 10),
+                                             ("LarvaLeg", ["--num_modules=2", "--num_blocks=2,1", "--leg=1"], 7)])
+def test_row_bands_with_receptive_halo_reproduce_the_full_image(hip_device, name, flags, halo):
+    """one image cut into row bands (one per GPU), each computed from its rows
+    plus the receptive halo, is the full-image result bit for bit; one row less of halo is not."""
+    from larvanet_amd import image_utils
+    m = _model(name, flags, seed=3)
+    assert m.receptive_halo() == halo
+    rng = np.random.RandomState(11)
+    img = rng.randint(0, 256, size=(3, 61, 37)).astype(np.float32)
+    full = m.upscale([img], 4)[0]
+    world = 4
+    bands = [image_utils.upscale_banded(m, img, 4, r, world, lambda mine, r=r: [
+        image_utils.upscale_band(m, img, 4, *image_utils.band_rows(img.shape[1], world)[q], halo) for q in range(world)])
+        for r in range(1)]
+    assert bands[0].shape == full.shape and np.array_equal(bands[0], full)
+    short = np.concatenate([image_utils.upscale_band(m, img, 4, r0, r1, halo - 1)
+                            for r0, r1 in image_utils.band_rows(img.shape[1], world)], axis=1)
+    assert not np.array_equal(short, full)  # the halo is tight
+    assert image_utils.band_rows(5, 8)[0] == (0, 0) and image_utils.band_rows(5, 8)[-1] == (4, 5)
