@@ -116,7 +116,8 @@ class PackedConv:
     gradients (inference) they are cached until the weight's storage/version moves or
     invalidate() is called (restore / load_state_dict / optimizer step do)."""
 
-    __slots__ = ("weight", "bias", "cin_pad", "slices", "_key", "_packs", "_bufs", "_prepacked", "grad_inplace")
+    __slots__ = ("weight", "bias", "cin_pad", "slices", "_key", "_packs", "_bufs", "_prepacked", "grad_inplace",
+                 "joint", "joint_slot")
 
     def __init__(self, weight, bias, cin_pad=None, slices=None):
         self.weight, self.bias, self.cin_pad = weight, bias, cin_pad
@@ -128,6 +129,8 @@ class PackedConv:
         self._packs = None
         self._bufs = None
         self._prepacked = False
+        self.joint = None       # JointBwd: this conv's dgrad image lives in a shared arena (see there)
+        self.joint_slot = 0
 
     def invalidate(self):
         self._key = None
@@ -147,7 +150,9 @@ class PackedConv:
                 return torch.empty(K.packed_weight_floats(a, b), device=dev, dtype=torch.float32)
             if self.slices is None:
                 cin_k = cin_total if self.cin_pad is None else self.cin_pad
-                specs = [(buf(cout, cin_k), None if self.cin_pad is not None else buf(cin_k, cout), cin_k, 0)]
+                bwd = None if self.cin_pad is not None else \
+                    (self.joint.view(self.joint_slot, dev) if self.joint is not None else buf(cin_k, cout))
+                specs = [(buf(cout, cin_k), bwd, cin_k, 0)]
             else:
                 specs = [(buf(cout, cin_total), None, cin_total, 0)]
                 specs += [(buf(cout, c), buf(c, cout), c, o) for (o, c) in self.slices]
@@ -176,6 +181,70 @@ class PackedConv:
         if self._packs is None:
             self.refresh()
         return self._packs
+
+
+class JointBwd:
+    """Two convolutions that read the SAME tensor (the first conv of body i+1 and the first conv of
+    exit i's leg both read fea_i): the gradient of that tensor is the sum of their two input
+    gradients, i.e. ONE convolution over the channel concatenation of their output gradients with
+    the two dgrad weight images stacked along K.  The packed dgrad images are chunk-major, so
+    stacking is adjacency: both PackedConvs write their image into one arena and the arena IS the
+    stacked image.  Replaces two conv launches + autograd's accumulation add by one launch."""
+
+    def __init__(self, first, second):
+        cout, cin = int(first.weight.shape[0]), int(first.weight.shape[1])
+        if tuple(second.weight.shape) != tuple(first.weight.shape) or first.slices or second.slices:
+            raise RuntimeError("larvanet_amd: joint input gradients need two plain convs of one shape")
+        self.floats = K.packed_weight_floats(cin, cout)
+        self.cin = cin
+        self._arena = None
+        first.joint, first.joint_slot = self, 0
+        second.joint, second.joint_slot = self, 1
+
+    def arena(self, dev):
+        if self._arena is None or self._arena.device != dev:
+            self._arena = torch.empty(2 * self.floats, device=dev, dtype=torch.float32)
+        return self._arena
+
+    def view(self, slot, dev):
+        return self.arena(dev)[slot * self.floats:(slot + 1) * self.floats]
+
+
+class JointInputGrad:
+    """Book-keeping of the fusion above inside one StepScope.  Forward: ExitFn notes the tensor it
+    reads, the BodyFn that reads the same tensor next marks itself as partner.  Backward (autograd
+    runs the later-created BodyFn first): the body leaves its last dgrad launch undone, parks its
+    operands here and returns no input gradient; the exit then issues the one stacked convolution
+    and returns the complete gradient of the shared tensor."""
+
+    active = False
+    _exits = {}    # data_ptr of the shared tensor -> the leg's first PackedConv
+    _parked = {}   # data_ptr -> (dh_body, g, dy) of the partner body
+
+    @classmethod
+    def reset(cls):
+        cls._exits, cls._parked = {}, {}
+
+    @classmethod
+    def note_exit(cls, fea, pc):
+        if cls.active and pc.joint is not None:
+            cls._exits[fea.data_ptr()] = pc
+
+    @classmethod
+    def partner_of(cls, x, pc):
+        """Key under which a body whose first conv is `pc` parks its last dgrad, or None."""
+        other = cls._exits.get(x.data_ptr()) if cls.active else None
+        if other is None or pc.joint is None or other.joint is not pc.joint or pc.joint_slot != 0:
+            return None
+        return x.data_ptr()
+
+    @classmethod
+    def park(cls, key, dh, g, dy):
+        cls._parked[key] = (dh, g, dy)
+
+    @classmethod
+    def take(cls, fea):
+        return cls._parked.pop(fea.data_ptr(), None) if cls._parked else None
 
 
 def pack_all(pcs):
@@ -318,10 +387,11 @@ class StepScope:
     Leaving the scope joins the side streams and issues the queued weight gradients, so they are
     complete on the current stream afterwards (also as the tail of a hipGraph capture)."""
 
-    def __init__(self, side_streams=False, defer_wgrad=True, split_flush=False):
+    def __init__(self, side_streams=False, defer_wgrad=True, split_flush=False, joint_input_grads=True):
         self.side_streams = side_streams
         self.defer_wgrad = defer_wgrad
         self.split_flush = split_flush
+        self.joint_input_grads = joint_input_grads
         self.early_targets = None   # split flush: tensors complete when the scope ends
 
     def __enter__(self):
@@ -329,6 +399,9 @@ class StepScope:
         SideStreams.active = bool(self.side_streams) and gpu
         DeferredWgrad.active = bool(self.defer_wgrad) and gpu
         DeferredWgrad.drop()
+        # (with side streams the exit and the next body run concurrently: keep them independent)
+        JointInputGrad.active = bool(self.joint_input_grads) and gpu and not SideStreams.active
+        JointInputGrad.reset()
         return self
 
     def __exit__(self, exc_type, *exc):
@@ -339,10 +412,14 @@ class StepScope:
                 self.early_targets = DeferredWgrad.flush(split=self.split_flush)
             else:
                 DeferredWgrad.drop()
+            if exc_type is None and JointInputGrad._parked:
+                raise RuntimeError("larvanet_amd: a body parked its input gradient but its exit never ran backward")
         finally:
             DeferredWgrad._pending = {}
             SideStreams.active = False
             DeferredWgrad.active = False
+            JointInputGrad.active = False
+            JointInputGrad.reset()
         return False
 
 
@@ -446,6 +523,7 @@ class BodyFn(torch.autograd.Function):
         ctx.pcs = pcs
         ctx.nb = nb
         ctx.wshape = tuple(params[0].shape)
+        ctx.joint_key = JointInputGrad.partner_of(x, pcs[0])
         return fea
 
     @staticmethod
@@ -468,6 +546,8 @@ class BodyFn(torch.autograd.Function):
             jobs[2 * j] = (dh, fea_j, ctx.wshape, 0, c) + _targets(pcs[2 * j])
             if j > 0:
                 g = K.conv3x3(dh, bw1, c, res0=g)
+            elif ctx.joint_key is not None and JointInputGrad.active:
+                JointInputGrad.park(ctx.joint_key, dh, g, dy)  # the exit that shares x finishes it
             else:
                 dx = K.conv3x3(dh, bw1, c, res0=g, res1=dy)
         grads = _wgrad(jobs, c, c, inplace=all(_targets(pc)[0] is not None for pc in pcs))
@@ -529,6 +609,7 @@ class ExitFn(torch.autograd.Function):
         h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True)
         out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base)
         term = K.l1_fwd(out, truth)
+        JointInputGrad.note_exit(fea, pcs[0])
         ctx.save_for_backward(fea, h, out, truth)
         ctx.pcs = pcs
         ctx.wshape = tuple(w1.shape)
@@ -538,16 +619,27 @@ class ExitFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _dout, gterm):
-        if gterm is None:
-            return (None,) * 8
         fea, h, out, truth = ctx.saved_tensors
         pcs = ctx.pcs
         c = ctx.wshape[0]
+        parked = JointInputGrad.take(fea)
+        if gterm is None:
+            if parked is None:
+                return (None,) * 8
+            dh_b, g_b, dy_b = parked  # no loss on this exit: only the partner body's gradient
+            arena = pcs[0].joint.arena(fea.device)
+            return (K.conv3x3(dh_b, arena[:pcs[0].joint.floats], c, res0=g_b, res1=dy_b),) + (None,) * 7
         (_, bw1), = pcs[0].get()
         (_, bw2), = pcs[1].get()
         dyl = K.l1_bwd_unshuffle4(out, truth, gterm.contiguous())
         dh = K.conv3x3(dyl, bw2, c, mask=h)
-        dfea = K.conv3x3(dh, bw1, c)
+        if parked is None:
+            dfea = K.conv3x3(dh, bw1, c)
+        else:
+            # d fea = dgrad(body conv1)(dh_body) + g + dy  +  dgrad(leg conv1)(dh): one launch over
+            # K = [dh_body ; dh] with the two dgrad images stacked (JointBwd arena)
+            dh_b, g_b, dy_b = parked
+            dfea = K.conv3x3([dh_b, dh], pcs[0].joint.arena(fea.device), c, res0=g_b, res1=dy_b)
         (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0]),
                                          (dyl, h, ctx.wshape, 0, c) + _targets(pcs[1])], c, c,
                                         inplace=all(_targets(pc)[0] is not None for pc in pcs))

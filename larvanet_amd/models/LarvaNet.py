@@ -159,6 +159,16 @@ class LarvaNetModule(nn.Module):
         self.head = LarvaHead()
         for i, nb in enumerate(parse_num_blocks(args)):
             setattr(self, "body_%d" % i, LarvaBody(num_blocks=nb))
+        self._join_input_grads()
+
+    def _join_input_grads(self):
+        """body i+1's first conv and exit i's first conv read the same tensor: their dgrad weight
+        images share an arena so that one launch computes the summed input gradient (JointBwd)."""
+        from ..autograd import JointBwd
+        for i in range(self.len - 1):
+            nxt = getattr(self, "body_%d" % (i + 1))
+            if nxt._pcs:
+                JointBwd(nxt._pcs[0], getattr(self, "body_%d" % i).leg._pcs[0])
 
     def packed_convs(self):
         out = []
@@ -214,6 +224,8 @@ class LarvaNet(BaseModel):
         self.use_side_streams = os.environ.get("LARVA_SIDE_STREAMS", "0") != "0"
         # weight gradients of all layers in a few large launches at the end of backward
         self.defer_wgrad = os.environ.get("LARVA_DEFER_WGRAD", "1") != "0"
+        # one dgrad launch for the two convs that read the same body output (next body + this exit)
+        self.joint_input_grads = os.environ.get("LARVA_JOINT_DGRAD", "1") != "0"
         # data parallel: all-reduce the first half of the bucket beside the second half's wgrad kernels
         self.overlap_allreduce = os.environ.get("LARVA_OVERLAP_ALLREDUCE", "1") != "0"
 
@@ -330,7 +342,7 @@ class LarvaNet(BaseModel):
 
     def _scope(self):
         return StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad,
-                         split_flush=self._split_backward())
+                         split_flush=self._split_backward(), joint_input_grads=self.joint_input_grads)
 
     def _split_backward(self):
         """Data parallel with in-place gradients: backward ends in two halves so that the

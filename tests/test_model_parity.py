@@ -170,6 +170,28 @@ def test_deferred_wgrad_trains_like_per_node_wgrad(hip_device, name, flags):
         assert np.abs(ga - gb).max() <= 1e-5 * max(np.abs(ga).max(), 1e-30), k
 
 
+@pytest.mark.parametrize("name,flags", [("LarvaNet", ["--num_modules=3", "--num_blocks=2,1,1"]),
+                                        ("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,2"])])
+def test_joint_input_gradient_launch_matches_separate_launches(hip_device, name, flags):
+    """d fea_i as ONE conv over [dh_body ; dh_leg] == two convs + autograd's add, to fp32 rounding
+    (the K loop is one chain of 96 channels instead of two chains of 48 added afterwards)."""
+    g = torch.Generator().manual_seed(23)
+    x = (torch.rand(2, 3, 12, 16, generator=g) * 255).to(hip_device)
+    t = (torch.rand(2, 3, 48, 64, generator=g) * 255).to(hip_device)
+    results = []
+    for joint in (False, True):
+        m = _model(name, flags, training=True, seed=5)
+        m.use_hip_graph = False
+        m.joint_input_grads = joint
+        loss, _ = m._forward_backward(x, t)
+        torch.cuda.synchronize()
+        results.append((float(loss.detach()), {k: p.grad.cpu().numpy().copy() for k, p in m.model.named_parameters()}))
+    assert results[0][0] == results[1][0]
+    for k, ga in results[0][1].items():
+        gb = results[1][1][k]
+        assert np.abs(ga - gb).max() <= 2e-5 * max(np.abs(ga).max(), 1e-30), k
+
+
 def test_v2_tail_f8(hip_device, golden):
     """LarvaNetV2: merge conv over the un-materialised concatenation, tail exit, (M+1)-way loss."""
     g = golden("f8_v2_tail.npz")
