@@ -113,10 +113,21 @@ int larva_l1_bwd(const float* a, const float* b, const float* gout, long long nu
                  void* stream);
 /* nn.L1Loss backward fused with the nn.PixelShuffle(4) backward of the exit it scores
  * (models/LarvaNet.py:108,113,261): a, b [N][C][4H][4W] -> ga [N][16C][H][W]. */
-int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, float* ga, int N, int C,
-                            int H, int W, void* stream);
+/* ga = sign(a - b) * (gout[0] * gscale) / numel; gscale carries the 1/num_modules of the mean over
+ * exits (models/LarvaNet.py:109) so that no separate scaling pass is needed. */
+int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, float gscale, float* ga, int N,
+                            int C, int H, int W, void* stream);
 /* `loss += ...; loss / num_modules` (models/LarvaNet.py:104-109): out = (sum of n <= 8 device scalars) / divisor. */
 int larva_sum_scalars(const float* const* terms, int n, float divisor, float* out, void* stream);
+/* The same loss tail in two launches less per exit: larva_l1_partial leaves the block partial sums
+ * of sum|a - b| (*blocks <= larva_l1_workspace_floats() floats), larva_loss_from_partials computes
+ * ( sum_i scale[i] * sum(terms[i][0..count[i])) ) / divisor for n <= 8 terms (scale = 1 / numel for
+ * partial sums; count 1, scale 1 for a ready scalar) -- bit-identical to larva_l1_fwd per exit
+ * followed by larva_sum_scalars. */
+int larva_l1_partial(const float* a, const float* b, long long numel, float* partial, int* blocks_out,
+                     void* stream);
+int larva_loss_from_partials(const float* const* terms, const int* count, const float* scale, int n,
+                             float divisor, float* out, void* stream);
 
 /* ---- PixelShuffle(4) backward (models/LarvaNet.py:261): in [N][C][4H][4W] -> out [N][16C][H][W] */
 int larva_pixel_unshuffle4(const float* in, float* out, int N, int C, int H, int W, void* stream);

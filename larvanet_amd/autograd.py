@@ -11,6 +11,7 @@ All weight gradients of a module are computed by ONE batched launch at the end o
 """
 import os
 
+import numpy as np
 import torch
 
 from . import kernels as K
@@ -387,6 +388,23 @@ class StepScope:
     Leaving the scope joins the side streams and issues the queued weight gradients, so they are
     complete on the current stream afterwards (also as the tail of a hipGraph capture)."""
 
+    depth = 0
+    _padded = {}
+
+    @classmethod
+    def padded_input(cls, shape, device):
+        """Zero tensor for the head's channel-padded input.  Inside a scope it is a cached buffer
+        (zeroed once; the caller overwrites the same sub-block every step), elsewhere a fresh one."""
+        if cls.depth == 0:
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+        key = (tuple(shape), str(device))
+        buf = cls._padded.get(key)
+        if buf is None:
+            if len(cls._padded) > 8:
+                cls._padded.clear()
+            buf = cls._padded[key] = torch.zeros(shape, device=device, dtype=torch.float32)
+        return buf
+
     def __init__(self, side_streams=False, defer_wgrad=True, split_flush=False, joint_input_grads=True):
         self.side_streams = side_streams
         self.defer_wgrad = defer_wgrad
@@ -402,6 +420,7 @@ class StepScope:
         # (with side streams the exit and the next body run concurrently: keep them independent)
         JointInputGrad.active = bool(self.joint_input_grads) and gpu and not SideStreams.active
         JointInputGrad.reset()
+        StepScope.depth += 1
         return self
 
     def __exit__(self, exc_type, *exc):
@@ -415,6 +434,7 @@ class StepScope:
             if exc_type is None and JointInputGrad._parked:
                 raise RuntimeError("larvanet_amd: a body parked its input gradient but its exit never ran backward")
         finally:
+            StepScope.depth -= 1
             DeferredWgrad._pending = {}
             SideStreams.active = False
             DeferredWgrad.active = False
@@ -474,7 +494,7 @@ class HeadFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, pc):
         N, C, H, W = x.shape
         P = PaddedWidth.pitch_of(W) if _lw() is not None else W
-        x16 = torch.zeros((N, 16, H, P), device=x.device, dtype=torch.float32)
+        x16 = StepScope.padded_input((N, 16, H, P), x.device)  # channels C..15 / columns W..P-1 stay zero
         x16[:, :C, :, :W] = x
         (fwd, _), = pc.get()
         out = K.conv3x3(x16, fwd, int(weight.shape[0]), bias=bias.detach(), logical_w=_lw())
@@ -602,13 +622,21 @@ class ExitFn(torch.autograd.Function):
     Returns (exit image, loss term); the image output carries no gradient path of its own."""
 
     @staticmethod
-    def forward(ctx, fea, base, truth, pcs, w1, b1, w2, b2):
+    def forward(ctx, fea, base, truth, pcs, w1, b1, w2, b2, divisor=None):
         (f1, _), = pcs[0].get()
         (f2, _), = pcs[1].get()
         c = int(w1.shape[0])
         h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True)
         out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base)
-        term = K.l1_fwd(out, truth)
+        if divisor is None:
+            term = K.l1_fwd(out, truth)   # the finished L1 value
+            ctx.gscale = 1.0
+        else:
+            # the term as it enters the mean over `divisor` exits: block partial sums of |out-truth|,
+            # finished by MeanTermsFn together with the other exits (see LossTerm); its gradient
+            # arrives unscaled and the 1/divisor is applied inside the L1 backward kernel
+            term, _ = K.l1_partial(out, truth)
+            ctx.gscale = float(np.float32(1.0) / np.float32(divisor))
         JointInputGrad.note_exit(fea, pcs[0])
         ctx.save_for_backward(fea, h, out, truth)
         ctx.pcs = pcs
@@ -625,13 +653,15 @@ class ExitFn(torch.autograd.Function):
         parked = JointInputGrad.take(fea)
         if gterm is None:
             if parked is None:
-                return (None,) * 8
+                return (None,) * 9
             dh_b, g_b, dy_b = parked  # no loss on this exit: only the partner body's gradient
             arena = pcs[0].joint.arena(fea.device)
-            return (K.conv3x3(dh_b, arena[:pcs[0].joint.floats], c, res0=g_b, res1=dy_b),) + (None,) * 7
+            return (K.conv3x3(dh_b, arena[:pcs[0].joint.floats], c, res0=g_b, res1=dy_b),) + (None,) * 8
         (_, bw1), = pcs[0].get()
         (_, bw2), = pcs[1].get()
-        dyl = K.l1_bwd_unshuffle4(out, truth, gterm.contiguous())
+        # (a partial-sum term receives its scalar gradient broadcast to its shape: element 0)
+        g0 = gterm.as_strided((), ()) if gterm.dim() else gterm.contiguous()
+        dyl = K.l1_bwd_unshuffle4(out, truth, g0, ctx.gscale)
         dh = K.conv3x3(dyl, bw2, c, mask=h)
         if parked is None:
             dfea = K.conv3x3(dh, bw1, c)
@@ -647,22 +677,50 @@ class ExitFn(torch.autograd.Function):
             dw1 = db1 = None
         if _targets(pcs[1])[0] is not None:
             dw2 = db2 = None
-        return dfea, None, None, None, dw1, db1, dw2, db2
+        return dfea, None, None, None, dw1, db1, dw2, db2, None
+
+
+class LossTerm:
+    """What one exit contributes to the mean loss: a finished scalar (scale 1), or the block partial
+    sums of sum|out - truth| with scale = 1 / numel whose producer (ExitFn with a divisor) applies
+    the 1/n of the mean in its own backward kernel (`prescaled`)."""
+
+    __slots__ = ("tensor", "scale", "prescaled")
+
+    def __init__(self, tensor, scale=1.0, prescaled=False):
+        self.tensor, self.scale, self.prescaled = tensor, float(scale), bool(prescaled)
 
 
 class MeanTermsFn(torch.autograd.Function):
     """`loss += term` over the exits and `loss / num_modules` (models/LarvaNet.py:104-109) as one
-    launch; every term receives the same gradient g / n."""
+    launch over scalars and/or partial sums (same arithmetic, same order as finishing every L1
+    separately and adding the scalars).  A finished scalar receives the gradient g / n; a
+    prescaled partial-sum term receives g itself (broadcast view, no kernel)."""
 
     @staticmethod
-    def forward(ctx, *terms):
-        ctx.n = len(terms)
-        return K.sum_scalars([t.contiguous() for t in terms], float(len(terms)))
+    def forward(ctx, meta, *tensors):
+        ctx.meta = meta
+        ctx.shapes = [tuple(t.shape) for t in tensors]
+        return K.loss_from_partials([t.contiguous() for t in tensors], [m[0] for m in meta], float(len(tensors)))
 
     @staticmethod
     def backward(ctx, g):
-        gm = g / ctx.n
-        return (gm,) * ctx.n
+        n = len(ctx.meta)
+        gm = None
+        grads = []
+        for (scale, prescaled), shape in zip(ctx.meta, ctx.shapes):
+            if prescaled:
+                grads.append(g.expand(shape))
+            else:
+                gm = g / n if gm is None else gm
+                grads.append(gm if scale == 1.0 else gm * scale)
+        return (None,) + tuple(grads)
+
+
+def mean_of_terms(terms):
+    """terms: LossTerm or 0-d tensors -> their mean as a 0-d tensor (one launch)."""
+    terms = [t if isinstance(t, LossTerm) else LossTerm(t) for t in terms]
+    return MeanTermsFn.apply([(t.scale, t.prescaled) for t in terms], *[t.tensor for t in terms])
 
 
 class MergeFn(torch.autograd.Function):

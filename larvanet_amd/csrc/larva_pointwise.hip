@@ -141,9 +141,9 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
 // output and the truth in HR layout, writes sign(out - truth) * gout / numel straight into the
 // [N][16C][H][W] layout the leg's dgrad / wgrad consume (no HR-layout gradient tensor).
 __global__ void l1_bwd_unshuffle4_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                         const float* __restrict__ gout, float inv_numel,
+                                         const float* __restrict__ gout, float gscale, float inv_numel,
                                          float* __restrict__ out, int planes, int H, int W) {
-  const float g = gout[0] * inv_numel;
+  const float g = (gout[0] * gscale) * inv_numel;
   const int HH = 4 * H;
   const long long total = (long long)planes * HH * W;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -164,6 +164,33 @@ __global__ void l1_bwd_unshuffle4_kernel(const float* __restrict__ a, const floa
       o[e * plane] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
     }
   }
+}
+
+// out[0] = ( sum_i  scale_i * (sum of the count_i floats at p_i) ) / divisor: the mean over the
+// exits of their L1 terms straight from the block partial sums of l1_partial_kernel (count_i =
+// its block count, scale_i = 1 / numel), or of ready scalars (count 1, scale 1).  Each term is
+// reduced exactly like l1_finish_kernel does, the terms are added in index order: bit-identical
+// to l1_finish + sum_scalars, in one launch instead of n + 1.
+struct TermList {
+  const float* p[8];
+  int count[8];
+  float scale[8];
+  int n;
+};
+__global__ __launch_bounds__(256) void loss_from_partials_kernel(TermList l, float divisor, float* __restrict__ out) {
+  __shared__ float ws[4];
+  float total = 0.f;
+  for (int i = 0; i < l.n; ++i) {
+    float s = 0.f;
+    for (int k = threadIdx.x; k < l.count[i]; k += 256) s += l.p[i][k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    total += ((ws[0] + ws[1]) + (ws[2] + ws[3])) * l.scale[i];
+  }
+  if (threadIdx.x == 0) out[0] = total / divisor;
 }
 
 // out[0] = (t0 + t1 + ... ) / divisor over up to 8 device scalars, added in index order.
@@ -332,15 +359,45 @@ int larva_l1_fwd(const float* a, const float* b, long long numel, float* workspa
   return (int)hipGetLastError();
 }
 
-// L1 backward written in the pixel-unshuffled layout: a, b [N][C][4H][4W] -> ga [N][16C][H][W].
-int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, float* ga, int N, int C,
-                            int H, int W, void* stream) {
+// Block partial sums of sum|a - b| only (no finishing launch): `partial` receives *blocks <=
+// larva_l1_workspace_floats() floats, to be consumed by larva_loss_from_partials.
+int larva_l1_partial(const float* a, const float* b, long long numel, float* partial, int* blocks_out,
+                     void* stream) {
+  if (!a || !b || !partial || !blocks_out || numel <= 0) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return (int)hipErrorInvalidValue;
+  int blocks = grid_for(numel / 4, 256);
+  if (blocks > kL1Blocks) blocks = kL1Blocks;
+  *blocks_out = blocks;
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, numel, partial);
+  return (int)hipGetLastError();
+}
+
+// out[0] = ( sum_i scale[i] * (sum of count[i] floats at terms[i]) ) / divisor, n <= 8 terms.
+int larva_loss_from_partials(const float* const* terms, const int* count, const float* scale, int n,
+                             float divisor, float* out, void* stream) {
+  if (!terms || !count || !scale || n < 1 || n > 8 || !out) return (int)hipErrorInvalidValue;
+  TermList l{};
+  for (int i = 0; i < n; ++i) {
+    if (!terms[i] || count[i] < 1) return (int)hipErrorInvalidValue;
+    l.p[i] = terms[i];
+    l.count[i] = count[i];
+    l.scale[i] = scale[i];
+  }
+  l.n = n;
+  hipLaunchKernelGGL(loss_from_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, l, divisor, out);
+  return (int)hipGetLastError();
+}
+
+// L1 backward written in the pixel-unshuffled layout: a, b [N][C][4H][4W] -> ga [N][16C][H][W],
+// ga = sign(a - b) * (gout[0] * gscale) / numel (gscale: e.g. the 1/M of the mean over exits).
+int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, float gscale, float* ga, int N,
+                            int C, int H, int W, void* stream) {
   if (!a || !b || !gout || !ga || N <= 0 || C <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return (int)hipErrorInvalidValue;
   const long long work = (long long)N * C * 4 * H * W;
   const float inv = 1.0f / (float)(work * 4);
   hipLaunchKernelGGL(l1_bwd_unshuffle4_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, a, b,
-                     gout, inv, ga, N * C, H, W);
+                     gout, gscale, inv, ga, N * C, H, W);
   return (int)hipGetLastError();
 }
 
@@ -417,6 +474,6 @@ int larva_sqerr_u8(const float* out, const unsigned char* truth, int C, int H, i
 
 const char* larva_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
-int larva_abi_version(void) { return 1; }
+int larva_abi_version(void) { return 2; }
 
 }  // extern "C"

@@ -256,12 +256,12 @@ _L1_WORKSPACES = {}
 
 
 def _l1_workspace(device):
-    """Zero-initialised once per (device, stream): it carries the kernel's self-resetting ticket."""
+    """Block partial sums of l1_fwd, one buffer per (device, stream)."""
     lib = hip_lib.load()
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     ws = _L1_WORKSPACES.get(key)
     if ws is None:
-        ws = torch.zeros(int(lib.larva_l1_workspace_floats()), device=device, dtype=torch.float32)
+        ws = torch.empty(int(lib.larva_l1_workspace_floats()), device=device, dtype=torch.float32)
         _L1_WORKSPACES[key] = ws
     return ws
 
@@ -278,8 +278,40 @@ def l1_fwd(a, b):
     return loss
 
 
-def l1_bwd_unshuffle4(a, b, gout):
-    """Gradient of mean|a - b| w.r.t. a, written as [N][16C][H][W] (pixel-unshuffled)."""
+def l1_partial(a, b):
+    """Block partial sums of sum|a - b| -> (partials [blocks], 1 / numel): an L1 term that
+    loss_from_partials finishes together with the other exits' terms."""
+    lib = hip_lib.load()
+    _chk(a, "a")
+    _chk(b, "b", a.shape)
+    part = torch.empty(int(lib.larva_l1_workspace_floats()), device=a.device, dtype=torch.float32)
+    blocks = ctypes.c_int(0)
+    hip_lib.check(lib.larva_l1_partial(a.data_ptr(), b.data_ptr(), a.numel(), part.data_ptr(), ctypes.byref(blocks),
+                                       _stream()), "larva_l1_partial")
+    return part[:int(blocks.value)], 1.0 / float(a.numel())
+
+
+def loss_from_partials(terms, scales, divisor):
+    """( sum_i scales[i] * terms[i].sum() ) / divisor as a 0-d tensor, one launch, fixed order."""
+    lib = hip_lib.load()
+    if not 1 <= len(terms) <= 8:
+        raise RuntimeError("larvanet_amd: 1..8 loss terms")
+    ptrs, counts = [], []
+    for t in terms:
+        _chk(t, "term")
+        if t.dim() > 1:
+            raise RuntimeError("larvanet_amd: a loss term is a scalar or a vector of partial sums")
+        ptrs.append(t.data_ptr())
+        counts.append(max(1, int(t.numel())))
+    out = torch.empty((), device=terms[0].device, dtype=torch.float32)
+    sc = (ctypes.c_float * len(terms))(*[float(v) for v in scales])
+    hip_lib.check(lib.larva_loss_from_partials(hip_lib.ptr_array(ptrs), hip_lib.int_array(counts), sc, len(terms),
+                                               float(divisor), out.data_ptr(), _stream()), "larva_loss_from_partials")
+    return out
+
+
+def l1_bwd_unshuffle4(a, b, gout, gscale=1.0):
+    """Gradient of mean|a - b| * gscale w.r.t. a, written as [N][16C][H][W] (pixel-unshuffled)."""
     lib = hip_lib.load()
     _chk(a, "a")
     _chk(b, "b", a.shape)
@@ -288,8 +320,9 @@ def l1_bwd_unshuffle4(a, b, gout):
     if HH % 4 or WW % 4:
         raise RuntimeError("larvanet_amd: spatial dims must be divisible by 4")
     out = torch.empty((N, 16 * C, HH // 4, WW // 4), device=a.device, dtype=torch.float32)
-    hip_lib.check(lib.larva_l1_bwd_unshuffle4(a.data_ptr(), b.data_ptr(), gout.data_ptr(), out.data_ptr(), N, C,
-                                              HH // 4, WW // 4, _stream()), "larva_l1_bwd_unshuffle4")
+    hip_lib.check(lib.larva_l1_bwd_unshuffle4(a.data_ptr(), b.data_ptr(), gout.data_ptr(), float(gscale),
+                                              out.data_ptr(), N, C, HH // 4, WW // 4, _stream()),
+                  "larva_l1_bwd_unshuffle4")
     return out
 
 

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .. import dist as ldist
 from .. import kernels as K
-from ..autograd import (BodyFn, ExitFn, GradBucket, HeadFn, L1LossFn, LegFn, MeanTermsFn, PackedConv, PaddedWidth,
+from ..autograd import (BodyFn, ExitFn, GradBucket, HeadFn, L1LossFn, LegFn, LossTerm, PackedConv, PaddedWidth, mean_of_terms,
                         SideStreams, StepScope, pack_all)
 from ..optim import FlatAdamW, flatten_parameters
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
@@ -290,15 +290,28 @@ class LarvaNet(BaseModel):
             self.scheduler = self._make_scheduler()
 
     # ------------------------------------------------------------------ training
+    def _grad_one(self, loss):
+        """d loss / d loss = 1 as a persistent tensor (autograd would fill a new one every step)."""
+        one = getattr(self, "_one", None)
+        if one is None or one.device != loss.device:
+            one = self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        return one
+
+    def _num_loss_terms(self):
+        return self.args.num_modules
+
     def _exit_fused(self, leg, fea, base, truth_tensor):
         """leg(fea, base) and loss_fn(out, truth) as one autograd node (ExitFn) when loss_fn is
-        the stock L1Loss; otherwise the two separate calls of the reference."""
+        the stock L1Loss; otherwise the two separate calls of the reference.  Returns (image, term):
+        in the fused case the term is a LossTerm of partial sums that the mean over the exits
+        finishes (no per-exit finishing launch, the 1/M of the mean applied inside L1's backward)."""
         if isinstance(self.loss_fn, L1Loss) and isinstance(leg, LarvaLeg):
             for pc in leg._pcs:
                 pc.refresh()
             c1, c2 = leg.recon_block[0], leg.recon_block[2]
-            return ExitFn.apply(fea.contiguous(), base.contiguous(), truth_tensor.contiguous(), leg._pcs,
-                                c1.weight, c1.bias, c2.weight, c2.bias)
+            out, part = ExitFn.apply(fea.contiguous(), base.contiguous(), truth_tensor.contiguous(), leg._pcs,
+                                     c1.weight, c1.bias, c2.weight, c2.bias, self._num_loss_terms())
+            return out, LossTerm(part, 1.0 / float(out.numel()), prescaled=True)
         out = leg(fea, base)
         return out, self.loss_fn(out, truth_tensor)
 
@@ -310,7 +323,7 @@ class LarvaNet(BaseModel):
         side = SideStreams.fork("leg", fea, base, truth_tensor)
         with torch.cuda.stream(side):
             out, term = self._exit_fused(leg, fea, base, truth_tensor)
-        SideStreams.keep(out, term)
+        SideStreams.keep(out, term.tensor if isinstance(term, LossTerm) else term)
         self._pending_exit_sync = True
         return out, term
 
@@ -333,7 +346,7 @@ class LarvaNet(BaseModel):
             out, term = self._exit(body.leg, fea, base, truth_tensor)
             terms.append(term)
         self._sync_exits()
-        return MeanTermsFn.apply(*terms), out
+        return mean_of_terms(terms), out
 
     # hipGraph path: one step issues ~330 short kernels; launched one by one from Python the GPU
     # idles between them, so forward + backward are captured once per batch shape and replayed.
@@ -376,7 +389,7 @@ class LarvaNet(BaseModel):
                 self._zero_grad()
                 with self._scope():
                     loss, _ = self._exit_losses(self._static_in, self._static_truth)
-                    loss.backward()
+                    loss.backward(self._grad_one(loss))
                 DeferredWgrad.flush_late()
         torch.cuda.current_stream().wait_stream(side)
         self._zero_grad()
@@ -385,7 +398,7 @@ class LarvaNet(BaseModel):
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             with self._scope() as scope:
                 loss, out = self._exit_losses(self._static_in, self._static_truth)
-                loss.backward()
+                loss.backward(self._grad_one(loss))
         self._note_early(scope)
         self._graph_late = None
         if DeferredWgrad._late:  # second half of a split backward: its own graph, same memory pool
@@ -430,7 +443,7 @@ class LarvaNet(BaseModel):
         self._zero_grad()
         with self._scope() as scope:
             loss, out = self._exit_losses(input_tensor, truth_tensor)
-            loss.backward()
+            loss.backward(self._grad_one(loss))
         self._note_early(scope)
         self._late = DeferredWgrad.flush_late if DeferredWgrad._late else None
         return loss, out

@@ -11,7 +11,7 @@ state_dict adds tail.merge_conv.{weight,bias} and tail.recon_block.{0,2}.{weight
 import torch
 import torch.nn as nn
 
-from ..autograd import LegFn, MeanTermsFn, MergeFn, PackedConv
+from ..autograd import LegFn, MergeFn, PackedConv, mean_of_terms
 from . import LarvaNet as V1
 from .LarvaNet import NUM_FILTERS, _conv, _require_hip, init_conv
 
@@ -92,6 +92,9 @@ class LarvaNet(V1.LarvaNet):
             self.optim, mode="max", factor=self.args.lr_decay, patience=self.args.patience,
             threshold=self.args.threshold, threshold_mode="abs", min_lr=self.args.min_lr)
 
+    def _num_loss_terms(self):
+        return self.args.num_modules + 1
+
     def _exit_losses(self, input_tensor, truth_tensor):
         """models/LarvaNetV2.py:104-123: every exit plus the tail, / (M + 1)."""
         net = self.model
@@ -108,7 +111,7 @@ class LarvaNet(V1.LarvaNet):
         out = net.tail(feats, base)
         terms.append(self.loss_fn(out, truth_tensor))
         self._sync_exits()
-        return MeanTermsFn.apply(*terms), out
+        return mean_of_terms(terms), out
 
     def receptive_halo(self):
         # head + bodies + merge conv + the tail's two convs

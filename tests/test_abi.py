@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(hip_lib.SIGNATURES) == declared  # binding table and header agree
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.larva_abi_version() == 1
+    assert lib.larva_abi_version() == 2
     # pure host-side size helpers need no device
     assert lib.larva_packed_weight_floats(48, 48) == 3 * 9 * 16 * 48
     assert lib.larva_packed_weight_floats(64, 64) == 4 * 9 * 16 * 80

@@ -332,10 +332,19 @@ def test_l1_bwd_unshuffle_and_sum_scalars(hip_device):
     s = K.sum_scalars(terms, 3.0)
     torch.cuda.synchronize()
     assert float(s) == np.float32(np.float32(np.float32(1.5) + np.float32(2.25)) + np.float32(3.0)) / np.float32(3.0)
-    # repeated single-launch L1 forward: the self-resetting ticket must survive many calls
     x, y = _dev(a, hip_device), _dev(b, hip_device)
     vals = [float(K.l1_fwd(x, y)) for _ in range(5)]
     assert len(set(vals)) == 1 and abs(vals[0] - R.l1_mean(a, b)) < 1e-5 * R.l1_mean(a, b)
+    # the fused loss tail: partial sums finished together with other terms == finishing each L1
+    # on its own and adding the scalars (bit for bit), and the gradient scale rides in the kernel
+    part, inv = K.l1_partial(x, y)
+    assert part.dim() == 1 and inv == 1.0 / a.size
+    three = torch.tensor(3.0, device=hip_device)
+    fused = K.loss_from_partials([part, three, part], [inv, 1.0, inv], 3.0)
+    l1 = K.l1_fwd(x, y)
+    assert float(fused) == float(K.sum_scalars([l1, three, l1], 3.0))
+    half = K.l1_bwd_unshuffle4(x, y, g, 0.5)
+    assert torch.equal(half, K.l1_bwd_unshuffle4(x, y, torch.tensor(0.125, device=hip_device)))
 
 
 def test_gather_patches_matches_numpy_crop_rot_flip(hip_device):
