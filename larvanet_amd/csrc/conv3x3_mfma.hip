@@ -30,6 +30,9 @@
 // Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
 // bit 0 = skip the MFMA blocks, bit 1 = skip the global->LDS staging, bit 2 = skip the
 // epilogue's global traffic, bit 3 = return at kernel entry, bit 4 = plain (not non-temporal) output stores.
+#ifndef LARVA_AUX_EARLY
+#define LARVA_AUX_EARLY 1   // 0: mask / residual / base operands loaded in the epilogue (A/B timing)
+#endif
 #ifndef LARVA_SHADOW
 #define LARVA_SHADOW 1   // 0: operand reads in a block in front of each k-step's MFMAs (A/B timing)
 #endif
@@ -355,6 +358,38 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       for (int r = 0; r < 4; ++r) bias[c][r] = a.bias[(ct0 + c) * 16 + lq * 4 + r];
   }
 
+  // So are the epilogue's other operands (ReLU mask, residuals, bicubic base): issued here, they
+  // land under the whole K loop instead of being waited for after it (the mask / residual
+  // variants ran 1-1.3 us longer than plain ReLU).  They are older than every LDS-DMA piece, so
+  // the first counted wait of the ring covers them too.
+  constexpr bool kShuffleEpi = (EPI == kEpiShuffle || EPI == kEpiShuffleBase);
+  constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiShuffleBase) ? 1 : (EPI == kEpiRes2 ? 2 : 0);
+  f32x4 aux[NAUX > 0 ? NAUX : 1][NCT][NPG];
+  auto load_aux = [&]() {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
+        if constexpr (kShuffleEpi) {
+          const int HH = 4 * a.H, WW = 4 * a.W;
+          const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
+          aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.base + idx);
+        } else {
+          const size_t plane = (size_t)a.H * a.pitch;
+          const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (EPI == kEpiMask) aux[0][c][p][r] = a.mask[idx0 + r * plane];
+            if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) aux[0][c][p][r] = a.res0[idx0 + r * plane];
+            if constexpr (EPI == kEpiRes2) aux[1][c][p][r] = a.res1[idx0 + r * plane];
+          }
+        }
+      }
+  };
+  if constexpr (NAUX > 0 && LARVA_AUX_EARLY && !(LARVA_DIAG & 4)) load_aux();
+
   f32x4 acc[NCT][NPG];
 #pragma unroll
   for (int c = 0; c < NCT; ++c)
@@ -429,22 +464,14 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     return;
   }
 
+  if constexpr (NAUX > 0 && !LARVA_AUX_EARLY) load_aux();
+
   // Epilogue.  Lane (lr, lq) holds, in acc[c][p][r], output channel (ct0+c)*16 + lq*4 + r of
   // pixel (y0 + pg/3, x0 + (pg%3)*16 + lr).
   if constexpr (EPI == kEpiShuffle || EPI == kEpiShuffleBase) {
     // PixelShuffle(4): out[n, C, 4y+i, 4x+j] = conv[n, 16C + 4i + j, y, x]; here C = ct0+c,
     // i = lq, j = r -> one aligned 16-byte store per lane (models/LarvaNet.py:261,265-266).
     const int HH = 4 * a.H, WW = 4 * a.W;
-    f32x4 basev[NCT][NPG];
-#pragma unroll
-    for (int c = 0; c < NCT; ++c)
-#pragma unroll
-      for (int p = 0; p < NPG; ++p) {
-        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
-        const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
-        const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
-        if constexpr (EPI == kEpiShuffleBase) basev[c][p] = *reinterpret_cast<const f32x4*>(a.base + idx);
-      }
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -453,27 +480,11 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         const int y = y0 + prow, x = x0 + pcol * 16 + lr;
         const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
         f32x4 v = acc[c][p] + bias[c];
-        if constexpr (EPI == kEpiShuffleBase) v += basev[c][p];
+        if constexpr (EPI == kEpiShuffleBase) v += aux[0][c][p];
         if (y < a.H && x < a.W) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
       }
   } else {
     const size_t plane = (size_t)a.H * a.pitch;
-    constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1) ? 1 : (EPI == kEpiRes2 ? 2 : 0);
-    f32x4 aux[NAUX > 0 ? NAUX : 1][NCT][NPG];
-#pragma unroll
-    for (int c = 0; c < NCT; ++c)
-#pragma unroll
-      for (int p = 0; p < NPG; ++p) {
-        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
-        const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
-        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr (EPI == kEpiMask) aux[0][c][p][r] = a.mask[idx0 + r * plane];
-          if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) aux[0][c][p][r] = a.res0[idx0 + r * plane];
-          if constexpr (EPI == kEpiRes2) aux[1][c][p][r] = a.res1[idx0 + r * plane];
-        }
-      }
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll

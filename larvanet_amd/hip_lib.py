@@ -82,14 +82,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # LARVA_HIP_LIB: another build of the same sources (same-box A/B timing of compile-time options)
+    path = os.environ.get("LARVA_HIP_LIB") or LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
             "larvanet_amd: %s is missing. Build it with `python -m larvanet_amd.build` "
-            "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback." % LIB_PATH)
+            "(hipcc --offload-arch=gfx950); there is no CPU or PyTorch fallback." % path)
     # torch must own the process's HIP runtime: loading this library first would bring in a
     # second libamdhip64 that later finds "no ROCm-capable device".
     import torch  # noqa: F401
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header and library disagree
         fn.restype = res
