@@ -128,6 +128,11 @@ int larva_l1_partial(const float* a, const float* b, long long numel, float* par
                      void* stream);
 int larva_loss_from_partials(const float* const* terms, const int* count, const float* scale, int n,
                              float divisor, float* out, void* stream);
+/* larva_l1_partial and larva_l1_bwd_unshuffle4 in one pass over (a, b), for a gradient value known
+ * on the host (training seeds loss.backward() with 1): grad [N][16C][H][W] = sign(a - b) * gvalue *
+ * gscale / numel, a, b [N][C][4H][4W]; same partial sums and gradient values as the two calls. */
+int larva_l1_partial_grad(const float* a, const float* b, float gvalue, float gscale, float* partial,
+                          int* blocks_out, float* grad, int N, int C, int H, int W, void* stream);
 
 /* ---- PixelShuffle(4) backward (models/LarvaNet.py:261): in [N][C][4H][4W] -> out [N][16C][H][W] */
 int larva_pixel_unshuffle4(const float* in, float* out, int N, int C, int H, int W, void* stream);

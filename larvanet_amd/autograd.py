@@ -390,6 +390,11 @@ class StepScope:
 
     depth = 0
     _padded = {}
+    # Value of the gradient that loss.backward() will be seeded with, when the caller of the scope
+    # guarantees it (the plugin seeds with 1 and backpropagates the mean of the exits untouched):
+    # the exits then write their L1 gradient during the FORWARD pass, in the same sweep over
+    # (output, truth) that computes the loss.  None = unknown, the exits do it in backward.
+    seed_grad = None
 
     @classmethod
     def padded_input(cls, shape, device):
@@ -405,7 +410,9 @@ class StepScope:
             buf = cls._padded[key] = torch.zeros(shape, device=device, dtype=torch.float32)
         return buf
 
-    def __init__(self, side_streams=False, defer_wgrad=True, split_flush=False, joint_input_grads=True):
+    def __init__(self, side_streams=False, defer_wgrad=True, split_flush=False, joint_input_grads=True,
+                 seed_grad=None):
+        self.seed_grad_value = seed_grad
         self.side_streams = side_streams
         self.defer_wgrad = defer_wgrad
         self.split_flush = split_flush
@@ -421,6 +428,7 @@ class StepScope:
         JointInputGrad.active = bool(self.joint_input_grads) and gpu and not SideStreams.active
         JointInputGrad.reset()
         StepScope.depth += 1
+        StepScope.seed_grad = self.seed_grad_value
         return self
 
     def __exit__(self, exc_type, *exc):
@@ -435,6 +443,7 @@ class StepScope:
                 raise RuntimeError("larvanet_amd: a body parked its input gradient but its exit never ran backward")
         finally:
             StepScope.depth -= 1
+            StepScope.seed_grad = None
             DeferredWgrad._pending = {}
             SideStreams.active = False
             DeferredWgrad.active = False
@@ -628,6 +637,7 @@ class ExitFn(torch.autograd.Function):
         c = int(w1.shape[0])
         h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True)
         out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base)
+        dyl = None
         if divisor is None:
             term = K.l1_fwd(out, truth)   # the finished L1 value
             ctx.gscale = 1.0
@@ -635,10 +645,17 @@ class ExitFn(torch.autograd.Function):
             # the term as it enters the mean over `divisor` exits: block partial sums of |out-truth|,
             # finished by MeanTermsFn together with the other exits (see LossTerm); its gradient
             # arrives unscaled and the 1/divisor is applied inside the L1 backward kernel
-            term, _ = K.l1_partial(out, truth)
             ctx.gscale = float(np.float32(1.0) / np.float32(divisor))
+            if StepScope.seed_grad is not None:  # gradient value known now: one sweep does both
+                term, _, dyl = K.l1_partial_grad(out, truth, StepScope.seed_grad, ctx.gscale)
+            else:
+                term, _ = K.l1_partial(out, truth)
         JointInputGrad.note_exit(fea, pcs[0])
-        ctx.save_for_backward(fea, h, out, truth)
+        ctx.have_dyl = dyl is not None
+        if dyl is not None:
+            ctx.save_for_backward(fea, h, dyl)
+        else:
+            ctx.save_for_backward(fea, h, out, truth)
         ctx.pcs = pcs
         ctx.wshape = tuple(w1.shape)
         ctx.mark_non_differentiable(out)
@@ -647,7 +664,10 @@ class ExitFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _dout, gterm):
-        fea, h, out, truth = ctx.saved_tensors
+        if ctx.have_dyl:
+            fea, h, dyl = ctx.saved_tensors
+        else:
+            fea, h, out, truth = ctx.saved_tensors
         pcs = ctx.pcs
         c = ctx.wshape[0]
         parked = JointInputGrad.take(fea)
@@ -659,9 +679,10 @@ class ExitFn(torch.autograd.Function):
             return (K.conv3x3(dh_b, arena[:pcs[0].joint.floats], c, res0=g_b, res1=dy_b),) + (None,) * 8
         (_, bw1), = pcs[0].get()
         (_, bw2), = pcs[1].get()
-        # (a partial-sum term receives its scalar gradient broadcast to its shape: element 0)
-        g0 = gterm.as_strided((), ()) if gterm.dim() else gterm.contiguous()
-        dyl = K.l1_bwd_unshuffle4(out, truth, g0, ctx.gscale)
+        if not ctx.have_dyl:
+            # (a partial-sum term receives its scalar gradient broadcast to its shape: element 0)
+            g0 = gterm.as_strided((), ()) if gterm.dim() else gterm.contiguous()
+            dyl = K.l1_bwd_unshuffle4(out, truth, g0, ctx.gscale)
         dh = K.conv3x3(dyl, bw2, c, mask=h)
         if parked is None:
             dfea = K.conv3x3(dh, bw1, c)

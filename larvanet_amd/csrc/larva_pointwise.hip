@@ -166,6 +166,41 @@ __global__ void l1_bwd_unshuffle4_kernel(const float* __restrict__ a, const floa
   }
 }
 
+// L1 forward and backward of one exit in ONE pass over (a, b): block partial sums of |a - b| (as
+// l1_partial_kernel, same block/thread decomposition of the flat index: identical sums) AND the
+// gradient sign(a - b) * g in pixel-unshuffled layout, for a gradient value g known on the host
+// (training: d loss / d loss = 1 times the 1/M of the mean over exits, times 1 / numel).
+__global__ __launch_bounds__(256) void l1_partial_grad_kernel(const float* __restrict__ a,
+                                                              const float* __restrict__ b, long long numel,
+                                                              float g, float* __restrict__ partial,
+                                                              float* __restrict__ grad, int H, int W) {
+  float s = 0.f;
+  const long long n4 = numel >> 2;  // one f32x4 = the 4 sub-pixel columns (j) of one LR pixel
+  const int HH = 4 * H;
+  const size_t plane = (size_t)H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 va = reinterpret_cast<const f32x4*>(a)[i];
+    const f32x4 vb = reinterpret_cast<const f32x4*>(b)[i];
+    s += fabsf(va[0] - vb[0]) + fabsf(va[1] - vb[1]) + fabsf(va[2] - vb[2]) + fabsf(va[3] - vb[3]);
+    const int x = (int)(i % W);
+    const long long t2 = i / W;
+    const int Y = (int)(t2 % HH);
+    const long long p = t2 / HH;  // image * HR channels + HR channel
+    float* o = grad + ((size_t)(p * 16 + 4 * (Y & 3)) * H + (Y >> 2)) * W + x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = va[e] - vb[e];
+      o[e * plane] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
 // out[0] = ( sum_i  scale_i * (sum of the count_i floats at p_i) ) / divisor: the mean over the
 // exits of their L1 terms straight from the block partial sums of l1_partial_kernel (count_i =
 // its block count, scale_i = 1 / numel), or of ready scalars (count 1, scale 1).  Each term is
@@ -369,6 +404,25 @@ int larva_l1_partial(const float* a, const float* b, long long numel, float* par
   if (blocks > kL1Blocks) blocks = kL1Blocks;
   *blocks_out = blocks;
   hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, numel, partial);
+  return (int)hipGetLastError();
+}
+
+// larva_l1_partial plus, in the same pass, the gradient the exit's backward will need:
+// grad [N][16C][H][W] = sign(a - b) * (gvalue * gscale / numel) for a, b [N][C][4H][4W] -- valid when
+// the gradient arriving at this L1 term is the host-known constant gvalue (the seed of
+// loss.backward(), 1).  Same partial sums as larva_l1_partial, bit for bit.
+int larva_l1_partial_grad(const float* a, const float* b, float gvalue, float gscale, float* partial,
+                          int* blocks_out, float* grad, int N, int C, int H, int W, void* stream) {
+  if (!a || !b || !partial || !blocks_out || !grad || N <= 0 || C <= 0 || H <= 0 || W <= 0)
+    return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return (int)hipErrorInvalidValue;
+  const long long numel = (long long)N * C * 16 * H * W;
+  int blocks = grid_for(numel / 4, 256);
+  if (blocks > kL1Blocks) blocks = kL1Blocks;
+  *blocks_out = blocks;
+  const float g = (gvalue * gscale) * (1.0f / (float)numel);  // the arithmetic of l1_bwd_unshuffle4_kernel
+  hipLaunchKernelGGL(l1_partial_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, numel, g, partial,
+                     grad, H, W);
   return (int)hipGetLastError();
 }
 

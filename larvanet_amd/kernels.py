@@ -291,6 +291,24 @@ def l1_partial(a, b):
     return part[:int(blocks.value)], 1.0 / float(a.numel())
 
 
+def l1_partial_grad(a, b, gvalue, gscale):
+    """l1_partial + l1_bwd_unshuffle4 in one pass, for an upstream gradient known on the host:
+    -> (partials, 1 / numel, grad [N][16C][H][W])."""
+    lib = hip_lib.load()
+    _chk(a, "a")
+    _chk(b, "b", a.shape)
+    N, C, HH, WW = (int(v) for v in a.shape)
+    if HH % 4 or WW % 4:
+        raise RuntimeError("larvanet_amd: spatial dims must be divisible by 4")
+    part = torch.empty(int(lib.larva_l1_workspace_floats()), device=a.device, dtype=torch.float32)
+    grad = torch.empty((N, 16 * C, HH // 4, WW // 4), device=a.device, dtype=torch.float32)
+    blocks = ctypes.c_int(0)
+    hip_lib.check(lib.larva_l1_partial_grad(a.data_ptr(), b.data_ptr(), float(gvalue), float(gscale), part.data_ptr(),
+                                            ctypes.byref(blocks), grad.data_ptr(), N, C, HH // 4, WW // 4, _stream()),
+                  "larva_l1_partial_grad")
+    return part[:int(blocks.value)], 1.0 / float(a.numel()), grad
+
+
 def loss_from_partials(terms, scales, divisor):
     """( sum_i scales[i] * terms[i].sum() ) / divisor as a 0-d tensor, one launch, fixed order."""
     lib = hip_lib.load()

@@ -226,6 +226,8 @@ class LarvaNet(BaseModel):
         self.defer_wgrad = os.environ.get("LARVA_DEFER_WGRAD", "1") != "0"
         # one dgrad launch for the two convs that read the same body output (next body + this exit)
         self.joint_input_grads = os.environ.get("LARVA_JOINT_DGRAD", "1") != "0"
+        # the exits' L1 gradient is written by the forward sweep that computes the L1 value
+        self.l1_grad_in_forward = os.environ.get("LARVA_L1_GRAD_FWD", "1") != "0"
         # data parallel: all-reduce the first half of the bucket beside the second half's wgrad kernels
         self.overlap_allreduce = os.environ.get("LARVA_OVERLAP_ALLREDUCE", "1") != "0"
 
@@ -354,8 +356,10 @@ class LarvaNet(BaseModel):
         return (tuple(input_tensor.shape), tuple(truth_tensor.shape), str(input_tensor.device))
 
     def _scope(self):
+        # seed_grad: _forward_backward seeds loss.backward() with _grad_one and nothing scales the loss
         return StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad,
-                         split_flush=self._split_backward(), joint_input_grads=self.joint_input_grads)
+                         split_flush=self._split_backward(), joint_input_grads=self.joint_input_grads,
+                         seed_grad=1.0 if self.l1_grad_in_forward else None)
 
     def _split_backward(self):
         """Data parallel with in-place gradients: backward ends in two halves so that the

@@ -343,6 +343,9 @@ def test_l1_bwd_unshuffle_and_sum_scalars(hip_device):
     fused = K.loss_from_partials([part, three, part], [inv, 1.0, inv], 3.0)
     l1 = K.l1_fwd(x, y)
     assert float(fused) == float(K.sum_scalars([l1, three, l1], 3.0))
+    part2, inv2, grad2 = K.l1_partial_grad(x, y, 0.25, 0.5)
+    assert torch.equal(part2, part) and inv2 == inv
+    assert torch.equal(grad2, K.l1_bwd_unshuffle4(x, y, g, 0.5))  # one sweep == the two kernels
     half = K.l1_bwd_unshuffle4(x, y, g, 0.5)
     assert torch.equal(half, K.l1_bwd_unshuffle4(x, y, torch.tensor(0.125, device=hip_device)))
 
