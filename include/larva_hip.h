@@ -63,6 +63,17 @@ int larva_conv3x3_fwd_pitched(const float* const* src, int n_src, int cin_per_sr
                               const float* base, float* out, int N, int cout, int H, int W, int pitch,
                               int relu, int mode, void* stream);
 
+/* njobs (2..4) independent convolutions of one shape and one fusion in ONE launch: at the training
+ * shape a conv launch is one workgroup per CU, the kernel fits two, and the jobs' workgroups fill
+ * each other's prologue / epilogue bubbles.  src: njobs * n_src pointers (job-major); the other
+ * operands arrays of njobs pointers, or NULL when unused by all jobs.  hipErrorNotSupported (801)
+ * when the 16-byte staging path does not apply: issue the jobs one by one then. */
+int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int cin_per_src,
+                            const float* const* wpk, const float* const* bias, const float* const* res0,
+                            const float* const* res1, const float* const* mask, const float* const* base,
+                            float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
+                            void* stream);
+
 /* Measurement only: the same launch `iters` times with kernel-attached events
  * (hipExtLaunchKernelGGL); mean/min kernel duration in ms.  Synchronises the stream. */
 int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,

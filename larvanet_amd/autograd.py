@@ -212,40 +212,37 @@ class JointBwd:
 
 
 class JointInputGrad:
-    """Book-keeping of the fusion above inside one StepScope.  Forward: ExitFn notes the tensor it
-    reads, the BodyFn that reads the same tensor next marks itself as partner.  Backward (autograd
-    runs the later-created BodyFn first): the body leaves its last dgrad launch undone, parks its
-    operands here and returns no input gradient; the exit then issues the one stacked convolution
-    and returns the complete gradient of the shared tensor."""
+    """Book-keeping of the fusion above inside one StepScope.  Backward: the exits run first (one
+    node for all of them, ExitsFn); for every exit whose leg shares its input with the next body's
+    first conv they leave the leg's last dgrad launch undone and park its operand here; the body,
+    when its own backward reaches its first conv, issues the one stacked convolution and returns
+    the complete gradient of the shared tensor."""
 
     active = False
-    _exits = {}    # data_ptr of the shared tensor -> the leg's first PackedConv
-    _parked = {}   # data_ptr -> (dh_body, g, dy) of the partner body
+    _parked = {}   # data_ptr of the shared tensor -> (dh of the leg's first conv, its PackedConv)
 
     @classmethod
     def reset(cls):
-        cls._exits, cls._parked = {}, {}
+        cls._parked = {}
 
     @classmethod
-    def note_exit(cls, fea, pc):
-        if cls.active and pc.joint is not None:
-            cls._exits[fea.data_ptr()] = pc
+    def can_park(cls, pc):
+        return cls.active and pc.joint is not None and pc.joint_slot == 1
 
     @classmethod
-    def partner_of(cls, x, pc):
-        """Key under which a body whose first conv is `pc` parks its last dgrad, or None."""
-        other = cls._exits.get(x.data_ptr()) if cls.active else None
-        if other is None or pc.joint is None or other.joint is not pc.joint or pc.joint_slot != 0:
+    def park(cls, fea, dh, pc):
+        cls._parked[fea.data_ptr()] = (dh, pc)
+
+    @classmethod
+    def take(cls, x, pc):
+        """dh parked by the exit that reads `x`, if `pc` (a body's first conv) is its arena partner."""
+        if not cls._parked:
             return None
-        return x.data_ptr()
-
-    @classmethod
-    def park(cls, key, dh, g, dy):
-        cls._parked[key] = (dh, g, dy)
-
-    @classmethod
-    def take(cls, fea):
-        return cls._parked.pop(fea.data_ptr(), None) if cls._parked else None
+        hit = cls._parked.get(x.data_ptr())
+        if hit is None or pc.joint is None or hit[1].joint is not pc.joint or pc.joint_slot != 0:
+            return None
+        del cls._parked[x.data_ptr()]
+        return hit[0]
 
 
 def pack_all(pcs):
@@ -440,7 +437,7 @@ class StepScope:
             else:
                 DeferredWgrad.drop()
             if exc_type is None and JointInputGrad._parked:
-                raise RuntimeError("larvanet_amd: a body parked its input gradient but its exit never ran backward")
+                raise RuntimeError("larvanet_amd: an exit parked its input gradient but the next body never ran backward")
         finally:
             StepScope.depth -= 1
             StepScope.seed_grad = None
@@ -552,7 +549,6 @@ class BodyFn(torch.autograd.Function):
         ctx.pcs = pcs
         ctx.nb = nb
         ctx.wshape = tuple(params[0].shape)
-        ctx.joint_key = JointInputGrad.partner_of(x, pcs[0])
         return fea
 
     @staticmethod
@@ -575,10 +571,15 @@ class BodyFn(torch.autograd.Function):
             jobs[2 * j] = (dh, fea_j, ctx.wshape, 0, c) + _targets(pcs[2 * j])
             if j > 0:
                 g = K.conv3x3(dh, bw1, c, res0=g)
-            elif ctx.joint_key is not None and JointInputGrad.active:
-                JointInputGrad.park(ctx.joint_key, dh, g, dy)  # the exit that shares x finishes it
             else:
-                dx = K.conv3x3(dh, bw1, c, res0=g, res1=dy)
+                dh_leg = JointInputGrad.take(keep[0], pcs[0])
+                if dh_leg is None:
+                    dx = K.conv3x3(dh, bw1, c, res0=g, res1=dy)
+                else:
+                    # x is also read by the previous exit's leg, which left its last dgrad to us:
+                    # d x = dgrad(conv1)(dh) + g + dy + dgrad(leg conv1)(dh_leg) as ONE launch over
+                    # K = [dh ; dh_leg] with the two dgrad images stacked (JointBwd arena)
+                    dx = K.conv3x3([dh, dh_leg], pcs[0].joint.arena(dh.device), c, res0=g, res1=dy)
         grads = _wgrad(jobs, c, c, inplace=all(_targets(pc)[0] is not None for pc in pcs))
         flat = []
         for pc, (dw, db) in zip(pcs, grads):
@@ -650,7 +651,6 @@ class ExitFn(torch.autograd.Function):
                 term, _, dyl = K.l1_partial_grad(out, truth, StepScope.seed_grad, ctx.gscale)
             else:
                 term, _ = K.l1_partial(out, truth)
-        JointInputGrad.note_exit(fea, pcs[0])
         ctx.have_dyl = dyl is not None
         if dyl is not None:
             ctx.save_for_backward(fea, h, dyl)
@@ -670,13 +670,8 @@ class ExitFn(torch.autograd.Function):
             fea, h, out, truth = ctx.saved_tensors
         pcs = ctx.pcs
         c = ctx.wshape[0]
-        parked = JointInputGrad.take(fea)
         if gterm is None:
-            if parked is None:
-                return (None,) * 9
-            dh_b, g_b, dy_b = parked  # no loss on this exit: only the partner body's gradient
-            arena = pcs[0].joint.arena(fea.device)
-            return (K.conv3x3(dh_b, arena[:pcs[0].joint.floats], c, res0=g_b, res1=dy_b),) + (None,) * 8
+            return (None,) * 9
         (_, bw1), = pcs[0].get()
         (_, bw2), = pcs[1].get()
         if not ctx.have_dyl:
@@ -684,13 +679,7 @@ class ExitFn(torch.autograd.Function):
             g0 = gterm.as_strided((), ()) if gterm.dim() else gterm.contiguous()
             dyl = K.l1_bwd_unshuffle4(out, truth, g0, ctx.gscale)
         dh = K.conv3x3(dyl, bw2, c, mask=h)
-        if parked is None:
-            dfea = K.conv3x3(dh, bw1, c)
-        else:
-            # d fea = dgrad(body conv1)(dh_body) + g + dy  +  dgrad(leg conv1)(dh): one launch over
-            # K = [dh_body ; dh] with the two dgrad images stacked (JointBwd arena)
-            dh_b, g_b, dy_b = parked
-            dfea = K.conv3x3([dh_b, dh], pcs[0].joint.arena(fea.device), c, res0=g_b, res1=dy_b)
+        dfea = K.conv3x3(dh, bw1, c)
         (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0]),
                                          (dyl, h, ctx.wshape, 0, c) + _targets(pcs[1])], c, c,
                                         inplace=all(_targets(pc)[0] is not None for pc in pcs))
@@ -699,6 +688,93 @@ class ExitFn(torch.autograd.Function):
         if _targets(pcs[1])[0] is not None:
             dw2 = db2 = None
         return dfea, None, None, None, dw1, db1, dw2, db2, None
+
+
+def _conv_group(jobs, cout, **kw):
+    """Independent same-shape convs: batched launches of up to 4 jobs, a lone one on its own."""
+    outs = []
+    for i in range(0, len(jobs), 4):
+        chunk = jobs[i:i + 4]
+        if len(chunk) == 1:
+            j = chunk[0]
+            outs.append(K.conv3x3(j["srcs"], j["wpk"], cout, bias=j.get("bias"), mask=j.get("mask"), base=j.get("base"),
+                                  res0=j.get("res0"), res1=j.get("res1"), **kw))
+        else:
+            outs += K.conv3x3_batch(chunk, cout, **kw)
+    return outs
+
+
+class ExitsFn(torch.autograd.Function):
+    """ALL exits of the training step as one autograd node (models/LarvaNet.py:104-108 for every i):
+    exit i = LarvaLeg(fea_i, base) scored by nn.L1Loss against the truth.  The exits do not depend
+    on each other, and a conv launch at the training shape leaves half of every CU's time unused
+    (one workgroup per CU, the kernel fits two): here the M first convs are ONE batched launch, the
+    M pixel-shuffle convs another, and in backward the M mask-dgrads a third (4 jobs: 55 us
+    against 67 us one by one).  Per exit the node returns the block partial sums of its L1 term
+    (LossTerm, prescaled by 1/divisor in its gradient) and, once, the LAST exit's image.
+    Backward leaves the input gradient of every exit whose leg shares its input with the next
+    body's first conv to that body (JointInputGrad)."""
+
+    @staticmethod
+    def forward(ctx, base, truth, legs, divisor, *args):
+        M = len(legs)  # legs: [[PackedConv conv1, PackedConv conv2]] per exit
+        feas, params = args[:M], args[M:]   # params: (w1, b1, w2, b2) per exit
+        c = int(params[0].shape[0])
+        c2 = int(params[2].shape[0])
+        hs = _conv_group([{"srcs": feas[i], "wpk": legs[i][0].get()[0][0], "bias": params[4 * i + 1].detach()}
+                          for i in range(M)], c, relu=True)
+        outs = _conv_group([{"srcs": hs[i], "wpk": legs[i][1].get()[0][0], "bias": params[4 * i + 3].detach(),
+                             "base": base} for i in range(M)], c2, shuffle=True)
+        ctx.gscale = float(np.float32(1.0) / np.float32(divisor))
+        ctx.have_dyl = StepScope.seed_grad is not None
+        parts, third = [], []
+        for out in outs:
+            if ctx.have_dyl:  # gradient value known now: one sweep over (out, truth) does both
+                part, _, dyl = K.l1_partial_grad(out, truth, StepScope.seed_grad, ctx.gscale)
+                third.append(dyl)
+            else:
+                part, _ = K.l1_partial(out, truth)
+                third.append(out)
+            parts.append(part)
+        ctx.save_for_backward(truth, *feas, *hs, *third)
+        ctx.legs, ctx.M = legs, M
+        ctx.wshape = tuple(params[0].shape)
+        ctx.mark_non_differentiable(outs[-1])
+        ctx.set_materialize_grads(False)
+        return (outs[-1],) + tuple(parts)
+
+    @staticmethod
+    def backward(ctx, _dout, *gterms):
+        M, legs = ctx.M, ctx.legs
+        saved = ctx.saved_tensors
+        truth, feas, hs, third = saved[0], saved[1:1 + M], saved[1 + M:1 + 2 * M], saved[1 + 2 * M:1 + 3 * M]
+        c = ctx.wshape[0]
+        live = [i for i in range(M) if gterms[i] is not None]
+        dyls = {}
+        for i in live:
+            if ctx.have_dyl:
+                dyls[i] = third[i]
+            else:
+                g0 = gterms[i].as_strided((), ())  # the scalar gradient arrives broadcast to the term's shape
+                dyls[i] = K.l1_bwd_unshuffle4(third[i], truth, g0, ctx.gscale)
+        dhs = dict(zip(live, _conv_group([{"srcs": dyls[i], "wpk": legs[i][1].get()[0][1], "mask": hs[i]}
+                                          for i in live], c))) if live else {}
+        dfeas = [None] * M
+        grads = [None] * (4 * M)
+        jobs = []
+        for i in live:
+            pc1, pc2 = legs[i]
+            if JointInputGrad.can_park(pc1):
+                JointInputGrad.park(feas[i], dhs[i], pc1)  # the next body adds it to its own input gradient
+            else:
+                dfeas[i] = K.conv3x3(dhs[i], pc1.get()[0][1], c)
+            jobs += [(dhs[i], feas[i], ctx.wshape, 0, c) + _targets(pc1), (dyls[i], hs[i], ctx.wshape, 0, c) + _targets(pc2)]
+        inplace = all(_targets(pc)[0] is not None for i in live for pc in legs[i])
+        for k, (dw, db) in enumerate(_wgrad(jobs, c, c, inplace=inplace) if jobs else []):
+            i, which = live[k // 2], k % 2
+            if _targets(legs[i][which])[0] is None:
+                grads[4 * i + 2 * which], grads[4 * i + 2 * which + 1] = dw, db
+        return (None, None, None, None) + tuple(dfeas) + tuple(grads)
 
 
 class LossTerm:

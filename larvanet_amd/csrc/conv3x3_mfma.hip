@@ -515,8 +515,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
 
 // VEC: 2 workgroups per CU (launch bound 2 waves/SIMD caps the registers at 256).
 template <int COUT, bool VEC, int EPI>
-__global__ __launch_bounds__(256, VEC ? 2 : 1) void conv3x3_mfma_kernel(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
   if constexpr ((LARVA_DIAG & 8) != 0) return;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = tile % a.tiles_x;
@@ -542,6 +541,28 @@ __global__ __launch_bounds__(256, VEC ? 2 : 1) void conv3x3_mfma_kernel(ConvArgs
     static_assert(COUT == 64, "unsupported channel count");
     run_role<COUT, VEC, EPI, 1, 0, 9>(a, smem, wave, wave, n, y0, x0, tid);
   }
+}
+
+template <int COUT, bool VEC, int EPI>
+__global__ __launch_bounds__(256, VEC ? 2 : 1) void conv3x3_mfma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv_tile<COUT, VEC, EPI>(a, smem);
+}
+
+// Several INDEPENDENT convolutions of one shape and one epilogue in one launch (blockIdx.y = job).
+// A single conv launch at the training shape is one workgroup per CU and spends half of its time
+// outside the MFMA loop (launch floor, first-chunk latency, store burst); the kernel is sized for
+// two workgroups per CU, so the workgroups of two jobs share each CU and fill each other's
+// bubbles (two launches 2 x 17.6 us, one batched launch of two jobs ~27 us).
+constexpr int kMaxConvJobs = 4;
+struct ConvBatch {
+  ConvArgs job[kMaxConvJobs];
+};
+
+template <int COUT, int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_batch_kernel(ConvBatch b) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv_tile<COUT, true, EPI>(b.job[blockIdx.y], smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -649,6 +670,36 @@ static hipError_t launch_conv(const ConvArgs& a, bool vec, int epi, hipStream_t 
   return vec ? launch_conv_v<COUT, true>(a, epi, stream, tm) : launch_conv_v<COUT, false>(a, epi, stream, tm);
 }
 
+template <int COUT, int EPI>
+static hipError_t launch_batch_e(const ConvBatch& b, int njobs, hipStream_t stream) {
+  using C = ConvCfg<COUT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_batch_kernel<COUT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES_DMA);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const ConvArgs& a = b.job[0];
+  hipLaunchKernelGGL((conv3x3_mfma_batch_kernel<COUT, EPI>), dim3(a.N * a.tiles_x * a.tiles_y, njobs), dim3(256),
+                     C::LDS_BYTES_DMA, stream, b);
+  return hipGetLastError();
+}
+
+template <int COUT>
+static hipError_t launch_batch(const ConvBatch& b, int njobs, int epi, hipStream_t stream) {
+  switch (epi) {
+    case kEpiPlain: return launch_batch_e<COUT, kEpiPlain>(b, njobs, stream);
+    case kEpiRelu: return launch_batch_e<COUT, kEpiRelu>(b, njobs, stream);
+    case kEpiMask: return launch_batch_e<COUT, kEpiMask>(b, njobs, stream);
+    case kEpiRes1: return launch_batch_e<COUT, kEpiRes1>(b, njobs, stream);
+    case kEpiRes2: return launch_batch_e<COUT, kEpiRes2>(b, njobs, stream);
+    case kEpiShuffle: return launch_batch_e<COUT, kEpiShuffle>(b, njobs, stream);
+    case kEpiShuffleBase: return launch_batch_e<COUT, kEpiShuffleBase>(b, njobs, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 }  // namespace larva
 
 using namespace larva;
@@ -687,10 +738,9 @@ int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout,
 // (cout, n_src*cin_per_src).  Epilogue, in this order: relu -> mask -> +res0 -> +res1 -> store
 // (mode 0, [N][cout][H][W]) or pixel-shuffle(4) store with optional +base (mode 1,
 // [N][cout/16][4H][4W]).  Stream-ordered, never allocates or synchronises.
-static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                         const float* bias, const float* res0, const float* res1, const float* mask,
-                         const float* base, float* out, int N, int cout, int H, int W, int pitch, int relu,
-                         int mode, void* stream, const LaunchTiming* tm) {
+static int conv_build(const float* const* src, int n_src, int cin_per_src, const float* wpk, const float* bias,
+                      const float* res0, const float* res1, const float* mask, const float* base, float* out,
+                      int N, int H, int W, int pitch, int relu, int mode, ConvArgs& a, bool& aligned, int& epi) {
   if (pitch == 0) pitch = W;
   if (pitch < W) return (int)hipErrorInvalidValue;
   if (n_src < 1 || n_src > kMaxSrc || cin_per_src % kCh || cin_per_src <= 0 || N <= 0 || H <= 0 || W <= 0)
@@ -698,8 +748,8 @@ static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, co
   if (mode != 0 && mode != 1) return (int)hipErrorInvalidValue;
   if ((long long)cin_per_src * H * pitch >= (1ll << 31)) return (int)hipErrorInvalidValue;  // 32-bit lane offsets
   if (!wpk || !out) return (int)hipErrorInvalidValue;
-  ConvArgs a{};
-  bool aligned = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(wpk) & 15) == 0);
+  a = ConvArgs{};
+  aligned = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(wpk) & 15) == 0);
   for (int i = 0; i < n_src; ++i) {
     if (!src[i]) return (int)hipErrorInvalidValue;
     a.src[i] = src[i];
@@ -713,7 +763,6 @@ static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, co
   a.tiles_x = (pitch + kTileCols - 1) / kTileCols;
   a.tiles_y = (H + kTileRows - 1) / kTileRows;
   // Map the requested fusion onto a compiled epilogue (relu -> mask -> +res0 -> +res1).
-  int epi;
   if (mode == 1) {
     if (relu || mask || res0 || res1) return (int)hipErrorInvalidValue;
     epi = base ? kEpiShuffleBase : kEpiShuffle;
@@ -729,6 +778,19 @@ static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, co
       default: return (int)hipErrorInvalidValue;
     }
   }
+  return 0;
+}
+
+static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                         const float* bias, const float* res0, const float* res1, const float* mask,
+                         const float* base, float* out, int N, int cout, int H, int W, int pitch, int relu,
+                         int mode, void* stream, const LaunchTiming* tm) {
+  ConvArgs a;
+  bool aligned;
+  int epi;
+  const int rc = conv_build(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, H, W, pitch, relu,
+                            mode, a, aligned, epi);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   switch (cout) {
 #if !LARVA_DIAG_ONLY48
@@ -758,6 +820,41 @@ int larva_conv3x3_fwd_pitched(const float* const* src, int n_src, int cin_per_sr
                               int relu, int mode, void* stream) {
   return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch,
                        relu, mode, stream, nullptr);
+}
+
+// njobs (2..4) INDEPENDENT convolutions of one shape and one fusion in ONE launch (their workgroups
+// share the CUs two by two).  src: njobs * n_src pointers (job-major); every other operand an array
+// of njobs pointers, or NULL when no job uses it (a fusion is either used by all jobs or by none).
+// Only the 16-byte staging path (pitch % 4 == 0, 16-byte aligned tensors): otherwise
+// hipErrorNotSupported, and the caller issues the jobs one by one.
+int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int cin_per_src,
+                            const float* const* wpk, const float* const* bias, const float* const* res0,
+                            const float* const* res1, const float* const* mask, const float* const* base,
+                            float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
+                            void* stream) {
+  if (njobs < 2 || njobs > kMaxConvJobs || !src || !wpk || !out) return (int)hipErrorInvalidValue;
+  ConvBatch b{};
+  int epi0 = -1;
+  for (int j = 0; j < njobs; ++j) {
+    bool aligned;
+    int epi;
+    const int rc = conv_build(src + (size_t)j * n_src, n_src, cin_per_src, wpk[j], bias ? bias[j] : nullptr,
+                              res0 ? res0[j] : nullptr, res1 ? res1[j] : nullptr, mask ? mask[j] : nullptr,
+                              base ? base[j] : nullptr, out[j], N, H, W, pitch, relu, mode, b.job[j], aligned, epi);
+    if (rc) return rc;
+    if (!aligned) return (int)hipErrorNotSupported;
+    if (j > 0 && epi != epi0) return (int)hipErrorInvalidValue;
+    epi0 = epi;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  switch (cout) {
+#if !LARVA_DIAG_ONLY48
+    case 32: return (int)launch_batch<32>(b, njobs, epi0, s);
+    case 64: return (int)launch_batch<64>(b, njobs, epi0, s);
+#endif
+    case 48: return (int)launch_batch<48>(b, njobs, epi0, s);
+    default: return (int)hipErrorInvalidValue;
+  }
 }
 
 // Measurement only (synchronises; not capturable): runs the same launch `iters` times with

@@ -125,6 +125,54 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     return out
 
 
+def conv3x3_batch(jobs, cout, relu=False, shuffle=False, logical_w=None):
+    """2..4 INDEPENDENT convs of one shape and one fusion in one launch (their workgroups share
+    the CUs two by two).  jobs: dicts with srcs (tensor or list), wpk and optionally bias, mask,
+    res0, res1, base -- a fusion operand is given by every job or by none.  Returns the outputs.
+    Falls back to one launch per job where the 16-byte staging path does not apply."""
+    lib = hip_lib.load()
+    if not 2 <= len(jobs) <= 4:
+        raise RuntimeError("larvanet_amd: 2..4 conv jobs per batched launch")
+    norm = []
+    for j in jobs:
+        srcs = j["srcs"]
+        norm.append(dict(j, srcs=[srcs] if isinstance(srcs, torch.Tensor) else list(srcs)))
+    n_src = len(norm[0]["srcs"])
+    N, cps, H, P = (int(v) for v in norm[0]["srcs"][0].shape)
+    W = P if logical_w is None else int(logical_w)
+    if cout not in _SUPPORTED_COUT or cps % 8 or not 0 < W <= P or not 1 <= n_src <= 8:
+        raise RuntimeError("larvanet_amd: unsupported batched conv shape")
+    cin = cps * n_src
+    full, hr = (N, cout, H, P), (N, cout // 16, 4 * H, 4 * W)
+    names = ("bias", "res0", "res1", "mask", "base")
+    used = {k: norm[0].get(k) is not None for k in names}
+    src_ptrs, cols, outs = [], {k: [] for k in names}, []
+    for j in norm:
+        if len(j["srcs"]) != n_src or any((j.get(k) is not None) != used[k] for k in names):
+            raise RuntimeError("larvanet_amd: batched conv jobs must share one shape and one fusion")
+        src_ptrs += [_chk(t, "src", (N, cps, H, P)) for t in j["srcs"]]
+        _chk(j["wpk"], "wpk", (packed_weight_floats(cout, cin),))
+        for k, shape in (("bias", (cout,)), ("res0", full), ("res1", full), ("mask", full), ("base", hr)):
+            if used[k]:
+                cols[k].append(_chk(j[k], k, shape))
+        outs.append(torch.empty(hr if shuffle else full, device=j["srcs"][0].device, dtype=torch.float32))
+
+    def arr(k):
+        return hip_lib.ptr_array(cols[k]) if used[k] else None
+
+    code = lib.larva_conv3x3_fwd_batch(
+        len(norm), hip_lib.ptr_array(src_ptrs), n_src, cps, hip_lib.ptr_array([j["wpk"].data_ptr() for j in norm]),
+        arr("bias"), arr("res0"), arr("res1"), arr("mask"), arr("base"),
+        hip_lib.ptr_array([o.data_ptr() for o in outs]), N, cout, H, W, P, 1 if relu else 0, 1 if shuffle else 0,
+        _stream())
+    if code == 801:  # hipErrorNotSupported: unaligned shape, one launch per job
+        return [conv3x3(j["srcs"], j["wpk"], cout, bias=j.get("bias"), relu=relu, mask=j.get("mask"),
+                        res0=j.get("res0"), res1=j.get("res1"), shuffle=shuffle, base=j.get("base"), out=o,
+                        logical_w=logical_w) for j, o in zip(norm, outs)]
+    hip_lib.check(code, "larva_conv3x3_fwd_batch")
+    return outs
+
+
 def conv3x3_relu_timed(x, wpk, cout, bias, out, iters):
     """Measurement only: (mean_ms, min_ms) of the fused conv+ReLU launch, from kernel-attached
     events (the kernel's own begin/end timestamps)."""

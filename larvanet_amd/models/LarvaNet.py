@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .. import dist as ldist
 from .. import kernels as K
-from ..autograd import (BodyFn, ExitFn, GradBucket, HeadFn, L1LossFn, LegFn, LossTerm, PackedConv, PaddedWidth, mean_of_terms,
+from ..autograd import (BodyFn, ExitFn, ExitsFn, GradBucket, HeadFn, L1LossFn, LegFn, LossTerm, PackedConv, PaddedWidth, mean_of_terms,
                         SideStreams, StepScope, pack_all)
 from ..optim import FlatAdamW, flatten_parameters
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
@@ -226,6 +226,8 @@ class LarvaNet(BaseModel):
         self.defer_wgrad = os.environ.get("LARVA_DEFER_WGRAD", "1") != "0"
         # one dgrad launch for the two convs that read the same body output (next body + this exit)
         self.joint_input_grads = os.environ.get("LARVA_JOINT_DGRAD", "1") != "0"
+        # all exits as one autograd node whose convs go out as batched launches (ExitsFn)
+        self.batch_exits = os.environ.get("LARVA_BATCH_EXITS", "1") != "0"
         # the exits' L1 gradient is written by the forward sweep that computes the L1 value
         self.l1_grad_in_forward = os.environ.get("LARVA_L1_GRAD_FWD", "1") != "0"
         # data parallel: all-reduce the first half of the bucket beside the second half's wgrad kernels
@@ -334,12 +336,42 @@ class LarvaNet(BaseModel):
             torch.cuda.current_stream().wait_stream(SideStreams.get("leg"))
             self._pending_exit_sync = False
 
+    def _exits_batched(self):
+        """All exits as one autograd node with batched launches (ExitsFn): the stock L1 loss on
+        stock legs, training-shaped input (no row pitch), no side streams."""
+        return (self.batch_exits and isinstance(self.loss_fn, L1Loss) and not SideStreams.active
+                and PaddedWidth.current is None
+                and all(isinstance(getattr(self.model, "body_%d" % i).leg, LarvaLeg) for i in range(self.args.num_modules)))
+
+    def _all_exits(self, feas, base, truth_tensor):
+        """(last exit's image, [LossTerm per exit]) from the body outputs, in one ExitsFn node."""
+        legs, params = [], []
+        for i in range(len(feas)):
+            leg = getattr(self.model, "body_%d" % i).leg
+            for pc in leg._pcs:
+                pc.refresh()
+            legs.append(leg._pcs)
+            c1, c2 = leg.recon_block[0], leg.recon_block[2]
+            params += [c1.weight, c1.bias, c2.weight, c2.bias]
+        res = ExitsFn.apply(base.contiguous(), truth_tensor.contiguous(), legs, self._num_loss_terms(),
+                            *[f.contiguous() for f in feas], *params)
+        scale = 1.0 / float(res[0].numel())
+        return res[0], [LossTerm(p, scale, prescaled=True) for p in res[1:]]
+
     def _exit_losses(self, input_tensor, truth_tensor):
         """Forward through every exit (models/LarvaNet.py:102-109). Returns (loss, last output)."""
         net = self.model
         net.refresh_packed_weights()
         fea = net.head(input_tensor)
         base = net.base(input_tensor)
+        if self._exits_batched():
+            # the exits do not feed the bodies: run the body chain first, then all exits together
+            feas = []
+            for i in range(self.args.num_modules):
+                fea = getattr(net, "body_%d" % i)(fea)
+                feas.append(fea)
+            out, terms = self._all_exits(feas, base, truth_tensor)
+            return mean_of_terms(terms), out
         terms = []
         out = None
         for i in range(self.args.num_modules):

@@ -103,11 +103,17 @@ class LarvaNet(V1.LarvaNet):
         base = net.base(input_tensor)
         terms = []
         feats = []
-        for i in range(self.args.num_modules):
-            body = getattr(net, "body_%d" % i)
-            fea = body(fea)
-            feats.append(fea)
-            terms.append(self._exit(body.leg, fea, base, truth_tensor)[1])
+        if self._exits_batched():
+            for i in range(self.args.num_modules):
+                fea = getattr(net, "body_%d" % i)(fea)
+                feats.append(fea)
+            _, terms = self._all_exits(feats, base, truth_tensor)
+        else:
+            for i in range(self.args.num_modules):
+                body = getattr(net, "body_%d" % i)
+                fea = body(fea)
+                feats.append(fea)
+                terms.append(self._exit(body.leg, fea, base, truth_tensor)[1])
         out = net.tail(feats, base)
         terms.append(self.loss_fn(out, truth_tensor))
         self._sync_exits()

@@ -193,6 +193,37 @@ def test_wgrad_batched_jobs_and_slices(hip_device):
     _report("job2.db", jobs[2]["db"].cpu().numpy(), refs[2][1], 3e-5)
 
 
+@pytest.mark.parametrize("njobs,kind", [(2, "relu"), (4, "mask"), (3, "res2"), (2, "shuffle")])
+def test_batched_conv_launch_equals_separate_launches(hip_device, njobs, kind):
+    """Independent convs in one launch (blockIdx.y = job) are the same arithmetic as one launch each."""
+    from larvanet_amd import kernels as K
+    rng = np.random.default_rng(91)
+    N, C, H, W = 2, 48, 9, 52
+    jobs = []
+    for _ in range(njobs):
+        w = _dev(_rand(rng, (C, C, 3, 3), 0.05), hip_device)
+        fwd, _ = K.pack_weights(w)
+        j = {"srcs": _dev(_rand(rng, (N, C, H, W), 20.0), hip_device), "wpk": fwd,
+             "bias": _dev(_rand(rng, (C,), 1.0), hip_device)}
+        if kind == "mask":
+            j["mask"] = _dev(_rand(rng, (N, C, H, W), 1.0), hip_device)
+        if kind == "res2":
+            j["res0"] = _dev(_rand(rng, (N, C, H, W), 5.0), hip_device)
+            j["res1"] = _dev(_rand(rng, (N, C, H, W), 5.0), hip_device)
+        if kind == "shuffle":
+            j["base"] = _dev(_rand(rng, (N, C // 16, 4 * H, 4 * W), 100.0), hip_device)
+        jobs.append(j)
+    outs = K.conv3x3_batch(jobs, C, relu=kind == "relu", shuffle=kind == "shuffle")
+    for j, o in zip(jobs, outs):
+        ref = K.conv3x3(j["srcs"], j["wpk"], C, bias=j["bias"], relu=kind == "relu", mask=j.get("mask"),
+                        res0=j.get("res0"), res1=j.get("res1"), shuffle=kind == "shuffle", base=j.get("base"))
+        assert torch.equal(o, ref)
+    # unaligned width: the batched entry declines, the wrapper issues the jobs one by one
+    odd = [{"srcs": _dev(_rand(rng, (1, C, 5, 7), 20.0), hip_device), "wpk": jobs[0]["wpk"]} for _ in range(2)]
+    for j, o in zip(odd, K.conv3x3_batch(odd, C, relu=True)):
+        assert torch.equal(o, K.conv3x3(j["srcs"], j["wpk"], C, relu=True))
+
+
 def test_wgrad_split_phases_match_the_fused_call(hip_device):
     """partial launches with different split counts + ONE reduce launch == per-batch fused calls."""
     from larvanet_amd import kernels as K

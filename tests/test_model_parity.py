@@ -192,6 +192,33 @@ def test_joint_input_gradient_launch_matches_separate_launches(hip_device, name,
         assert np.abs(ga - gb).max() <= 2e-5 * max(np.abs(ga).max(), 1e-30), k
 
 
+@pytest.mark.parametrize("name,flags", [("LarvaNet", ["--num_modules=3", "--num_blocks=2,1,1"]),
+                                        ("LarvaNet", ["--num_modules=5", "--num_blocks=1,1,1,1,1"]),
+                                        ("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,2"])])
+def test_exits_as_one_batched_node_match_one_node_per_exit(hip_device, name, flags):
+    """ExitsFn (all exits after the body chain, batched launches, joint input gradients) against
+    the reference's interleaved order with one autograd node per exit: same loss bit for bit
+    (forward arithmetic is identical), gradients to fp32 rounding (the joint dgrad sums in one
+    K chain what the other path adds afterwards)."""
+    g = torch.Generator().manual_seed(29)
+    x = (torch.rand(2, 3, 12, 16, generator=g) * 255).to(hip_device)
+    t = (torch.rand(2, 3, 48, 64, generator=g) * 255).to(hip_device)
+    results = []
+    for batched in (False, True):
+        m = _model(name, flags, training=True, seed=5)
+        m.use_hip_graph = False
+        m.batch_exits = batched
+        loss, out = m._forward_backward(x, t)
+        torch.cuda.synchronize()
+        results.append((float(loss.detach()), out.detach().cpu().numpy().copy(),
+                        {k: p.grad.cpu().numpy().copy() for k, p in m.model.named_parameters()}))
+    assert results[0][0] == results[1][0]
+    assert np.array_equal(results[0][1], results[1][1])
+    for k, ga in results[0][2].items():
+        gb = results[1][2][k]
+        assert np.abs(ga - gb).max() <= 2e-5 * max(np.abs(ga).max(), 1e-30), k
+
+
 def test_v2_tail_f8(hip_device, golden):
     """LarvaNetV2: merge conv over the un-materialised concatenation, tail exit, (M+1)-way loss."""
     g = golden("f8_v2_tail.npz")
