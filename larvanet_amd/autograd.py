@@ -7,7 +7,10 @@ Backward structure of one residual block  y = x + conv2(relu(conv1(x)))  given g
     dh = dgrad(conv2)(g) * [h > 0]          (mask fused into the conv epilogue)
     dx = g + dgrad(conv1)(dh)               (skip gradient fused as a residual operand)
     dW2, db2 = wgrad(g, h);  dW1, db1 = wgrad(dh, x)
-All weight gradients of a module are computed by ONE batched launch at the end of its backward.
+Inside the plugin's training step (StepScope) the weight gradients of ALL layers are queued and
+issued in two or three large launches when backward ends (DeferredWgrad), all exits run as one node
+with batched launches (ExitsFn), and a tensor read by two convs gets its gradient from one stacked
+dgrad launch (JointBwd / JointInputGrad).
 """
 import os
 
@@ -57,7 +60,7 @@ class SideStreams:
       * `leg`:   exit i (leg convs + L1) runs beside body i+1, forward and -- because autograd
                  replays a node on its forward stream -- backward;
       * `wgrad`: weight-gradient batches (never on the critical path) run beside the dgrad chain.
-    Only active inside `with SideStreams.scope():` (the plugin's forward+backward), which joins
+    Only active inside `with StepScope(side_streams=True):` (the plugin's forward+backward), which joins
     every side stream before it returns; anywhere else everything stays on the current stream.
     Tensors that a side stream still reads are kept referenced until the join, so the caching
     allocator cannot hand their memory out early (also during hipGraph capture)."""
@@ -95,17 +98,6 @@ class SideStreams:
             if dev == torch.cuda.current_device():
                 cur.wait_stream(st)
         cls._keep.clear()
-
-    class scope:
-        def __enter__(self):
-            SideStreams.active = torch.cuda.is_available()
-            return self
-
-        def __exit__(self, *exc):
-            if SideStreams.active:
-                SideStreams.join()
-            SideStreams.active = False
-            return False
 
 
 class PackedConv:
