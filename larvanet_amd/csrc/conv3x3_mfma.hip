@@ -30,6 +30,9 @@
 // Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
 // bit 0 = skip the MFMA blocks, bit 1 = skip the global->LDS staging, bit 2 = skip the
 // epilogue's global traffic, bit 3 = return at kernel entry, bit 4 = plain (not non-temporal) output stores.
+#ifndef LARVA_LOADER_WAVE
+#define LARVA_LOADER_WAVE 1   // 0: the four MFMA waves issue the LDS-DMA pieces themselves (A/B timing)
+#endif
 #ifndef LARVA_AUX_EARLY
 #define LARVA_AUX_EARLY 1   // 0: mask / residual / base operands loaded in the epilogue (A/B timing)
 #endif
@@ -39,16 +42,28 @@
 #ifndef LARVA_DIAG
 #define LARVA_DIAG 0
 #endif
+// LARVA_DIAG bit 5 (32): in-kernel timeline.  Wave 0 of every workgroup writes 100 MHz wall-clock
+// stamps (s_memrealtime) at kernel entry, after the DMA issue, after the first chunk landed, after
+// the K loop, after the stores were issued and after they drained, to the buffer given to
+// larva_diag_set_stamps (16 x uint64 per workgroup; slots 8.. = exit of chunk c's barrier).  tools/diag_conv.py --timeline.
 #ifndef LARVA_DIAG_ONLY48
 #define LARVA_DIAG_ONLY48 0
 #endif
 
 namespace larva {
 
+#if defined(LARVA_DIAG) && (LARVA_DIAG & 32)
+__device__ unsigned long long* g_stamps = nullptr;
+__device__ __forceinline__ void stamp(int k) {
+  if (g_stamps && threadIdx.x == 0) g_stamps[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime();
+}
+#else
+__device__ __forceinline__ void stamp(int) {}
+#endif
+
 constexpr int kCh = 8;  // input channels per K chunk
 
 // Source of every LDS-DMA lane that falls outside the image (zero padding) or into layout padding.
-__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
 struct ConvArgs {
   const float* src[kMaxSrc];  // channel-concatenated inputs, each [N][cin_per_src][H][W]
@@ -98,6 +113,10 @@ struct ConvCfg {
   static constexpr int STAGE_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr int STEPS = 9 * (kCh / 4);                               // 18 k-steps per chunk
   static constexpr size_t LDS_BYTES_DMA = 3 * STAGE_FLOATS * sizeof(float);
+  // LDS-DMA path: a fifth wave issues the pieces of chunks >= 2 (see run_loader); it keeps two
+  // chunks in flight, and vmcnt counts 63 operations at most.
+  static constexpr bool LOADER = LARVA_LOADER_WAVE && 2 * PIECES <= 63;
+  static constexpr int THREADS_DMA = LOADER ? 320 : 256;
   static constexpr size_t LDS_BYTES_REG = 2 * STAGE_FLOATS * sizeof(float);
   // register-staged path
   static constexpr int RIN_SLOTS = kCh * kHaloRows * (kRS / 4);             // 560 float4 slots
@@ -113,18 +132,16 @@ struct ConvCfg {
 template <int COUT>
 struct DmaPlan {
   // Per piece i of this wave (piece index p = wave + 4 i, clamped): the lane's source offset in
-  // floats relative to the chunk's image base (input pieces) or weight base (weight pieces), or
-  // -1 when the lane's 16 bytes are zero padding; plus the wave-uniform LDS offset and kind.
-  int off[ConvCfg<COUT>::NPW];
-  unsigned ok;    // bit i: this lane's 16 bytes of piece i come from memory (else zeros)
+  // BYTES relative to the chunk's image base (input pieces) or weight base (weight pieces), or
+  // kDmaZero when the lane's 16 bytes are zero padding (the buffer range check then writes zeros).
+  // Fixed for the whole kernel: chunks only move the two base addresses.
+  unsigned voff[ConvCfg<COUT>::NPW];
 };
 
 template <int COUT>
 __device__ __forceinline__ void make_plan(const ConvArgs& a, int wave, int lane, int y0, int x0,
                                           DmaPlan<COUT>& pl) {
   using C = ConvCfg<COUT>;
-  static_assert(C::NPW <= 32, "validity mask is 32 bits");
-  pl.ok = 0;
 #pragma unroll
   for (int i = 0; i < C::NPW; ++i) {
     const int p = min(wave + 4 * i, C::PIECES - 1);  // surplus pieces repeat the last one (same bytes)
@@ -142,14 +159,15 @@ __device__ __forceinline__ void make_plan(const ConvArgs& a, int wave, int lane,
     const bool w_ok = ws * 4 < C::W_USED;
     const bool isw = p >= C::IN_PIECES;  // wave-uniform
     const bool ok = isw ? w_ok : in_ok;
-    pl.off[i] = ok ? (isw ? ws * 4 : in_off) : 0;
-    pl.ok |= (ok ? 1u : 0u) << i;
+    pl.voff[i] = ok ? 4u * (unsigned)(isw ? ws * 4 : in_off) : kDmaZero;
   }
 }
 
 struct ChunkSrc {
-  const float* img;  // first of the chunk's 8 channel planes of image n
-  const float* wgt;  // the chunk's packed weights
+  i32x4 img;  // buffer descriptor at the first of the chunk's 8 channel planes of image n
+  i32x4 wgt;  // buffer descriptor at the chunk's packed weights
+  const float* img_ptr;
+  const float* wgt_ptr;
 };
 
 template <int COUT>
@@ -159,23 +177,86 @@ __device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int 
   const int s_idx = c0 / a.cin_per_src;
   const int c_in_src = c0 - s_idx * a.cin_per_src;
   ChunkSrc cs;
-  cs.img = a.src[s_idx] + ((size_t)n * a.cin_per_src + c_in_src) * ((size_t)a.H * a.pitch);
-  cs.wgt = a.wpk + (size_t)chunk * C::W_USED;
+  cs.img_ptr = a.src[s_idx] + ((size_t)n * a.cin_per_src + c_in_src) * ((size_t)a.H * a.pitch);
+  cs.wgt_ptr = a.wpk + (size_t)chunk * C::W_USED;
+  cs.img = dma_rsrc(cs.img_ptr);
+  cs.wgt = dma_rsrc(cs.wgt_ptr);
   return cs;
 }
 
-// One 1 KiB piece: lane l's 16 bytes go to stage + lds_off + 16 l.  Branch-free source select
-// (integer arithmetic on purpose: a pointer ternary becomes exec-masked branches here).
+// One 1 KiB piece: lane l's 16 bytes go to LDS byte address stage_addr + 1024 p + 16 l.  Scalar
+// work only: pick the descriptor, form the LDS address, issue.
 template <int COUT>
-__device__ __forceinline__ void dma_piece(const DmaPlan<COUT>& pl, int i, int wave, const float* img,
-                                          const float* wgt, float* stage) {
+__device__ __forceinline__ void dma_piece(const DmaPlan<COUT>& pl, int i, int wave, const ChunkSrc& cs,
+                                          unsigned stage_addr) {
   using C = ConvCfg<COUT>;
   const int p = min(wave + 4 * i, C::PIECES - 1);  // scalar; weight pieces follow the input pieces in LDS
   const bool isw = p >= C::IN_PIECES;
-  const uint64_t base = reinterpret_cast<uint64_t>(isw ? wgt : img);
-  const uint64_t zero = reinterpret_cast<uint64_t>(&g_zero_page[0]);
-  const uint64_t addr = ((pl.ok >> i) & 1u) ? base + 4ull * (uint32_t)pl.off[i] : zero;
-  lds_dma<16>(reinterpret_cast<const void*>(addr), stage + p * 256);
+  i32x4 rsrc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rsrc[k] = isw ? cs.wgt[k] : cs.img[k];
+  lds_dma16_buf(rsrc, pl.voff[i], 0, stage_addr + 1024u * (unsigned)p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loader wave.  Issuing one 1 KiB LDS-DMA piece costs the issuing wave ~100 cycles, and a wave that
+// is not issuing MFMAs idles its SIMD's matrix pipe: with the 28 pieces of a chunk dealt to the four
+// MFMA waves the K loop ran at 13.4 us against 10.1 us of MFMAs (in-kernel timeline,
+// tools/diag_conv.py --timeline).  So the workgroup has a FIFTH wave that does nothing but stream:
+// after the barrier that opens chunk c it issues all pieces of chunk c+2 into the stage chunk c-1
+// has just vacated, and before the next barrier it waits until chunk c+1 has landed.  Chunks 0 and
+// 1 are still issued by the MFMA waves (four waves start the ring faster than one).
+// ---------------------------------------------------------------------------------------------
+template <int COUT>
+struct LoaderPlan {
+  unsigned voff[ConvCfg<COUT>::PIECES];   // this lane's source offset of EVERY piece, or kDmaZero
+};
+
+template <int COUT>
+__device__ __forceinline__ void make_loader_plan(const ConvArgs& a, int lane, int y0, int x0, LoaderPlan<COUT>& pl) {
+  using C = ConvCfg<COUT>;
+#pragma unroll
+  for (int p = 0; p < C::PIECES; ++p) {
+    if (p < C::IN_PIECES) {
+      const int slot = p * 64 + lane;
+      const int ci = slot / C::IN_SLOTS_PER_PLANE;
+      const int rem = slot - ci * C::IN_SLOTS_PER_PLANE;
+      const int r = rem / (kRS / 4);
+      const int q = rem - r * (kRS / 4);
+      const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+      const bool ok = ci < kCh && r < kHaloRows && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      pl.voff[p] = ok ? 4u * (unsigned)((ci * a.H + gy) * a.pitch + gx) : kDmaZero;
+    } else {
+      const int ws = (p - C::IN_PIECES) * 64 + lane;
+      pl.voff[p] = (ws * 4 < C::W_USED) ? 16u * (unsigned)ws : kDmaZero;
+    }
+  }
+}
+
+template <int COUT>
+__device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int lane, int n, int y0, int x0) {
+  using C = ConvCfg<COUT>;
+  LoaderPlan<COUT> pl;
+  make_loader_plan<COUT>(a, lane, y0, x0, pl);
+  const int last = a.n_chunks - 1;
+  int stage = 0;
+  for (int chunk = 0; chunk <= last; ++chunk) {
+    // everything but the youngest chunk's pieces has landed: for chunk >= 2 that is chunk `chunk`
+    // itself (chunks 0 and 1 come from the MFMA waves, which wait for them on their side)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PIECES) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // past the end the last chunk is streamed again into a stage nobody reads: every wait stays
+    // the same counted vmcnt(PIECES)
+    const ChunkSrc cs = chunk_src<COUT>(a, min(chunk + 2, last), n);
+    const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
+    const unsigned dst = lds_addr_of(smem + nstage * C::STAGE_FLOATS);
+#pragma unroll
+    for (int p = 0; p < C::PIECES; ++p)
+      lds_dma16_buf(p < C::IN_PIECES ? cs.img : cs.wgt, pl.voff[p], 0, dst + 1024u * (unsigned)p);
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  // no LDS-DMA may be in flight when the workgroup's LDS is released
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,7 +282,7 @@ __device__ __forceinline__ void reg_load(const ConvArgs& a, const ChunkSrc& cs, 
     const int q = rem - r * (kRS / 4);
     const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
     const bool row_ok = gy >= 0 && gy < a.H;
-    const float* row = cs.img + (size_t)ci * plane + (size_t)min(max(gy, 0), a.H - 1) * a.pitch;
+    const float* row = cs.img_ptr + (size_t)ci * plane + (size_t)min(max(gy, 0), a.H - 1) * a.pitch;
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -214,7 +295,7 @@ __device__ __forceinline__ void reg_load(const ConvArgs& a, const ChunkSrc& cs, 
 #pragma unroll
   for (int i = 0; i < C::RW_ITERS; ++i) {
     const int s = min(tid + i * 256, C::RW_SLOTS - 1);
-    const float* p = cs.wgt + 4 * s;  // packed images are only guaranteed 4-byte aligned here
+    const float* p = cs.wgt_ptr + 4 * s;  // packed images are only guaranteed 4-byte aligned here
     st.w[i] = f32x4{p[0], p[1], p[2], p[3]};
   }
 }
@@ -278,8 +359,8 @@ __device__ __forceinline__ void shadow_groups() {
 // PREFETCH: the wave's NPW LDS-DMA pieces of the chunk two ahead are issued between k-steps.
 template <int COUT, int NCT, int PG0, int NPG, bool PREFETCH>
 __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave, int lane,
-                                           f32x4 (&acc)[NCT][NPG], const DmaPlan<COUT>& pl, const float* nxt_img,
-                                           const float* nxt_wgt, float* nxt_stage) {
+                                           f32x4 (&acc)[NCT][NPG], const DmaPlan<COUT>& pl, const ChunkSrc& nxt,
+                                           unsigned nxt_stage) {
   using C = ConvCfg<COUT>;
   const int lr = lane & 15, lq = lane >> 4;
   const float* a_base = stage + C::IN_FLOATS + lq * C::CS + lr + ct0 * 16;
@@ -306,7 +387,7 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
                                                                   acc[m / NPG][m % NPG], 0, 0, 0);
       if constexpr (PREFETCH) {
         if (m == 0 && step % kEvery == 0 && step / kEvery < C::NPW)
-          dma_piece<COUT>(pl, step / kEvery, wave, nxt_img, nxt_wgt, nxt_stage);
+          dma_piece<COUT>(pl, step / kEvery, wave, nxt, nxt_stage);
       }
     }
     shadow_groups<NMF, NRD, 0>();
@@ -318,7 +399,7 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
       // unconditional (no branch inside the unrolled loop: a control-flow join makes hipcc wait
       // lgkmcnt(0), i.e. for the operand reads it has just issued)
       if (step % kEvery == 0 && step / kEvery < C::NPW)
-        dma_piece<COUT>(pl, step / kEvery, wave, nxt_img, nxt_wgt, nxt_stage);
+        dma_piece<COUT>(pl, step / kEvery, wave, nxt, nxt_stage);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -409,29 +490,41 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       for (int c = 0; c < 2; ++c) {
         const ChunkSrc cs = chunk_src<COUT>(a, min(c, last), n);
 #pragma unroll
-        for (int i = 0; i < C::NPW; ++i) dma_piece<COUT>(pl, i, wave, cs.img, cs.wgt, smem + c * C::STAGE_FLOATS);
+        for (int i = 0; i < C::NPW; ++i) dma_piece<COUT>(pl, i, wave, cs, lds_addr_of(smem + c * C::STAGE_FLOATS));
       }
     }
+    stamp(1);
     int stage = 0;
     for (int chunk = 0; chunk <= last; ++chunk) {
-      // The chunk's own pieces have landed (the NPW youngest operations belong to chunk+1) and,
-      // after the barrier, everybody's have, and everybody is done with the stage that
-      // chunk+2 is about to overwrite.
-      wait_and_barrier<(LARVA_DIAG & 2) ? 0 : C::NPW>();
-      const ChunkSrc nxt = chunk_src<COUT>(a, min(chunk + 2, last), n);
+      // The chunk's own pieces have landed and, after the barrier, everybody's have, and
+      // everybody is done with the stage that chunk+2 is about to overwrite.
+      if constexpr (C::LOADER) {
+        // this wave only issued its share of chunks 0 and 1: the first wait leaves chunk 1's
+        // pieces in flight, every later one finds nothing outstanding
+        if (chunk == 0) wait_and_barrier<(LARVA_DIAG & 2) ? 0 : C::NPW>();
+        else wait_and_barrier<0>();
+      } else {
+        // (the NPW youngest operations belong to chunk+1)
+        wait_and_barrier<(LARVA_DIAG & 2) ? 0 : C::NPW>();
+      }
+      if (chunk == 0) stamp(2);
+      stamp(8 + (chunk < 7 ? chunk : 7));
       const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
       if constexpr (!(LARVA_DIAG & 1)) {
-        if constexpr (!(LARVA_DIAG & 2))
-          mfma_chunk<COUT, NCT, PG0, NPG, true>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt.img,
-                                                nxt.wgt, smem + nstage * C::STAGE_FLOATS);
-        else
-          mfma_chunk<COUT, NCT, PG0, NPG, false>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt.img,
-                                                 nxt.wgt, smem + nstage * C::STAGE_FLOATS);
+        if constexpr (!(LARVA_DIAG & 2) && !C::LOADER) {
+          const ChunkSrc nxt = chunk_src<COUT>(a, min(chunk + 2, last), n);
+          mfma_chunk<COUT, NCT, PG0, NPG, true>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt,
+                                                lds_addr_of(smem + nstage * C::STAGE_FLOATS));
+        } else {
+          mfma_chunk<COUT, NCT, PG0, NPG, false>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, ChunkSrc{},
+                                                 0u);
+        }
       }
       stage = stage == 2 ? 0 : stage + 1;
     }
     // no LDS-DMA may be in flight when the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(3);
   } else {
     // ---- register staging, 2 stages ------------------------------------------------------------
     RegStaging<COUT> st;
@@ -448,7 +541,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         if (more) reg_load<COUT>(a, chunk_src<COUT>(a, chunk + 1, n), y0, x0, tid, st);
       }
       if constexpr (!(LARVA_DIAG & 1))
-        mfma_chunk<COUT, NCT, PG0, NPG, false>(cur, ct0, wave, lane, acc, DmaPlan<COUT>{}, nullptr, nullptr, nullptr);
+        mfma_chunk<COUT, NCT, PG0, NPG, false>(cur, ct0, wave, lane, acc, DmaPlan<COUT>{}, ChunkSrc{}, 0u);
       if constexpr (!(LARVA_DIAG & 2)) {
         if (more) reg_store<COUT>(nxt, tid, st);
       }
@@ -511,12 +604,18 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         }
       }
   }
+#if LARVA_DIAG & 32
+  stamp(4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(5);
+#endif
 }
 
 // VEC: 2 workgroups per CU (launch bound 2 waves/SIMD caps the registers at 256).
 template <int COUT, bool VEC, int EPI>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
   if constexpr ((LARVA_DIAG & 8) != 0) return;
+  stamp(0);
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = tile % a.tiles_x;
   const int t2 = tile / a.tiles_x;
@@ -529,6 +628,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
   // at priority 0 and take the matrix pipe only when these waves cannot use it.
   __builtin_amdgcn_s_setprio(1);
 
+  if constexpr (VEC && ConvCfg<COUT>::LOADER) {
+    if (wave == 4) {
+      if constexpr (!(LARVA_DIAG & 2)) run_loader<COUT>(a, smem, tid & 63, n, y0, x0);
+      return;
+    }
+  }
   // 9 pixel groups x CT cout groups, dealt to the 4 waves (one per SIMD) as evenly as a
   // rectangular (cout groups) x (pixel groups) ownership allows.
   if constexpr (COUT == 48) {  // 27 -> 7,7,7,6
@@ -544,7 +649,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
 }
 
 template <int COUT, bool VEC, int EPI>
-__global__ __launch_bounds__(256, VEC ? 2 : 1) void conv3x3_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(VEC ? ConvCfg<COUT>::THREADS_DMA : 256, VEC ? 2 : 1) void conv3x3_mfma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   conv_tile<COUT, VEC, EPI>(a, smem);
 }
@@ -560,7 +665,7 @@ struct ConvBatch {
 };
 
 template <int COUT, int EPI>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_batch_kernel(ConvBatch b) {
+__global__ __launch_bounds__(ConvCfg<COUT>::THREADS_DMA, 2) void conv3x3_mfma_batch_kernel(ConvBatch b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   conv_tile<COUT, true, EPI>(b.job[blockIdx.y], smem);
 }
@@ -643,11 +748,12 @@ static hipError_t launch_conv_e(const ConvArgs& a, hipStream_t stream, const Lau
     attr_set = true;
   }
   const int grid = a.N * a.tiles_x * a.tiles_y;
+  constexpr int threads = VEC ? C::THREADS_DMA : 256;
   if (tm)
-    hipExtLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(256), lds, stream,
+    hipExtLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(threads), lds, stream,
                           tm->start, tm->stop, 0, a);
   else
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(threads), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -681,8 +787,8 @@ static hipError_t launch_batch_e(const ConvBatch& b, int njobs, hipStream_t stre
     attr_set = true;
   }
   const ConvArgs& a = b.job[0];
-  hipLaunchKernelGGL((conv3x3_mfma_batch_kernel<COUT, EPI>), dim3(a.N * a.tiles_x * a.tiles_y, njobs), dim3(256),
-                     C::LDS_BYTES_DMA, stream, b);
+  hipLaunchKernelGGL((conv3x3_mfma_batch_kernel<COUT, EPI>), dim3(a.N * a.tiles_x * a.tiles_y, njobs),
+                     dim3(C::THREADS_DMA), C::LDS_BYTES_DMA, stream, b);
   return hipGetLastError();
 }
 
@@ -856,6 +962,12 @@ int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int c
     default: return (int)hipErrorInvalidValue;
   }
 }
+
+#if LARVA_DIAG & 32
+int larva_diag_set_stamps(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(larva::g_stamps), &buf, sizeof(buf));
+}
+#endif
 
 // Measurement only (synchronises; not capturable): runs the same launch `iters` times with
 // kernel-attached events and returns the mean and minimum kernel duration in milliseconds.

@@ -65,4 +65,34 @@ __device__ __forceinline__ void lds_dma(const void* gsrc, float* lds_dst_wave_un
                  : "memory");
 }
 
+// The same through a raw buffer descriptor (4 SGPRs: base, stride 0, num_records 2^31-1): lane l's
+// 16 bytes at base + soffset + voff land at LDS byte address lds_base + 16 l.  A lane whose voff is
+// out of range (>= 2^31, see kDmaZero) WRITES ZEROS (probed on gfx950: tools/probe_lds_dma.hip), so
+// padding costs no address select and no zero page.  Nothing here is per-lane arithmetic: the wave
+// issues 3 scalar moves and the load.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kDmaZero = 0x80000000u;
+
+__device__ __forceinline__ i32x4 dma_rsrc(const void* base) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));
+  r[2] = 0x7fffffff;
+  r[3] = 0x00020000;
+  return r;
+}
+
+__device__ __forceinline__ void lds_dma16_buf(i32x4 rsrc, unsigned voff, int soff_uniform, unsigned lds_addr_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_addr_uniform), "v"(voff), "s"(rsrc), "s"(soff_uniform)
+               : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr_of(const float* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p));
+}
+
 }  // namespace larva

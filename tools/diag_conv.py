@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "_diag")
 SRC = os.path.join(ROOT, "larvanet_amd", "csrc", "conv3x3_mfma.hip")
+TIMELINE = 32   # full kernel + in-kernel wall-clock stamps (--timeline)
+TIMELINE_MFMA = 38   # the same without staging and epilogue traffic
 VARIANTS = {0: "full kernel", 1: "no MFMA", 2: "no staging loads", 4: "no epilogue traffic", 3: "no MFMA, no staging",
             6: "MFMA only", 7: "roles + barriers only", 8: "empty launch", 16: "plain output stores"}
 
@@ -23,7 +25,7 @@ VARIANTS = {0: "full kernel", 1: "no MFMA", 2: "no staging loads", 4: "no epilog
 def build():
     os.makedirs(OUT, exist_ok=True)
     procs = []
-    for v in VARIANTS:
+    for v in list(VARIANTS) + [TIMELINE, TIMELINE_MFMA]:
         so = os.path.join(OUT, "libconv_diag%d.so" % v)
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLARVA_DIAG=%d" % v,
                "-DLARVA_DIAG_ONLY48=1", SRC, "-o", so]
@@ -74,8 +76,54 @@ def main():
         print("%-26s" % ("%d %s" % (v, label)) + "".join("%11.1f us" % t for t in row))
 
 
+def timeline():
+    """Where inside its 18 us does a conv launch spend the time?  100 MHz wall-clock stamps of wave 0
+    of every workgroup, relative to the earliest kernel-entry stamp of the launch; a chain of 6
+    dependent launches (each reads the previous output), the last one is reported."""
+    import numpy as np
+    import torch
+    import ctypes as ct
+    from larvanet_amd import hip_lib, kernels as K
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    bufs = [(torch.randn(16, 48, 48, 48, generator=g) * 20).to(dev) for _ in range(2)]
+    w = (torch.randn(48, 48, 3, 3, generator=g) * 0.01).to(dev)
+    b = torch.zeros(48, device=dev)
+    fwd, _ = K.pack_weights(w)
+    which = TIMELINE_MFMA if "--mfma-only" in sys.argv else TIMELINE
+    lib = ctypes.CDLL(os.path.join(OUT, "libconv_diag%d.so" % which))
+    fn = lib.larva_conv3x3_fwd
+    fn.restype, fn.argtypes = hip_lib.SIGNATURES["larva_conv3x3_fwd"]
+    stamps = torch.zeros(256 * 16, device=dev, dtype=torch.int64)
+    lib.larva_diag_set_stamps.argtypes = [ct.c_void_p]
+    assert lib.larva_diag_set_stamps(stamps.data_ptr()) == 0
+    stream = torch.cuda.current_stream().cuda_stream
+    rows = []
+    for rep in range(5):
+        for i in range(6):
+            src, dst = bufs[i & 1], bufs[(i + 1) & 1]
+            assert fn(hip_lib.ptr_array([src.data_ptr()]), 1, 48, fwd.data_ptr(), b.data_ptr(), None, None, None, None,
+                      dst.data_ptr(), 16, 48, 48, 48, 1, 0, stream) == 0
+        torch.cuda.synchronize()
+        t = stamps.cpu().numpy().reshape(256, 16).astype(np.float64) * 0.01  # us
+        rows.append(t - t[:, 0].min())
+    t = np.median(np.stack(rows), axis=0)
+    names = ["kernel entry", "DMA of chunks 0,1 issued", "chunk 0 landed (1st barrier)", "K loop done",
+             "stores issued", "stores drained"]
+    print("stamp                              median over WGs   min     max    (us after the first workgroup's entry)")
+    for k, nme in enumerate(names):
+        print("%-34s %10.2f %10.2f %7.2f" % (nme, np.median(t[:, k]), t[:, k].min(), t[:, k].max()))
+    print("per workgroup: entry->issue %.2f, issue->landed %.2f, K loop %.2f, store issue %.2f, drain %.2f us (medians)"
+          % tuple(np.median(t[:, k + 1] - t[:, k]) for k in range(5)))
+    ends = np.concatenate([t[:, 9:14], t[:, 3:4]], axis=1) - t[:, 8:13 + 1]
+    print("chunk durations (barrier exit -> next barrier exit / loop end), medians: " +
+          " ".join("%.2f" % np.median(ends[:, c]) for c in range(6)))
+
+
 if __name__ == "__main__":
     if "--build" in sys.argv:
         build()
+    elif "--timeline" in sys.argv:
+        timeline()
     else:
         main()
