@@ -138,28 +138,32 @@ struct DmaPlan {
   unsigned voff[ConvCfg<COUT>::NPW];
 };
 
-template <int COUT>
+// WEIGHTS = the offsets of this wave's weight pieces (trivial: a linear image), else those of its
+// input pieces (halo tile decomposition + bounds).  Two passes so that the prologue can issue the
+// weight pieces before it has worked out the input pieces.
+template <int COUT, bool WEIGHTS>
 __device__ __forceinline__ void make_plan(const ConvArgs& a, int wave, int lane, int y0, int x0,
                                           DmaPlan<COUT>& pl) {
   using C = ConvCfg<COUT>;
 #pragma unroll
   for (int i = 0; i < C::NPW; ++i) {
     const int p = min(wave + 4 * i, C::PIECES - 1);  // surplus pieces repeat the last one (same bytes)
-    // input piece
-    const int slot = p * 64 + lane;
-    const int ci = slot / C::IN_SLOTS_PER_PLANE;
-    const int rem = slot - ci * C::IN_SLOTS_PER_PLANE;
-    const int r = rem / (kRS / 4);
-    const int q = rem - r * (kRS / 4);
-    const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
-    const bool in_ok = ci < kCh && r < kHaloRows && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const int in_off = (ci * a.H + gy) * a.pitch + gx;
-    // weight piece
-    const int ws = (p - C::IN_PIECES) * 64 + lane;
-    const bool w_ok = ws * 4 < C::W_USED;
-    const bool isw = p >= C::IN_PIECES;  // wave-uniform
-    const bool ok = isw ? w_ok : in_ok;
-    pl.voff[i] = ok ? 4u * (unsigned)(isw ? ws * 4 : in_off) : kDmaZero;
+    const bool isw = p >= C::IN_PIECES;              // wave-uniform
+    if constexpr (WEIGHTS) {
+      if (4 * i + 3 < C::IN_PIECES) continue;        // an input piece for every wave
+      const int ws = (p - C::IN_PIECES) * 64 + lane;
+      if (isw) pl.voff[i] = (ws * 4 < C::W_USED) ? 16u * (unsigned)ws : kDmaZero;
+    } else {
+      if (4 * i >= C::IN_PIECES) continue;           // a weight piece for every wave
+      const int slot = p * 64 + lane;
+      const int ci = slot / C::IN_SLOTS_PER_PLANE;
+      const int rem = slot - ci * C::IN_SLOTS_PER_PLANE;
+      const int r = rem / (kRS / 4);
+      const int q = rem - r * (kRS / 4);
+      const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+      const bool ok = ci < kCh && r < kHaloRows && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      if (!isw) pl.voff[i] = ok ? 4u * (unsigned)((ci * a.H + gy) * a.pitch + gx) : kDmaZero;
+    }
   }
 }
 
@@ -427,17 +431,19 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   const int lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
 
-  // Bias is fetched first (older than every LDS-DMA, so the counted waits below cover it) and
-  // added in the epilogue.
+  // Bias (added in the epilogue) and the epilogue's other operands are fetched inside the DMA
+  // prologue, older than chunk 1's pieces, so the first counted wait of the ring covers them.
   f32x4 bias[NCT];
 #pragma unroll
   for (int c = 0; c < NCT; ++c) bias[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (a.bias) {
+  auto load_bias = [&]() {
+    if (a.bias) {
 #pragma unroll
-    for (int c = 0; c < NCT; ++c)
+      for (int c = 0; c < NCT; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bias[c][r] = a.bias[(ct0 + c) * 16 + lq * 4 + r];
-  }
+        for (int r = 0; r < 4; ++r) bias[c][r] = a.bias[(ct0 + c) * 16 + lq * 4 + r];
+    }
+  };
 
   // So are the epilogue's other operands (ReLU mask, residuals, bicubic base): issued here, they
   // land under the whole K loop instead of being waited for after it (the mask / residual
@@ -469,7 +475,11 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         }
       }
   };
-  if constexpr (NAUX > 0 && LARVA_AUX_EARLY && !(LARVA_DIAG & 4)) load_aux();
+  auto load_early = [&]() {
+    load_bias();
+    if constexpr (NAUX > 0 && LARVA_AUX_EARLY && !(LARVA_DIAG & 4)) load_aux();
+  };
+  if constexpr (!VEC || (LARVA_DIAG & 2)) load_early();
 
   f32x4 acc[NCT][NPG];
 #pragma unroll
@@ -479,19 +489,30 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
 
   if constexpr (VEC) {
     // ---- LDS-DMA ring: chunk c lives in stage c % 3; chunks c+1 and c+2 are in flight --------
+    // Prologue: the weight pieces of chunk 0 go out first (their offsets need no arithmetic), then
+    // bias and epilogue operands, then the input pieces of chunk 0, then all of chunk 1 -- so that
+    // the youngest NPW operations are chunk 1's, which is what the first counted wait leaves in
+    // flight.  Chunk c is followed in the ring by chunk c+1 and c+2; past the end the last chunk is
+    // simply streamed again into a stage nobody reads any more, which keeps every wait the same
+    // counted vmcnt and the MFMA loop free of branches.
     DmaPlan<COUT> pl;
-    make_plan<COUT>(a, wave, lane, y0, x0, pl);
-    // Chunk c is followed in the ring by chunk c+1 and c+2; past the end the last chunk is simply
-    // streamed again into a stage nobody reads any more, which keeps every wait the same counted
-    // vmcnt(NPW) and the MFMA loop free of branches.
     const int last = a.n_chunks - 1;
     if constexpr (!(LARVA_DIAG & 2)) {
+      const ChunkSrc cs0 = chunk_src<COUT>(a, 0, n);
+      const unsigned st0 = lds_addr_of(smem), st1 = lds_addr_of(smem + C::STAGE_FLOATS);
+      make_plan<COUT, true>(a, wave, lane, y0, x0, pl);
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const ChunkSrc cs = chunk_src<COUT>(a, min(c, last), n);
+      for (int i = 0; i < C::NPW; ++i)
+        if (wave + 4 * i >= C::IN_PIECES) dma_piece<COUT>(pl, i, wave, cs0, st0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_early();
+      make_plan<COUT, false>(a, wave, lane, y0, x0, pl);
 #pragma unroll
-        for (int i = 0; i < C::NPW; ++i) dma_piece<COUT>(pl, i, wave, cs, lds_addr_of(smem + c * C::STAGE_FLOATS));
-      }
+      for (int i = 0; i < C::NPW; ++i)
+        if (wave + 4 * i < C::IN_PIECES) dma_piece<COUT>(pl, i, wave, cs0, st0);
+      const ChunkSrc cs1 = chunk_src<COUT>(a, min(1, last), n);
+#pragma unroll
+      for (int i = 0; i < C::NPW; ++i) dma_piece<COUT>(pl, i, wave, cs1, st1);
     }
     stamp(1);
     int stage = 0;
