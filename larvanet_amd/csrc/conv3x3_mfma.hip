@@ -80,7 +80,16 @@ struct ConvArgs {
   int pitch;                  // row stride (floats) of every [..][H][W] tensor above; >= W.  Columns
                               // [W, pitch) of the inputs hold zeros and are written as zeros.
   int tiles_x, tiles_y;
+  // ceil(2^40 / d) for d = tiles_x, tiles_y, cin_per_src / 8: the kernel's wave-uniform divisions
+  // as one 64-bit multiply + shift (a runtime integer division is ~40 vector instructions, three of
+  // them stood at the very start of every workgroup); exact while dividend * divisor < 2^40
+  unsigned long long magic_tx, magic_ty, magic_cps;
 };
+
+__host__ __device__ __forceinline__ unsigned long long div_magic(int d) { return ((1ull << 40) + d - 1) / (unsigned)d; }
+__device__ __forceinline__ int div_by_magic(int n, unsigned long long magic) {
+  return (int)(((unsigned long long)(unsigned)n * magic) >> 40);
+}
 
 // Epilogue variants (compile-time so that every residual/mask load of a wave is in flight at
 // once instead of one dependent L2 round trip per runtime branch).
@@ -178,7 +187,7 @@ template <int COUT>
 __device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int n) {
   using C = ConvCfg<COUT>;
   const int c0 = chunk * kCh;
-  const int s_idx = c0 / a.cin_per_src;
+  const int s_idx = div_by_magic(chunk, a.magic_cps);
   const int c_in_src = c0 - s_idx * a.cin_per_src;
   ChunkSrc cs;
   cs.img_ptr = a.src[s_idx] + ((size_t)n * a.cin_per_src + c_in_src) * ((size_t)a.H * a.pitch);
@@ -500,16 +509,20 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     if constexpr (!(LARVA_DIAG & 2)) {
       const ChunkSrc cs0 = chunk_src<COUT>(a, 0, n);
       const unsigned st0 = lds_addr_of(smem), st1 = lds_addr_of(smem + C::STAGE_FLOATS);
+      stamp(6);
       make_plan<COUT, true>(a, wave, lane, y0, x0, pl);
 #pragma unroll
       for (int i = 0; i < C::NPW; ++i)
         if (wave + 4 * i >= C::IN_PIECES) dma_piece<COUT>(pl, i, wave, cs0, st0);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(7);
       load_early();
+      stamp(14);
       make_plan<COUT, false>(a, wave, lane, y0, x0, pl);
 #pragma unroll
       for (int i = 0; i < C::NPW; ++i)
         if (wave + 4 * i < C::IN_PIECES) dma_piece<COUT>(pl, i, wave, cs0, st0);
+      stamp(15);
       const ChunkSrc cs1 = chunk_src<COUT>(a, min(1, last), n);
 #pragma unroll
       for (int i = 0; i < C::NPW; ++i) dma_piece<COUT>(pl, i, wave, cs1, st1);
@@ -638,10 +651,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
   if constexpr ((LARVA_DIAG & 8) != 0) return;
   stamp(0);
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = tile % a.tiles_x;
-  const int t2 = tile / a.tiles_x;
-  const int ty = t2 % a.tiles_y;
-  const int n = t2 / a.tiles_y;
+  const int t2 = div_by_magic(tile, a.magic_tx);
+  const int tx = tile - t2 * a.tiles_x;
+  const int n = div_by_magic(t2, a.magic_ty);
+  const int ty = t2 - n * a.tiles_y;
   const int x0 = tx * kTileCols, y0 = ty * kTileRows;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -889,6 +902,10 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
   a.N = N; a.H = H; a.W = W; a.pitch = pitch;
   a.tiles_x = (pitch + kTileCols - 1) / kTileCols;
   a.tiles_y = (H + kTileRows - 1) / kTileRows;
+  if ((long long)N * a.tiles_x * a.tiles_y >= (1ll << 20)) return (int)hipErrorInvalidValue;  // div_by_magic range
+  a.magic_tx = div_magic(a.tiles_x);
+  a.magic_ty = div_magic(a.tiles_y);
+  a.magic_cps = div_magic(cin_per_src / kCh);
   // Map the requested fusion onto a compiled epilogue (relu -> mask -> +res0 -> +res1).
   if (mode == 1) {
     if (relu || mask || res0 || res1) return (int)hipErrorInvalidValue;

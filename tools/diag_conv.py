@@ -115,6 +115,9 @@ def timeline():
         print("%-34s %10.2f %10.2f %7.2f" % (nme, np.median(t[:, k]), t[:, k].min(), t[:, k].max()))
     print("per workgroup: entry->issue %.2f, issue->landed %.2f, K loop %.2f, store issue %.2f, drain %.2f us (medians)"
           % tuple(np.median(t[:, k + 1] - t[:, k]) for k in range(5)))
+    pro = [t[:, 6] - t[:, 0], t[:, 7] - t[:, 6], t[:, 14] - t[:, 7], t[:, 15] - t[:, 14], t[:, 1] - t[:, 15]]
+    print("prologue: entry->chunk_src %.2f, weight plan+issue %.2f, bias/aux loads %.2f, input plan+issue %.2f, "
+          "chunk 1 issue %.2f us (medians)" % tuple(np.median(v) for v in pro))
     ends = np.concatenate([t[:, 9:14], t[:, 3:4]], axis=1) - t[:, 8:13 + 1]
     print("chunk durations (barrier exit -> next barrier exit / loop end), medians: " +
           " ".join("%.2f" % np.median(ends[:, c]) for c in range(6)))
