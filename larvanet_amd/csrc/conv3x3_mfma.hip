@@ -80,6 +80,7 @@ struct ConvArgs {
   int pitch;                  // row stride (floats) of every [..][H][W] tensor above; >= W.  Columns
                               // [W, pitch) of the inputs hold zeros and are written as zeros.
   int tiles_x, tiles_y;
+  int nwg;                    // N * tiles_x * tiles_y = workgroups of this conv (gridDim.x)
   // ceil(2^40 / d) for d = tiles_x, tiles_y, cin_per_src / 8: the kernel's wave-uniform divisions
   // as one 64-bit multiply + shift (a runtime integer division is ~40 vector instructions, three of
   // them stood at the very start of every workgroup); exact while dividend * divisor < 2^40
@@ -650,7 +651,13 @@ template <int COUT, bool VEC, int EPI>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
   if constexpr ((LARVA_DIAG & 8) != 0) return;
   stamp(0);
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // Fetch every kernel argument NOW, in one batch of scalar loads.  Left alone the compiler loads
+  // each field in the block that first uses it: three dependent s_load round trips (~0.15 us each)
+  // stood between kernel entry and the first LDS-DMA request.
+  asm volatile("" ::"s"(a.src[0]), "s"(a.wpk), "s"(a.bias), "s"(a.out), "s"(a.cin_per_src), "s"(a.n_chunks), "s"(a.N),
+               "s"(a.H), "s"(a.W), "s"(a.pitch), "s"(a.tiles_x), "s"(a.tiles_y), "s"(a.magic_tx), "s"(a.magic_ty),
+               "s"(a.magic_cps), "s"(a.nwg));
+  const int tile = xcd_remap(blockIdx.x, a.nwg);
   const int t2 = div_by_magic(tile, a.magic_tx);
   const int tx = tile - t2 * a.tiles_x;
   const int n = div_by_magic(t2, a.magic_ty);
@@ -906,6 +913,7 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
   a.magic_tx = div_magic(a.tiles_x);
   a.magic_ty = div_magic(a.tiles_y);
   a.magic_cps = div_magic(cin_per_src / kCh);
+  a.nwg = N * a.tiles_x * a.tiles_y;
   // Map the requested fusion onto a compiled epilogue (relu -> mask -> +res0 -> +res1).
   if (mode == 1) {
     if (relu || mask || res0 || res1) return (int)hipErrorInvalidValue;
