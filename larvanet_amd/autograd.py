@@ -339,8 +339,19 @@ class DeferredWgrad:
 
     @staticmethod
     def _issue(launches):
+        """The partial-image launches one after the other, then ONE fixed-order reduction per
+        kernel shape over all of them (each layer with its own split count)."""
+        if K._WGRAD_VARIANT == "dma":
+            for cout, cin, chunk in launches:
+                K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
+            return
+        reduce_jobs = {}
         for cout, cin, chunk in launches:
-            K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
+            parts, used = K.conv3x3_wgrad_partial(chunk, cout, cin, _splits(len(chunk)))
+            reduce_jobs.setdefault((cout, cin), []).extend(dict(j, partial=p, splits=used) for j, p in zip(chunk, parts))
+        for (cout, cin), jobs in reduce_jobs.items():
+            for i in range(0, len(jobs), 64):
+                K.wgrad_reduce(jobs[i:i + 64], cout, cin)
 
     @classmethod
     def flush(cls, split=False):
