@@ -144,6 +144,10 @@ int larva_loss_from_partials(const float* const* terms, const int* count, const 
  * gscale / numel, a, b [N][C][4H][4W]; same partial sums and gradient values as the two calls. */
 int larva_l1_partial_grad(const float* a, const float* b, float gvalue, float gscale, float* partial,
                           int* blocks_out, float* grad, int N, int C, int H, int W, void* stream);
+/* The same for n <= 8 exit images a[i] scored against one truth image b, in one launch. */
+int larva_l1_partial_grad_batch(const float* const* a, const float* b, int n, float gvalue, float gscale,
+                                float* const* partial, int* blocks_out, float* const* grad, int N, int C, int H,
+                                int W, void* stream);
 
 /* ---- PixelShuffle(4) backward (models/LarvaNet.py:261): in [N][C][4H][4W] -> out [N][16C][H][W] */
 int larva_pixel_unshuffle4(const float* in, float* out, int N, int C, int H, int W, void* stream);

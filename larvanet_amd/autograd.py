@@ -731,14 +731,16 @@ class ExitsFn(torch.autograd.Function):
         ctx.gscale = float(np.float32(1.0) / np.float32(divisor))
         ctx.have_dyl = StepScope.seed_grad is not None
         parts, third = [], []
-        for out in outs:
-            if ctx.have_dyl:  # gradient value known now: one sweep over (out, truth) does both
-                part, _, dyl = K.l1_partial_grad(out, truth, StepScope.seed_grad, ctx.gscale)
-                third.append(dyl)
-            else:
+        if ctx.have_dyl:  # gradient value known now: one sweep over (out_i, truth) does both, all exits at once
+            for i in range(0, M, 8):
+                p8, _, g8 = K.l1_partial_grad_batch(outs[i:i + 8], truth, StepScope.seed_grad, ctx.gscale)
+                parts += p8
+                third += g8
+        else:
+            for out in outs:
                 part, _ = K.l1_partial(out, truth)
+                parts.append(part)
                 third.append(out)
-            parts.append(part)
         ctx.save_for_backward(truth, *feas, *hs, *third)
         ctx.legs, ctx.M = legs, M
         ctx.wshape = tuple(params[0].shape)

@@ -201,6 +201,44 @@ __global__ __launch_bounds__(256) void l1_partial_grad_kernel(const float* __res
   if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+// The same for up to 8 exits scored against ONE truth image in one launch (blockIdx.y = exit).
+struct L1Jobs {
+  const float* a[8];
+  float* partial[8];
+  float* grad[8];
+};
+__global__ __launch_bounds__(256) void l1_partial_grad_batch_kernel(L1Jobs jobs, const float* __restrict__ b,
+                                                                    long long numel, float g, int H, int W) {
+  const float* __restrict__ a = jobs.a[blockIdx.y];
+  float* __restrict__ partial = jobs.partial[blockIdx.y];
+  float* __restrict__ grad = jobs.grad[blockIdx.y];
+  float s = 0.f;
+  const long long n4 = numel >> 2;
+  const int HH = 4 * H;
+  const size_t plane = (size_t)H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 va = reinterpret_cast<const f32x4*>(a)[i];
+    const f32x4 vb = reinterpret_cast<const f32x4*>(b)[i];
+    s += fabsf(va[0] - vb[0]) + fabsf(va[1] - vb[1]) + fabsf(va[2] - vb[2]) + fabsf(va[3] - vb[3]);
+    const int x = (int)(i % W);
+    const long long t2 = i / W;
+    const int Y = (int)(t2 % HH);
+    const long long p = t2 / HH;
+    float* o = grad + ((size_t)(p * 16 + 4 * (Y & 3)) * H + (Y >> 2)) * W + x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = va[e] - vb[e];
+      o[e * plane] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
 // out[0] = ( sum_i  scale_i * (sum of the count_i floats at p_i) ) / divisor: the mean over the
 // exits of their L1 terms straight from the block partial sums of l1_partial_kernel (count_i =
 // its block count, scale_i = 1 / numel), or of ready scalars (count 1, scale 1).  Each term is
@@ -423,6 +461,30 @@ int larva_l1_partial_grad(const float* a, const float* b, float gvalue, float gs
   const float g = (gvalue * gscale) * (1.0f / (float)numel);  // the arithmetic of l1_bwd_unshuffle4_kernel
   hipLaunchKernelGGL(l1_partial_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, numel, g, partial,
                      grad, H, W);
+  return (int)hipGetLastError();
+}
+
+// larva_l1_partial_grad for n <= 8 images a[i] against the same b, one launch.
+int larva_l1_partial_grad_batch(const float* const* a, const float* b, int n, float gvalue, float gscale,
+                                float* const* partial, int* blocks_out, float* const* grad, int N, int C, int H,
+                                int W, void* stream) {
+  if (!a || !b || !partial || !blocks_out || !grad || n < 1 || n > 8 || N <= 0 || C <= 0 || H <= 0 || W <= 0)
+    return (int)hipErrorInvalidValue;
+  L1Jobs jobs{};
+  uintptr_t bits = reinterpret_cast<uintptr_t>(b);
+  for (int i = 0; i < n; ++i) {
+    if (!a[i] || !partial[i] || !grad[i]) return (int)hipErrorInvalidValue;
+    jobs.a[i] = a[i]; jobs.partial[i] = partial[i]; jobs.grad[i] = grad[i];
+    bits |= reinterpret_cast<uintptr_t>(a[i]);
+  }
+  if (bits & 15) return (int)hipErrorInvalidValue;
+  const long long numel = (long long)N * C * 16 * H * W;
+  int blocks = grid_for(numel / 4, 256);
+  if (blocks > kL1Blocks) blocks = kL1Blocks;
+  *blocks_out = blocks;
+  const float g = (gvalue * gscale) * (1.0f / (float)numel);
+  hipLaunchKernelGGL(l1_partial_grad_batch_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, jobs, b, numel,
+                     g, H, W);
   return (int)hipGetLastError();
 }
 

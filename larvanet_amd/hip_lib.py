@@ -63,6 +63,9 @@ SIGNATURES = {
     "larva_l1_partial_grad": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_float, ctypes.c_float, _c_float_p,
                                              _c_int_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_void_p]),
+    "larva_l1_partial_grad_batch": (ctypes.c_int, [_c_pp, _c_float_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, _c_pp,
+                                                   _c_int_p, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_void_p]),
     "larva_loss_from_partials": (ctypes.c_int, [_c_pp, _c_int_p, _c_float_p, ctypes.c_int, ctypes.c_float,
                                                 _c_float_p, ctypes.c_void_p]),
     "larva_sum_scalars": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_void_p]),

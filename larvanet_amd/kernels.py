@@ -357,6 +357,29 @@ def l1_partial_grad(a, b, gvalue, gscale):
     return part[:int(blocks.value)], 1.0 / float(a.numel()), grad
 
 
+def l1_partial_grad_batch(outs, truth, gvalue, gscale):
+    """l1_partial_grad for several exit images against one truth in one launch ->
+    ([partials], 1 / numel, [grads])."""
+    lib = hip_lib.load()
+    if not 1 <= len(outs) <= 8:
+        raise RuntimeError("larvanet_amd: 1..8 images per batched L1 sweep")
+    _chk(truth, "truth")
+    N, C, HH, WW = (int(v) for v in truth.shape)
+    if HH % 4 or WW % 4:
+        raise RuntimeError("larvanet_amd: spatial dims must be divisible by 4")
+    ptrs = [_chk(o, "out", truth.shape) for o in outs]
+    nws = int(lib.larva_l1_workspace_floats())
+    parts = [torch.empty(nws, device=truth.device, dtype=torch.float32) for _ in outs]
+    grads = [torch.empty((N, 16 * C, HH // 4, WW // 4), device=truth.device, dtype=torch.float32) for _ in outs]
+    blocks = ctypes.c_int(0)
+    hip_lib.check(lib.larva_l1_partial_grad_batch(
+        hip_lib.ptr_array(ptrs), truth.data_ptr(), len(outs), float(gvalue), float(gscale),
+        hip_lib.ptr_array([p.data_ptr() for p in parts]), ctypes.byref(blocks),
+        hip_lib.ptr_array([g.data_ptr() for g in grads]), N, C, HH // 4, WW // 4, _stream()), "larva_l1_partial_grad_batch")
+    nb = int(blocks.value)
+    return [p[:nb] for p in parts], 1.0 / float(truth.numel()), grads
+
+
 def loss_from_partials(terms, scales, divisor):
     """( sum_i scales[i] * terms[i].sum() ) / divisor as a 0-d tensor, one launch, fixed order."""
     lib = hip_lib.load()

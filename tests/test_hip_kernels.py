@@ -377,6 +377,9 @@ def test_l1_bwd_unshuffle_and_sum_scalars(hip_device):
     part2, inv2, grad2 = K.l1_partial_grad(x, y, 0.25, 0.5)
     assert torch.equal(part2, part) and inv2 == inv
     assert torch.equal(grad2, K.l1_bwd_unshuffle4(x, y, g, 0.5))  # one sweep == the two kernels
+    pb, invb, gb = K.l1_partial_grad_batch([x, y, x], y, 0.25, 0.5)  # three "exits" against truth y
+    assert invb == inv and torch.equal(pb[0], part) and torch.equal(gb[0], grad2) and torch.equal(pb[2], part)
+    assert float(pb[1].sum()) == 0.0 and float(gb[1].abs().sum()) == 0.0
     half = K.l1_bwd_unshuffle4(x, y, g, 0.5)
     assert torch.equal(half, K.l1_bwd_unshuffle4(x, y, torch.tensor(0.125, device=hip_device)))
 
