@@ -39,7 +39,7 @@ CONV_FLOP = 2 * 9 * CH * CH * BATCH * PATCH * PATCH      # 1.5288 GFLOP per 48->
 FP32_MFMA_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: Peak FP32 (matrix)
 # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per
 # the guide's gfx950 correction + WRITE_SIZE), see profiles/README.md; None until measured.
-HBM_TRAFFIC_PER_LAUNCH = (2 * 3887.0 + 6912.0) * 1024   # profiles/r01_c_pmc_conv3x3_relu_v2.csv
+HBM_TRAFFIC_PER_LAUNCH = (2 * 3919.0 + 7149.6) * 1024   # profiles/r01_h_pmc_conv3x3_relu_final.csv (KB)
 
 
 class TinyValLoader:
