@@ -126,6 +126,33 @@ def roofline_block(dev):
             "algorithmic_bytes_per_launch": 2 * BATCH * CH * PATCH * PATCH * 4 + 4 * (9 * CH * CH + CH)}
 
 
+def wgrad_block(dev, jobs=32, iters=5):
+    """Second kernel of the step (28 % of it): the weight-gradient launch as the step issues it
+    (32 layers x 8 workgroups, partial images + fixed-order reduction), timed with an event pair."""
+    from larvanet_amd import kernels as K
+    g = torch.Generator().manual_seed(6)
+    dy = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 1e-3).to(dev)
+    xs = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 20).to(dev)
+    js = [{"dy": dy + 0, "x": xs + 0, "dw": torch.empty(CH, CH, 3, 3, device=dev), "db": torch.empty(CH, device=dev)}
+          for _ in range(jobs)]
+    parts = K.conv3x3_wgrad(js, CH, CH, 256 // jobs)
+    for j, p in zip(js, parts):
+        j["partial"] = p
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        K.conv3x3_wgrad(js, CH, CH, 256 // jobs)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    achieved = CONV_FLOP * jobs / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "kernel": "wgrad3x3_pipe_kernel<48, 48> + wgrad_reduce_kernel, "
+            "%d layers x %d workgroups, 16x48x48x48 fp32" % (jobs, 256 // jobs), "ms_per_launch_pair": ms,
+            "flop_per_layer": CONV_FLOP}
+
+
 def host_cores():
     """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (a GPU
     box hands each job a share of a large host; 256 threads on a 16-CPU share thrash)."""
@@ -265,6 +292,7 @@ def main():
                    "loss_sync_per_step": bool(a.sync_loss), "hip_graph": bool(model.use_hip_graph),
                    "final_loss": float(loss)},
         "roofline": roofline_block(dev),
+        "roofline_wgrad": wgrad_block(dev),
         "infer": {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
                   "unit": "HR Mpixels/s"},
     }
