@@ -126,7 +126,7 @@ def roofline_block(dev):
             "algorithmic_bytes_per_launch": 2 * BATCH * CH * PATCH * PATCH * 4 + 4 * (9 * CH * CH + CH)}
 
 
-def wgrad_block(dev, jobs=32, iters=5):
+def wgrad_block(dev, jobs=32, iters=20):
     """Second kernel of the step (28 % of it): the weight-gradient launch as the step issues it
     (32 layers x 8 workgroups, partial images + fixed-order reduction), timed with an event pair."""
     from larvanet_amd import kernels as K
@@ -138,6 +138,8 @@ def wgrad_block(dev, jobs=32, iters=5):
     parts = K.conv3x3_wgrad(js, CH, CH, 256 // jobs)
     for j, p in zip(js, parts):
         j["partial"] = p
+    for _ in range(5):  # the chip needs a few hundred microseconds of load to settle its clock
+        K.conv3x3_wgrad(js, CH, CH, 256 // jobs)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
