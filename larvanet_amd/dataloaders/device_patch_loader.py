@@ -103,14 +103,17 @@ class DevicePatchLoader(BaseLoader):
     def get_image_pair(self, image_index, scale):
         return self.source.get_image_pair(image_index, scale)
 
-    def get_device_batch(self, batch_size, scale, input_patch_size, draws=None):
-        """-> (input tensor [B][3][p][p], truth tensor [B][3][p*scale][p*scale]) on the device."""
+    def get_device_batch(self, batch_size, scale, input_patch_size, draws=None, out=None):
+        """-> (input tensor [B][3][p][p], truth tensor [B][3][p*scale][p*scale]) on the device;
+        out = (input buffer, truth buffer) to fill in place (the plugin's `input_buffers()`: the
+        captured training step then reads the batch where the sampler wrote it, no copy)."""
         if draws is None:
             draws = draw_batch(self.rng, self.shapes, batch_size, input_patch_size)
         t = self.tables[scale]
         d = torch.from_numpy(np.ascontiguousarray(draws, dtype=np.int32)).to(self.device, non_blocking=True)
-        x = K.gather_patches(t["lr"], t["lr_off"], t["lr_hw"], d, batch_size, input_patch_size, 1)
-        y = K.gather_patches(t["hr"], t["hr_off"], t["hr_hw"], d, batch_size, input_patch_size * scale, scale)
+        ox, oy = out if out is not None else (None, None)
+        x = K.gather_patches(t["lr"], t["lr_off"], t["lr_hw"], d, batch_size, input_patch_size, 1, out=ox)
+        y = K.gather_patches(t["hr"], t["hr_off"], t["hr_hw"], d, batch_size, input_patch_size * scale, scale, out=oy)
         return x, y
 
     def get_patch_batch(self, batch_size, scale, input_patch_size):

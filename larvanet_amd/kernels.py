@@ -459,8 +459,9 @@ def adamw_step(p, g, m, v, step_lr, beta1, beta2, eps, weight_decay, grad_scale=
                   "larva_adamw_step")
 
 
-def gather_patches(data, offsets, hw, draws, batch, patch, mult):
-    """Augmented float patches [batch][3][patch][patch] from a uint8 dataset resident on the device."""
+def gather_patches(data, offsets, hw, draws, batch, patch, mult, out=None):
+    """Augmented float patches [batch][3][patch][patch] from a uint8 dataset resident on the device
+    (into `out` when given: e.g. the input buffer a captured training step reads)."""
     lib = hip_lib.load()
     for t, name, dt in ((data, "data", torch.uint8), (offsets, "offsets", torch.int64), (hw, "hw", torch.int32),
                         (draws, "draws", torch.int32)):
@@ -468,7 +469,9 @@ def gather_patches(data, offsets, hw, draws, batch, patch, mult):
             raise RuntimeError("larvanet_amd: %s must be a contiguous %s tensor on the HIP device" % (name, dt))
     if tuple(draws.shape) != (batch, 5):
         raise RuntimeError("larvanet_amd: draws must be [batch][5]")
-    out = torch.empty((batch, 3, patch, patch), device=data.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((batch, 3, patch, patch), device=data.device, dtype=torch.float32)
+    _chk(out, "out", (batch, 3, patch, patch))
     hip_lib.check(lib.larva_gather_patches(data.data_ptr(), offsets.data_ptr(), hw.data_ptr(), draws.data_ptr(),
                                            out.data_ptr(), batch, patch, mult, _stream()), "larva_gather_patches")
     return out

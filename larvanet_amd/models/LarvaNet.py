@@ -445,6 +445,17 @@ class LarvaNet(BaseModel):
         self._graph, self._graph_loss, self._graph_out = graph, loss, out
         self._graph_shape = self._graph_key(input_tensor, truth_tensor)
 
+    def input_buffers(self, input_shape, truth_shape):
+        """The (input, truth) tensors the captured training step reads, or None while no step of
+        that shape has been captured.  A producer on the device (dataloaders/device_patch_loader)
+        writes the next batch straight into them and passes them to train_step_larva, which then
+        skips its two copies into the graph's inputs."""
+        if not self.use_hip_graph or getattr(self, "_graph_shape", None) is None:
+            return None
+        if tuple(self._static_in.shape) != tuple(input_shape) or tuple(self._static_truth.shape) != tuple(truth_shape):
+            return None
+        return self._static_in, self._static_truth
+
     def _zero_grad(self):
         """optim.zero_grad() of the reference (models/LarvaNet.py:112).  With the flat gradient
         bucket every backward overwrites the gradients in place, so nothing has to be cleared
@@ -470,8 +481,11 @@ class LarvaNet(BaseModel):
                     self.use_hip_graph = False
                     torch.cuda.synchronize()
                     return self._forward_backward(input_tensor, truth_tensor)
-            self._static_in.copy_(input_tensor)
-            self._static_truth.copy_(truth_tensor)
+            # (a producer that filled input_buffers() in place hands the very same storage back)
+            if input_tensor.data_ptr() != self._static_in.data_ptr():
+                self._static_in.copy_(input_tensor)
+            if truth_tensor.data_ptr() != self._static_truth.data_ptr():
+                self._static_truth.copy_(truth_tensor)
             self._graph.replay()  # gradients are overwritten in place: no zero_grad needed
             self._late = self._graph_late.replay if self._graph_late is not None else None
             return self._graph_loss, self._graph_out

@@ -122,8 +122,11 @@ def main(argv=None):
             t0 = time.time()
             if getattr(loader, "is_device", False):
                 # dataset resident in HBM: the batch is cut, augmented and converted on the GPU
-                input_tensor, truth_tensor = loader.get_device_batch(batch_size=args.batch_size, scale=scale,
-                                                                     input_patch_size=args.input_patch_size)
+                p, b = args.input_patch_size, args.batch_size
+                bufs = model.input_buffers((b, 3, p, p), (b, 3, p * scale, p * scale)) \
+                    if hasattr(model, "input_buffers") else None
+                input_tensor, truth_tensor = loader.get_device_batch(batch_size=b, scale=scale, input_patch_size=p,
+                                                                     out=bufs)
                 t1 = time.time()
             else:
                 if loader.is_threaded:

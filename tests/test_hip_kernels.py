@@ -409,6 +409,12 @@ def test_gather_patches_matches_numpy_crop_rot_flip(hip_device):
     # seeded draw streams reproduce, and feed train-shaped batches
     x1, y1 = ld.get_device_batch(4, 4, p)
     assert tuple(x1.shape) == (4, 3, p, p) and tuple(y1.shape) == (4, 3, 4 * p, 4 * p) and x1.dtype == torch.float32
+    # in-place production into caller-owned buffers (the captured step's inputs)
+    bx, by = torch.empty_like(x1), torch.empty_like(y1)
+    ox, oy = ld.get_device_batch(4, 4, p, draws=draws[:4], out=(bx, by))
+    assert ox.data_ptr() == bx.data_ptr() and oy.data_ptr() == by.data_ptr()
+    rx, ry = ld.get_device_batch(4, 4, p, draws=draws[:4])
+    assert torch.equal(bx, rx) and torch.equal(by, ry)
 
 
 @pytest.mark.parametrize("W,P", [(13, 16), (50, 52), (26, 28), (47, 48)])

@@ -280,6 +280,32 @@ def test_device_resident_training_and_runtime_probe(hip_device, tmp_path, capsys
     assert res[4] > 0
 
 
+def test_step_reads_batches_produced_into_its_input_buffers(hip_device):
+    """A producer that fills input_buffers() in place trains exactly like one that hands over fresh
+    tensors (which the step copies into the captured graph's inputs)."""
+    g = torch.Generator().manual_seed(41)
+    batches = [((torch.rand(2, 3, 12, 16, generator=g) * 255).to(hip_device),
+                (torch.rand(2, 3, 48, 64, generator=g) * 255).to(hip_device)) for _ in range(4)]
+    args = types.SimpleNamespace(train_path="/tmp")
+    finals = []
+    for in_place in (False, True):
+        m = _model("LarvaNet", ["--num_modules=2", "--num_blocks=1,1"], training=True, seed=5)
+        assert m.input_buffers((2, 3, 12, 16), (2, 3, 48, 64)) is None  # nothing captured yet
+        losses = []
+        for x, t in batches:
+            bufs = m.input_buffers(x.shape, t.shape) if in_place else None
+            if bufs is not None:
+                bufs[0].copy_(x)
+                bufs[1].copy_(t)
+                x, t = bufs
+            losses.append(m.train_step_larva(args, FakeValLoader(7), x, t))
+        assert not in_place or m.input_buffers((2, 3, 12, 16), (2, 3, 48, 64)) is not None
+        finals.append((losses, {k: v.cpu().numpy().copy() for k, v in m.model.state_dict().items()}))
+    assert finals[0][0] == finals[1][0]
+    for k in finals[0][1]:
+        assert np.array_equal(finals[0][1][k], finals[1][1][k]), k
+
+
 def test_training_state_resume_is_bit_exact(hip_device, tmp_path):
     """weights + optimizer moments + scheduler + counters: 2 steps, save, 2 more == 4 straight."""
     g = torch.Generator().manual_seed(11)
