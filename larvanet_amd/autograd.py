@@ -803,7 +803,12 @@ class MeanTermsFn(torch.autograd.Function):
     def forward(ctx, meta, *tensors):
         ctx.meta = meta
         ctx.shapes = [tuple(t.shape) for t in tensors]
-        return K.loss_from_partials([t.contiguous() for t in tensors], [m[0] for m in meta], float(len(tensors)))
+        ts, scales = [t.contiguous() for t in tensors], [m[0] for m in meta]
+        if len(ts) <= 8:
+            return K.loss_from_partials(ts, scales, float(len(ts)))
+        # more terms than one launch takes: sums of groups of 8 first, then their mean
+        groups = [K.loss_from_partials(ts[i:i + 8], scales[i:i + 8], 1.0) for i in range(0, len(ts), 8)]
+        return K.loss_from_partials(groups, [1.0] * len(groups), float(len(ts)))
 
     @staticmethod
     def backward(ctx, g):

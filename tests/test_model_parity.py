@@ -194,6 +194,7 @@ def test_joint_input_gradient_launch_matches_separate_launches(hip_device, name,
 
 @pytest.mark.parametrize("name,flags", [("LarvaNet", ["--num_modules=3", "--num_blocks=2,1,1"]),
                                         ("LarvaNet", ["--num_modules=5", "--num_blocks=1,1,1,1,1"]),
+                                        ("LarvaNet", ["--num_modules=9", "--num_blocks=1,1,1,1,1,1,1,1,1"]),
                                         ("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,2"])])
 def test_exits_as_one_batched_node_match_one_node_per_exit(hip_device, name, flags):
     """ExitsFn (all exits after the body chain, batched launches, joint input gradients) against
