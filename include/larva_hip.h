@@ -103,13 +103,6 @@ int larva_wgrad_reduce(const float* const* partial, float* const* dw, float* con
                        const int* cin_off, const int* cin_valid, const int* w_cin_total,
                        const int* splits, int njobs, int cout, int cin, void* stream);
 
-/* Experimental variant (LDS-DMA staging, 1-row tiles, co-resident with conv workgroups); same
- * contract and partial-workspace size as larva_conv3x3_wgrad. */
-int larva_conv3x3_wgrad_dma(const float* const* dy, const float* const* x, float* const* partial,
-                            float* const* dw, float* const* db, const int* cin_off,
-                            const int* cin_valid, const int* w_cin_total, int njobs, int splits,
-                            int N, int cout, int cin, int H, int W, void* stream);
-
 /* ---- base image -----------------------------------------------------------------------------
  * F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False), models/LarvaNet.py:283-285.
  * in [N][C][H][W] -> out [N][C][4H][4W]. */

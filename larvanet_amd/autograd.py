@@ -341,10 +341,6 @@ class DeferredWgrad:
     def _issue(launches):
         """The partial-image launches one after the other, then ONE fixed-order reduction per
         kernel shape over all of them (each layer with its own split count)."""
-        if K._WGRAD_VARIANT == "dma":
-            for cout, cin, chunk in launches:
-                K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
-            return
         reduce_jobs = {}
         for cout, cin, chunk in launches:
             parts, used = K.conv3x3_wgrad_partial(chunk, cout, cin, _splits(len(chunk)))

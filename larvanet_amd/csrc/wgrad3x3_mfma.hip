@@ -15,10 +15,12 @@
 // weight gradient is on the critical path, so the caller queues them and fills the chip with
 // few, long-running workgroups instead of 256 short ones per layer.
 //
-// Staging is through registers on purpose: an LDS-DMA variant with 1-row tiles and a 2-stage ring
-// (wgrad3x3_dma_v2.hip.bak: 86 KiB LDS, fits beside a conv workgroup) measured 127 us per 8-layer
-// batch against 81 us here -- its 3x halo re-read of x (264 MB per batch, far beyond the L2s)
-// makes it bandwidth-bound, this kernel's 3-row tiles re-read 1.67x and stay MFMA-bound (95 %).
+// Two kernels: wgrad3x3_pipe_kernel (48x48 channels on 16-byte aligned tensors: LDS double buffer,
+// the next tile's staging laid out in the MFMA shadows, 12.5 us per tile against 11.1 us for its
+// MFMAs alone = 120 TFLOP/s in the training step) and the generic register-staged wgrad3x3_kernel
+// (every other shape; 16 us per layer at 48x48).  Staging is through registers in both: an LDS-DMA
+// variant with 1-row tiles (tried, removed) re-read the x halo 3x and became bandwidth-bound, and
+// 3-row tiles with the 16-byte channel strides DMA needs do not fit the LDS twice.
 //
 // Roofline: fp32 MFMA, 2*9*Cin*Cout FLOP per pixel (same as the forward conv).
 #include "larva_common.h"

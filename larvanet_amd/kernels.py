@@ -10,7 +10,6 @@ import torch
 from . import hip_lib
 
 _SUPPORTED_COUT = (32, 48, 64)
-_WGRAD_VARIANT = os.environ.get("LARVA_WGRAD", "reg")  # "dma": experimental LDS-DMA variant
 
 
 def _stream():
@@ -195,7 +194,7 @@ def wgrad_partial_floats(cout, cin, splits):
 
 
 def max_wgrad_jobs():
-    return 16 if _WGRAD_VARIANT == "dma" else 64
+    return 64
 
 
 def conv3x3_wgrad(jobs, cout, cin, splits):
@@ -230,8 +229,7 @@ def conv3x3_wgrad(jobs, cout, cin, splits):
         offs.append(off)
         valids.append(valid)
         totals.append(total)
-    fn = lib.larva_conv3x3_wgrad_dma if _WGRAD_VARIANT == "dma" else lib.larva_conv3x3_wgrad
-    code = fn(
+    code = lib.larva_conv3x3_wgrad(
         hip_lib.ptr_array(dys), hip_lib.ptr_array(xs), hip_lib.ptr_array(parts), hip_lib.ptr_array(dws),
         hip_lib.ptr_array(dbs), hip_lib.int_array(offs), hip_lib.int_array(valids), hip_lib.int_array(totals),
         len(jobs), splits, N, cout, cin, H, W, _stream())

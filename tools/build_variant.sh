@@ -7,6 +7,6 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p tools/_diag
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -Ilarvanet_amd/csrc \
-  larvanet_amd/csrc/conv3x3_mfma.hip larvanet_amd/csrc/wgrad3x3_mfma.hip larvanet_amd/csrc/wgrad3x3_dma.hip \
+  larvanet_amd/csrc/conv3x3_mfma.hip larvanet_amd/csrc/wgrad3x3_mfma.hip \
   larvanet_amd/csrc/larva_pointwise.hip -o tools/_diag/$name.so
 echo tools/_diag/$name.so
