@@ -95,13 +95,14 @@ int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* co
                         int N, int cout, int cin, int H, int W, void* stream);
 
 /* The two phases separately: partial images for njobs (<= 64) layers, and the fixed-order
- * reduction of up to 64 layers' partial images (each with its own split count) in one launch. */
+ * reduction of up to 64 layers' partial images (each with its own split count and kernel shape)
+ * in one launch. */
 int larva_conv3x3_wgrad_partial(const float* const* dy, const float* const* x, float* const* partial,
                                 int njobs, int splits, int N, int cout, int cin, int H, int W,
                                 int* splits_used, void* stream);
 int larva_wgrad_reduce(const float* const* partial, float* const* dw, float* const* db,
                        const int* cin_off, const int* cin_valid, const int* w_cin_total,
-                       const int* splits, int njobs, int cout, int cin, void* stream);
+                       const int* splits, const int* cout, const int* cin, int njobs, void* stream);
 
 /* ---- base image -----------------------------------------------------------------------------
  * F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False), models/LarvaNet.py:283-285.

@@ -339,15 +339,14 @@ class DeferredWgrad:
 
     @staticmethod
     def _issue(launches):
-        """The partial-image launches one after the other, then ONE fixed-order reduction per
-        kernel shape over all of them (each layer with its own split count)."""
-        reduce_jobs = {}
+        """The partial-image launches one after the other, then ONE fixed-order reduction over all
+        of them (each layer with its own split count and kernel shape)."""
+        reduce_jobs = []
         for cout, cin, chunk in launches:
             parts, used = K.conv3x3_wgrad_partial(chunk, cout, cin, _splits(len(chunk)))
-            reduce_jobs.setdefault((cout, cin), []).extend(dict(j, partial=p, splits=used) for j, p in zip(chunk, parts))
-        for (cout, cin), jobs in reduce_jobs.items():
-            for i in range(0, len(jobs), 64):
-                K.wgrad_reduce(jobs[i:i + 64], cout, cin)
+            reduce_jobs += [dict(j, partial=p, splits=used, cout=cout, cin=cin) for j, p in zip(chunk, parts)]
+        for i in range(0, len(reduce_jobs), 64):
+            K.wgrad_reduce(reduce_jobs[i:i + 64])
 
     @classmethod
     def flush(cls, split=False):

@@ -619,20 +619,20 @@ struct ReduceJob {
   int cin_valid;         // channels of this job that exist in dw (3 for the head, else CIN)
   int w_cin_total;
   int splits;            // partial images of this job
+  int cout, cin;         // kernel shape of this job (cin = the padded channel count of x)
 };
 
 constexpr int kMaxReduceJobs = 64;
 
 struct ReduceBatch {
   ReduceJob job[kMaxReduceJobs];
-  int cout, cin;  // kernel shape of every job in the batch
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceBatch rb) {
   const ReduceJob& j = rb.job[blockIdx.y];
-  const int ct_n = rb.cout / 16, nb = (rb.cin / 16) * 9;
+  const int ct_n = j.cout / 16, nb = (j.cin / 16) * 9;
   const int n_w = nb * ct_n * 256;
-  const int pf = n_w + rb.cout;  // multiple of 4
+  const int pf = n_w + j.cout;  // multiple of 4
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= pf) return;
   // one 16-byte column of the [splits][pf] partial matrix per thread; 8 independent loads in flight
@@ -749,25 +749,28 @@ int larva_conv3x3_wgrad_partial(const float* const* dy, const float* const* x, f
   return (int)e;
 }
 
-// Phase 2: fixed-order sum of the partial images of njobs (<= 64) same-shape layers -- possibly
-// produced by several phase-1 launches, each with its own split count -- into PyTorch-layout
+// Phase 2: fixed-order sum of the partial images of njobs (<= 64) layers -- possibly produced by
+// several phase-1 launches of different kernel shapes, each layer with its own split count and
+// (cout, cin) -- into PyTorch-layout
 // gradients: dw[i] [cout][w_cin_total[i]][3][3] at input-channel offset cin_off[i] (the first
 // cin_valid[i] channels are written; the rest of `cin` is zero padding of x), db[i] [cout] (may
 // be null).  Gradients are OVERWRITTEN, not accumulated.  One launch: a training step reduces
 // all of its layers at the end of backward instead of once per module.
 int larva_wgrad_reduce(const float* const* partial, float* const* dw, float* const* db,
                        const int* cin_off, const int* cin_valid, const int* w_cin_total,
-                       const int* splits, int njobs, int cout, int cin, void* stream) {
-  if (njobs < 1 || njobs > kMaxReduceJobs || cout % 16 || cin % 16) return (int)hipErrorInvalidValue;
+                       const int* splits, const int* cout, const int* cin, int njobs, void* stream) {
+  if (njobs < 1 || njobs > kMaxReduceJobs) return (int)hipErrorInvalidValue;
   ReduceBatch rb{};
+  int pf_max = 0;
   for (int i = 0; i < njobs; ++i) {
-    if (!partial[i] || !dw[i] || splits[i] < 1) return (int)hipErrorInvalidValue;
+    if (!partial[i] || !dw[i] || splits[i] < 1 || cout[i] <= 0 || cin[i] <= 0 || cout[i] % 16 || cin[i] % 16)
+      return (int)hipErrorInvalidValue;
     rb.job[i] = ReduceJob{partial[i], dw[i], db ? db[i] : nullptr, cin_off[i], cin_valid[i], w_cin_total[i],
-                          splits[i]};
+                          splits[i], cout[i], cin[i]};
+    const int pf = (cin[i] / 16) * 9 * (cout[i] / 16) * 256 + cout[i];
+    pf_max = pf > pf_max ? pf : pf_max;
   }
-  rb.cout = cout; rb.cin = cin;
-  const int pf = (cin / 16) * 9 * (cout / 16) * 256 + cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((pf / 4 + 255) / 256, njobs), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((pf_max / 4 + 255) / 256, njobs), dim3(256), 0, (hipStream_t)stream,
                      rb);
   return (int)hipGetLastError();
 }
@@ -780,9 +783,9 @@ int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* co
   int used = 0;
   int rc = larva_conv3x3_wgrad_partial(dy, x, partial, njobs, splits, N, cout, cin, H, W, &used, stream);
   if (rc) return rc;
-  int sp[kMaxJobs];
-  for (int i = 0; i < njobs; ++i) sp[i] = used;
-  return larva_wgrad_reduce(partial, dw, db, cin_off, cin_valid, w_cin_total, sp, njobs, cout, cin, stream);
+  int sp[kMaxJobs], co[kMaxJobs], ci[kMaxJobs];
+  for (int i = 0; i < njobs; ++i) { sp[i] = used; co[i] = cout; ci[i] = cin; }
+  return larva_wgrad_reduce(partial, dw, db, cin_off, cin_valid, w_cin_total, sp, co, ci, njobs, stream);
 }
 
 }  // extern "C"

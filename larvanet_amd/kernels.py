@@ -257,35 +257,39 @@ def conv3x3_wgrad_partial(jobs, cout, cin, splits):
     return parts, int(used.value)
 
 
-def wgrad_reduce(jobs, cout, cin):
-    """Phase 2: jobs (<= 64 dicts {partial, splits, dw, db (or None), cin_off, cin_valid}) of one
-    kernel shape, reduced in ONE launch; dw/db are overwritten."""
+def wgrad_reduce(jobs, cout=None, cin=None):
+    """Phase 2: jobs (<= 64 dicts {partial, splits, dw, db (or None), cin_off, cin_valid[, cout, cin]})
+    reduced in ONE launch; dw/db are overwritten.  cout/cin: the kernel shape of every job that does
+    not carry its own."""
     lib = hip_lib.load()
     if not 1 <= len(jobs) <= 64:
         raise RuntimeError("larvanet_amd: 1..64 reduce jobs per call")
-    parts, dws, dbs, offs, valids, totals, splits = [], [], [], [], [], [], []
+    parts, dws, dbs, offs, valids, totals, splits, couts, cins = [], [], [], [], [], [], [], [], []
     for j in jobs:
+        co, ci = int(j.get("cout", cout)), int(j.get("cin", cin))
         dw = j["dw"]
         _chk(dw, "dw")
-        if dw.dim() != 4 or int(dw.shape[0]) != cout or tuple(dw.shape[2:]) != (3, 3):
+        if dw.dim() != 4 or int(dw.shape[0]) != co or tuple(dw.shape[2:]) != (3, 3):
             raise RuntimeError("larvanet_amd: dw must be [cout][cin_total][3][3]")
         total = int(dw.shape[1])
         off = int(j.get("cin_off", 0))
-        valid = int(j.get("cin_valid", cin))
-        if off < 0 or valid < 1 or valid > cin or off + valid > total:
+        valid = int(j.get("cin_valid", ci))
+        if off < 0 or valid < 1 or valid > ci or off + valid > total:
             raise RuntimeError("larvanet_amd: wgrad channel slice out of range")
         sp = int(j["splits"])
-        parts.append(_chk(j["partial"], "partial", (wgrad_partial_floats(cout, cin, sp),)))
+        parts.append(_chk(j["partial"], "partial", (wgrad_partial_floats(co, ci, sp),)))
         dws.append(dw.data_ptr())
-        dbs.append(_opt(j.get("db"), "db", (cout,)))
+        dbs.append(_opt(j.get("db"), "db", (co,)))
         offs.append(off)
         valids.append(valid)
         totals.append(total)
         splits.append(sp)
+        couts.append(co)
+        cins.append(ci)
     code = lib.larva_wgrad_reduce(
         hip_lib.ptr_array(parts), hip_lib.ptr_array(dws), hip_lib.ptr_array(dbs), hip_lib.int_array(offs),
-        hip_lib.int_array(valids), hip_lib.int_array(totals), hip_lib.int_array(splits), len(jobs), cout, cin,
-        _stream())
+        hip_lib.int_array(valids), hip_lib.int_array(totals), hip_lib.int_array(splits), hip_lib.int_array(couts),
+        hip_lib.int_array(cins), len(jobs), _stream())
     hip_lib.check(code, "larva_wgrad_reduce")
 
 
