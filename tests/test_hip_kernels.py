@@ -514,3 +514,83 @@ def test_conv3x3_full_image_against_torch_cpu(hip_device):
     assert float((plain.cpu() - ref).abs().max()) / scale < 1e-5
     assert float((pitched.cpu()[..., :510] - ref).abs().max()) / scale < 1e-5
     assert not pitched.cpu()[..., 510:].any()
+
+
+def test_conv3x3_seeded_shape_fuzz(hip_device):
+    """40 seeded random problems through the conv entry point: batch, height, width (aligned and
+    not), 1..3 channel-concatenated sources of 8..48 channels, every epilogue, single and batched
+    launches -- against the C oracle.  Guards the staging paths (buffer-descriptor LDS-DMA with
+    zero fill by range check, loader wave, register staging) at shapes the fixed cases do not hit."""
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(20261003)
+    for case in range(40):
+        N = int(rng.integers(1, 4))
+        H = int(rng.integers(1, 23))
+        W = int(rng.choice([4, 8, 16, 20, 44, 48, 52, 96, 100, int(rng.integers(1, 70))]))
+        nsrc = int(rng.integers(1, 4))
+        cps = int(rng.choice([8, 16, 24, 48]))
+        cout = int(rng.choice([32, 48, 64])) if case % 4 == 0 else 48
+        epi = ["plain", "relu", "res1", "res2", "mask", "shuffle", "shuffle_base"][case % 7]
+        srcs = [_rand(rng, (N, cps, H, W), 10.0) for _ in range(nsrc)]
+        w = _rand(rng, (cout, cps * nsrc, 3, 3), 0.05)
+        b = _rand(rng, (cout,), 1.0)
+        ref = R.conv3x3(np.concatenate(srcs, axis=1), w, b)
+        kw = {}
+        r0, r1, m = (_rand(rng, ref.shape, 5.0) for _ in range(3))
+        if epi == "relu":
+            ref, kw["relu"] = np.maximum(ref, 0), True
+        elif epi == "res1":
+            ref, kw["res0"] = ref + r0, _dev(r0, hip_device)
+        elif epi == "res2":
+            ref = (ref + r0) + r1
+            kw["res0"], kw["res1"] = _dev(r0, hip_device), _dev(r1, hip_device)
+        elif epi == "mask":
+            ref, kw["mask"] = np.where(m > 0, ref, 0).astype(np.float32), _dev(m, hip_device)
+        elif epi.startswith("shuffle"):
+            ref, kw["shuffle"] = R.pixel_shuffle(ref, 4), True
+            if epi == "shuffle_base":
+                base = _rand(rng, ref.shape, 50.0)
+                ref, kw["base"] = ref + base, _dev(base, hip_device)
+        fwd, _ = K.pack_weights(_dev(w, hip_device))
+        dsrcs = [_dev(s, hip_device) for s in srcs]
+        out = K.conv3x3(dsrcs, fwd, cout, bias=_dev(b, hip_device), **kw)
+        torch.cuda.synchronize()
+        tag = "case %d N%d H%d W%d %dx%d->%d %s" % (case, N, H, W, nsrc, cps, cout, epi)
+        _report(tag, out.cpu().numpy(), ref, 3e-5)
+        if case % 3 == 0:  # the same problem twice in one batched launch
+            job = dict(srcs=dsrcs, wpk=fwd, bias=_dev(b, hip_device),
+                       **{k: v for k, v in kw.items() if k in ("res0", "res1", "mask", "base")})
+            o2 = K.conv3x3_batch([job, dict(job)], cout, relu=kw.get("relu", False), shuffle=kw.get("shuffle", False))
+            assert torch.equal(o2[0], out) and torch.equal(o2[1], out), tag
+
+
+def test_wgrad_seeded_shape_fuzz(hip_device):
+    """20 seeded random weight-gradient problems (batch, height, width aligned and not, 1..5 layers
+    per launch, split counts from 1 to more than there are tiles, 48x48 / 32x32 / 48x16 channels)
+    against the C oracle: both the pipelined kernel and the register-staged one."""
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(77001)
+    for case in range(20):
+        N = int(rng.integers(1, 4))
+        H = int(rng.integers(1, 20))
+        W = int(rng.choice([4, 16, 48, 52, 96, int(rng.integers(1, 60))]))
+        cout, cin, valid = [(48, 48, 48), (48, 48, 48), (32, 32, 32), (48, 16, 3)][case % 4]
+        njobs = int(rng.integers(1, 6))
+        splits = int(rng.choice([1, 2, 5, 16, 400]))
+        jobs, refs = [], []
+        for _ in range(njobs):
+            dy = _rand(rng, (N, cout, H, W), 1e-2)
+            x = np.zeros((N, cin, H, W), np.float32)
+            x[:, :valid] = _rand(rng, (N, valid, H, W), 10.0)
+            refs.append(R.conv3x3_wgrad(dy, x[:, :valid]))
+            jobs.append({"dy": _dev(dy, hip_device), "x": _dev(x, hip_device),
+                         "dw": torch.empty((cout, valid, 3, 3), device=hip_device),
+                         "db": torch.empty(cout, device=hip_device), "cin_valid": valid})
+        K.conv3x3_wgrad(jobs, cout, cin, splits)
+        torch.cuda.synchronize()
+        for i, (j, (dw_ref, db_ref)) in enumerate(zip(jobs, refs)):
+            tag = "case %d job %d N%d H%d W%d %dx%d splits %d" % (case, i, N, H, W, cout, cin, splits)
+            _report(tag + " dw", j["dw"].cpu().numpy(), dw_ref, 5e-5)
+            _report(tag + " db", j["db"].cpu().numpy(), db_ref, 5e-5)
