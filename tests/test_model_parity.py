@@ -350,3 +350,42 @@ def test_row_bands_with_receptive_halo_reproduce_the_full_image(hip_device, name
                             for r0, r1 in image_utils.band_rows(img.shape[1], world)], axis=1)
     assert not np.array_equal(short, full)  # the halo is tight
     assert image_utils.band_rows(5, 8)[0] == (0, 0) and image_utils.band_rows(5, 8)[-1] == (4, 5)
+
+
+def test_forward_and_train_step_shape_fuzz_against_the_cpu_restatement(hip_device):
+    """Seeded random network configurations (1..4 bodies of 1..3 blocks, V1 and V2) and image
+    sizes (aligned and odd): inference forward and one training step's loss and gradients against
+    oracle/larva_torch.py (the reference's own torch operators on the CPU) with the same weights."""
+    from oracle import larva_torch as T
+    rng = np.random.RandomState(4242)
+    for case in range(6):
+        M = int(rng.randint(1, 5))
+        blocks = [int(rng.randint(1, 4)) for _ in range(M)]
+        v2 = case % 3 == 2
+        name = "LarvaNetV2" if v2 else "LarvaNet"
+        flags = ["--num_modules=%d" % M, "--num_blocks=%s" % ",".join(map(str, blocks))]
+        m = _model(name, flags, training=True, seed=100 + case)
+        sd = {k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()}
+        # inference on an odd-sized image
+        h, w = int(rng.randint(5, 30)), int(rng.randint(5, 40))
+        img = rng.randint(0, 256, size=(3, h, w)).astype(np.float32)
+        got = m.upscale([img], 4)[0]
+        with torch.no_grad():
+            xt = torch.from_numpy(img)[None]
+            ref = (T.forward_v2(sd, xt, blocks) if v2 else T.forward(sd, xt, blocks))[0].numpy()
+        assert np.abs(got - ref).max() <= 2e-3, (case, name, blocks, h, w, float(np.abs(got - ref).max()))
+        # one training step: loss and gradients
+        n, p = int(rng.randint(1, 4)), 4 * int(rng.randint(2, 5))
+        x = torch.from_numpy(rng.randint(0, 256, size=(n, 3, p, p)).astype(np.float32))
+        t = torch.from_numpy(rng.randint(0, 256, size=(n, 3, 4 * p, 4 * p)).astype(np.float32))
+        m.use_hip_graph = False
+        loss, _ = m._forward_backward(x.to(hip_device), t.to(hip_device))
+        torch.cuda.synchronize()
+        sd_req = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref_loss = T.multi_exit_loss(sd_req, x, t, blocks, v2=v2)
+        ref_loss.backward()
+        ref_value = float(ref_loss.detach())
+        assert abs(float(loss.detach()) - ref_value) <= 2e-5 * abs(ref_value), (case, float(loss.detach()), ref_value)
+        for k, prm in m.model.named_parameters():
+            ga, gb = prm.grad.cpu().numpy(), sd_req[k].grad.numpy()
+            assert np.abs(ga - gb).max() <= 2e-4 * max(np.abs(gb).max(), 1e-30), (case, name, blocks, k)
