@@ -36,6 +36,9 @@
 #ifndef WG_DIAG
 #define WG_DIAG 0
 #endif
+#ifndef WG_ASM_MFMA
+#define WG_ASM_MFMA 1   // 1: the pipelined kernel's MFMAs are inline asm with the accumulator tied in an AGPR
+#endif
 
 
 namespace larva {
@@ -404,6 +407,7 @@ struct PipeCtx {
   float (&bv)[2][NBW];
   f32x4 (&acc)[COUT / 16][NBW];
   f32x4 (&bacc)[COUT / 16];   // BIAS wave: rows = co, every column = sum over pixels of dy
+  float one;                   // 1.0f in a VGPR (B operand of the bias MFMAs in the asm form)
 };
 
 // k-step KS of the pipelined tile loop: one scheduling region holding the step's MFMAs, the
@@ -414,7 +418,7 @@ struct PipeCtx {
 // too: CT extra MFMAs per k-step against an all-ones B operand, so that no wave issues VALU adds
 // and all four carry the same number of MFMAs.
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS>
-__device__ __forceinline__ void pipe_kstep(PipeCtx<COUT, CIN, NBW>& x) {
+__device__ __forceinline__ void pipe_kstep_builtin(PipeCtx<COUT, CIN, NBW>& x) {
   using C = WgCfg<COUT, CIN>;
   using P = WgPipe<COUT, CIN>;
   __builtin_amdgcn_sched_barrier(0);
@@ -463,6 +467,67 @@ __device__ __forceinline__ void pipe_kstep(PipeCtx<COUT, CIN, NBW>& x) {
     else if (m == 16 + WV) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
+}
+
+// The same k-step with the MFMAs as inline asm, accumulator tied to one AGPR quad ("+a").  With the
+// builtin the register allocator carries the loop's accumulators partly in VGPRs across the tile
+// loop's edge and shuttles ~190 of them per tile through v_accvgpr_read / v_accvgpr_write (the
+// MFMAs then read one AGPR quad and write another); tied operands leave it no such choice.  Asm
+// statements keep their order, so the layout is spelled out gap by gap instead of through
+// sched_group_barrier: gap m = MFMA m + its filler, pinned by a sched_barrier.
+__device__ __forceinline__ void mfma_tied(f32x4& acc, float a, float b) {
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS, int M>
+__device__ __forceinline__ void pipe_gap_asm(PipeCtx<COUT, CIN, NBW>& x, int& gy, int& gx, uint64_t& addr) {
+  using C = WgCfg<COUT, CIN>;
+  using P = WgPipe<COUT, CIN>;
+  constexpr int NMAIN = C::CT * NBW;
+  if constexpr (M < NMAIN) {
+    mfma_tied(x.acc[M / NBW][M % NBW], x.av[KS & 1][M / NBW], x.bv[KS & 1][M % NBW]);
+  } else {
+    mfma_tied(x.bacc[M - NMAIN], x.av[KS & 1][M - NMAIN], x.one);
+  }
+  // fillers: operand reads of the next k-step in the first gaps, then the staging slot
+  constexpr int G0 = C::CT + NBW;
+  if constexpr (KS + 1 < 36 && M < G0) {
+    constexpr int ks = KS + 1, row = ks / 12, col = 4 * (ks % 12);
+    if constexpr (M < C::CT) {
+      x.av[ks & 1][M] = x.a_base[M * 16 * C::PSD + row * kTileCols + col];
+    } else {
+      constexpr int bi = B0 + (M - C::CT), cit = bi / 9, tap = bi % 9, ky = tap / 3, kx = tap % 3;
+      x.bv[ks & 1][M - C::CT] = x.b_base[cit * 16 * C::PSX + (row + ky) * kRS + col + kx];
+    }
+  }
+  if constexpr (KS < P::NSLOT) {
+    if constexpr (M == G0) pipe_addr_a<COUT, CIN, KS>(x.g, x.next, gy, gx);
+    if constexpr (M == G0 + 1) addr = pipe_addr_b<COUT, CIN, KS>(x.g, x.next, x.b, gy, gx);
+    if constexpr (M == G0 + 2 + (WV & 1)) x.stage[KS] = *reinterpret_cast<const f32x4*>(addr);
+  }
+  constexpr bool kWrites = KS >= P::LAG && KS - P::LAG < P::NSLOT;
+  if constexpr (kWrites && M == G0 + 4 + WV) pipe_lds_write<COUT, CIN, KS - P::LAG>(x.g, x.nxt, x.stage[KS - P::LAG]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS, int M>
+__device__ __forceinline__ void pipe_gaps_asm(PipeCtx<COUT, CIN, NBW>& x, int& gy, int& gx, uint64_t& addr) {
+  if constexpr (M < (COUT / 16) * NBW + (BIAS ? COUT / 16 : 0)) {
+    pipe_gap_asm<COUT, CIN, B0, NBW, BIAS, WV, KS, M>(x, gy, gx, addr);
+    pipe_gaps_asm<COUT, CIN, B0, NBW, BIAS, WV, KS, M + 1>(x, gy, gx, addr);
+  }
+}
+
+template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS>
+__device__ __forceinline__ void pipe_kstep(PipeCtx<COUT, CIN, NBW>& x) {
+  if constexpr (WG_ASM_MFMA && !WG_DIAG) {
+    int gy = 0, gx = 0;
+    uint64_t addr = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    pipe_gaps_asm<COUT, CIN, B0, NBW, BIAS, WV, KS, 0>(x, gy, gx, addr);
+  } else {
+    pipe_kstep_builtin<COUT, CIN, B0, NBW, BIAS, WV, KS>(x);
+  }
 }
 
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS>
@@ -527,6 +592,8 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob
 
   f32x4 stage[P::NSLOT];
   float av[2][C::CT], bv[2][NBW];
+  float one = 1.0f;
+  asm volatile("" : "+v"(one));  // keep it in a register: the asm MFMA takes no literal
   int par = 0;
   for (int t = t_begin; t < t_end; ++t) {
     // the next tile (the last tile stages itself once more into the idle buffer: keeps the loop
@@ -542,7 +609,7 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob
     }
     float* cur = smem + par * P::BUF_FLOATS;
     PipeCtx<COUT, CIN, NBW> x{b, geom, tile_at(), cur + lr * C::PSD + lq, cur + C::DY_FLOATS + lr * C::PSX + lq + 3,
-                              smem + (par ^ 1) * P::BUF_FLOATS, stage, av, bv, acc, bacc};
+                              smem + (par ^ 1) * P::BUF_FLOATS, stage, av, bv, acc, bacc, one};
     wg_read<COUT, CIN, B0, NBW>(x.a_base, x.b_base, 0, av[0], bv[0]);
     __builtin_amdgcn_sched_barrier(0);
     pipe_ksteps<COUT, CIN, B0, NBW, BIAS, WV, 0>(x);
@@ -558,6 +625,8 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob
     par ^= 1;
   }
 
+  // (the compiler does not see the asm MFMAs: cover their write-back before the accumulators are read)
+  if constexpr (WG_ASM_MFMA && !WG_DIAG) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   float* part = j.partial + (size_t)split * C::PARTIAL_FLOATS;
 #pragma unroll
   for (int c = 0; c < C::CT; ++c)
