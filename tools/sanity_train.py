@@ -20,8 +20,8 @@ class Val:
         return lr[0].cpu().numpy(), hr[0].cpu().numpy(), "v"
 args = types.SimpleNamespace(train_path="/tmp")
 losses = []
-for i in range(400):
+for i in range(int(os.environ.get("STEPS", "400"))):
     losses.append(m.train_step_larva(args, Val(), lr, hr))
-print("loss step 1 %.4f, 50 %.4f, 100 %.4f, 200 %.4f, 400 %.4f" % (losses[0], losses[49], losses[99], losses[199], losses[399]))
-assert all(np.isfinite(losses)) and losses[399] < 0.5 * losses[0], "training does not converge"
+print("loss step 1 %.4f, 50 %.4f, 100 %.4f, 200 %.4f, last %.4f" % (losses[0], losses[49], losses[99], losses[199], losses[-1]))
+assert all(np.isfinite(losses)) and losses[-1] < 0.5 * losses[0], "training does not converge"
 print("graph in use:", m.use_hip_graph, " psnr of the fit:", m.validate_for_train(args, Val()))
