@@ -234,6 +234,9 @@ def main():
         print(json.dumps({"roofline": roofline_block(dev)}))
         return
 
+    # stdout carries exactly ONE line, the JSON; the plugin's progress prints go to stderr
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr
     import importlib
     model = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
     model.parse_args(["--num_modules=4", "--num_blocks=4,4,4,4"])
@@ -308,6 +311,7 @@ def main():
     }
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
+    sys.stdout = real_stdout
     print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as td
