@@ -2,7 +2,11 @@
 """Headline benchmark: HR Mpixels/s of the LarvaNet x4 multi-exit TRAINING step on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+N > 1 works both ways: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or as a plain
+`python bench.py --gpus N`: the parent then starts one child process per GPU itself -- before it
+has touched the GPU in any way -- relays rank 0's JSON line and exits non-zero if a rank fails.
 
 A step = one pass of the hot path over one synthetic batch per GPU: head conv, 4 bodies x 4
 residual blocks, 4 pixel-shuffle exits, 4 L1 losses, full backward (dgrad + wgrad + bias grads),
@@ -10,17 +14,28 @@ gradient all-reduce over RCCL when N > 1, AdamW -- i.e. train_step_larva (models
 of the reference) at the BASELINE configuration: 16 x 3 x 48 x 48 fp32 patches per GPU -> 16 x 3 x
 192 x 192, `--num_modules=4 --num_blocks=4,4,4,4`, 48 channels (the only channel count the
 reference can express).  value = N * 16 * 192 * 192 / t_step (pixels counted once).
+The K-step loop is timed --rounds times (barrier + synchronize on both sides of each); value and
+ms_per_step are the MEDIAN round, min / max are reported beside it.
 
 The JSON line also carries
-  roofline      fp32-MFMA roofline of the dominant kernel (fused conv3x3+ReLU, 48->48, 16x48x48),
-                timed live with events on the launch stream
-  cpu_baseline  the same training step in the torch CPU restatement (oracle/, kind "port") on the
-                host cores of this box, bounded sample
-  infer         inference-forward throughput (LarvaNetModule.forward) as extra information
+  roofline            fp32-MFMA roofline of the dominant kernel (fused conv3x3+ReLU, 48->48,
+                      16x48x48), timed live with events on the launch stream (in-graph chain)
+  roofline_c32/_c64   the same kernel at 32 and 64 channels (BASELINE configs 2 and 5)
+  roofline_wgrad      the weight-gradient launch as the step issues it
+  cpu_baseline        the same training step in the torch CPU restatement (oracle/, kind "port") on
+                      the host cores of this box, bounded sample
+  infer               inference-forward throughput (LarvaNetModule.forward) on the batch
+  infer_full_image    V1 and V2 on one 3 x 339 x 510 image (BASELINE config 5 at N = 1)
+  value_sync_loss     the same loop with the reference's per-step behaviour: fresh input tensors
+                      copied into the step and loss.item() (a host sync) every step
+  rccl_ranks, allreduce_exposed_us   N > 1: ranks in the RCCL communicator and the event-timed gap
+                      per step between the last weight-gradient kernel and the optimizer
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -29,19 +44,77 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
+# dmabuf IPC for RCCL: in the environment before the HIP runtime comes up (children inherit it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 BATCH, PATCH, SCALE, CH = 16, 48, 4, 48
 BLOCKS = [4, 4, 4, 4]
+FLAGS = ["--num_modules=4", "--num_blocks=4,4,4,4"]
 HR_PIX_PER_BATCH = BATCH * (PATCH * SCALE) ** 2          # 589 824
-CONV_FLOP = 2 * 9 * CH * CH * BATCH * PATCH * PATCH      # 1.5288 GFLOP per 48->48 layer
 FP32_MFMA_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: Peak FP32 (matrix)
-# HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per
-# the guide's gfx950 correction + WRITE_SIZE), see profiles/README.md; None until measured.
-HBM_TRAFFIC_PER_LAUNCH = (2 * 3919.0 + 7149.6) * 1024   # profiles/r01_h_pmc_conv3x3_relu_final.csv (KB)
+FULL_IMAGE = (3, 339, 510)                               # DIV2K-val-like LR image
+# HBM bytes per launch of the dominant kernel: NOT measured by this run (counters need rocprofv3);
+# taken from the committed PMC passes -- FETCH_SIZE doubled per the guide's gfx950 correction +
+# WRITE_SIZE, both in KB.  roofline.traffic_source names the file.
+HBM_TRAFFIC_PER_LAUNCH = (2 * 3919.0 + 7149.6) * 1024
+HBM_TRAFFIC_SOURCE = "profiles/r01_h_pmc_conv3x3_relu_final.csv (rocprofv3 --pmc passes; constant, not measured by this run)"
 
 
+def conv_flop(c):
+    return 2 * 9 * c * c * BATCH * PATCH * PATCH         # 1.5288 GFLOP per 48->48 layer
+
+
+# ------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """Start one child per rank (this process never touches the GPU), relay rank 0's stdout (the
+    JSON line), fail if any rank fails.  Children are this same script under RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT, i.e. exactly what torch.distributed.run would set."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        # (rank 0 writes one short line: its pipe cannot fill up while we wait)
+        time.sleep(0.2)
+    for r, p in enumerate(procs):
+        if failed is None and p.returncode != 0:
+            failed = (r, p.returncode)
+    if failed is not None:
+        for p in procs:          # the exact children started above, nothing else
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write("bench.py: rank %d exited with code %s\n" % failed)
+        return 1
+    out = procs[0].stdout.read().decode()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return 0 if out.strip() else 1
+
+
+# ------------------------------------------------------------------------------------------------
 class TinyValLoader:
     """train_step_larva validates once at global_step == 1 (models/LarvaNet.py:116-117); that
     happens inside the warm-up steps.  One small synthetic pair is enough."""
@@ -50,23 +123,63 @@ class TinyValLoader:
         return 1
 
     def get_image_pair(self, image_index, scale):
+        import numpy as np
         rng = np.random.RandomState(3)
         return (rng.randint(0, 256, (3, 24, 24)).astype(np.float32),
                 rng.randint(0, 256, (3, 96, 96)).astype(np.float32), "synthetic")
 
 
 def barrier_sync(dist_on):
+    import torch
     import torch.distributed as td
     if dist_on:
         td.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def chain_time_ms(dev, c, chain=40, reps=10):
+    """The fused conv3x3+ReLU kernel the way it runs inside the training step: a captured chain of
+    `chain` dependent launches (each reads the previous one's output), replayed back to back, timed
+    by a HIP event pair on the launch stream; per launch = replay time / chain."""
+    import torch
+    from larvanet_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(BATCH, c, PATCH, PATCH, generator=g) * 20).to(dev)
+    w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.zeros(c, device=dev)
+    fwd, _ = K.pack_weights(w)
+    bufs = [x.clone() * 0.0 + 1.0, torch.empty_like(x)]
+    wsmall = fwd * 0.05  # keeps the activations finite down the chain
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        K.conv3x3(bufs[0], wsmall, c, bias=b, relu=True, out=bufs[1])
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        for i in range(chain):
+            K.conv3x3(bufs[i & 1], wsmall, c, bias=b, relu=True, out=bufs[(i + 1) & 1])
+    graph.replay()
     torch.cuda.synchronize()
+    best = []
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            graph.replay()
+        e.record()
+        torch.cuda.synchronize()
+        best.append(s.elapsed_time(e) / (reps * chain))
+    return sorted(best)[1]
 
 
 def time_dominant_kernel(dev, iters=50):
-    """Duration of the fused conv3x3+ReLU kernel at 16x48x48x48 on the launch stream, two ways:
-    kernel-attached HIP events (hipExtLaunchKernelGGL start/stop = the kernel's own begin/end, what
-    rocprofv3 --kernel-trace reports) and a plain event pair around each launch (includes the
-    launch gap).  roofline.achieved uses the former."""
+    """Isolated launches of the same kernel, two ways: kernel-attached HIP events
+    (hipExtLaunchKernelGGL start/stop = the kernel's own begin/end) and a plain event pair around
+    each launch (includes the launch gap).  Extra information beside the in-graph chain."""
+    import numpy as np
+    import torch
     from larvanet_amd import kernels as K
     g = torch.Generator().manual_seed(5)
     x = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 20).to(dev)
@@ -85,50 +198,36 @@ def time_dominant_kernel(dev, iters=50):
         e.record()
     torch.cuda.synchronize()
     pair = sorted(s.elapsed_time(e) for s, e in evs)
-    # ... and the way the kernel runs inside the training step: a captured chain of dependent launches
-    # (each reads the previous one's output), back to back; time per launch = replay time / length.
-    chain, reps = 40, 10
-    bufs = [x.clone() * 0.0 + 1.0, torch.empty_like(x)]
-    wsmall = fwd * 0.05  # keeps the activations finite down the chain
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        K.conv3x3(bufs[0], wsmall, CH, bias=b, relu=True, out=bufs[1])
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-        for i in range(chain):
-            K.conv3x3(bufs[i & 1], wsmall, CH, bias=b, relu=True, out=bufs[(i + 1) & 1])
-    graph.replay()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(reps):
-        graph.replay()
-    e.record()
-    torch.cuda.synchronize()
-    in_graph = s.elapsed_time(e) / (reps * chain)
-    return k_mean, k_min, float(np.mean(pair)), in_graph
+    return k_mean, k_min, float(np.mean(pair))
 
 
-def roofline_block(dev):
-    k_mean_ms, k_min_ms, pair_ms, graph_ms = time_dominant_kernel(dev)
+def roofline_block(dev, c=CH, full=True):
+    graph_ms = chain_time_ms(dev, c)
     # priced on the in-graph time per launch (what the step pays, boundaries included), which is
     # also what rocprofv3 reports for this kernel inside the captured step
-    achieved = CONV_FLOP / (graph_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": HBM_TRAFFIC_PER_LAUNCH,
-            "kernel": "conv3x3_mfma_kernel<48, true, 1> (fused conv3x3+bias+ReLU), 16x48x48x48 fp32",
-            "flop_per_launch": CONV_FLOP, "avg_ms": graph_ms,
-            "timing": "HIP event pair around 10 replays of a captured chain of 40 dependent launches, per launch",
-            "isolated_kernel_attached_ms": k_mean_ms, "isolated_min_ms": k_min_ms,
-            "event_pair_ms_incl_launch_gap": pair_ms,
-            "algorithmic_bytes_per_launch": 2 * BATCH * CH * PATCH * PATCH * 4 + 4 * (9 * CH * CH + CH)}
+    flop = conv_flop(c)
+    achieved = flop / (graph_ms * 1e-3) / 1e12
+    blk = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+           "traffic": HBM_TRAFFIC_PER_LAUNCH if c == CH else None,
+           "kernel": "conv3x3_mfma_kernel<%d, true, 1> (fused conv3x3+bias+ReLU), 16x%dx48x48 fp32" % (c, c),
+           "flop_per_launch": flop, "avg_ms": graph_ms,
+           "timing": "HIP event pair around 10 replays of a captured chain of 40 dependent launches, per launch "
+                     "(median of 3)",
+           "algorithmic_bytes_per_launch": 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c)}
+    if c == CH:
+        blk["traffic_source"] = HBM_TRAFFIC_SOURCE
+    if full:
+        k_mean_ms, k_min_ms, pair_ms = time_dominant_kernel(dev)
+        blk.update({"isolated_kernel_attached_ms": k_mean_ms, "isolated_min_ms": k_min_ms,
+                    "event_pair_ms_incl_launch_gap": pair_ms})
+    return blk
 
 
 def wgrad_block(dev, jobs=32, iters=20):
     """Second kernel of the step (28 % of it): the weight-gradient launch as the step issues it
     (32 layers x 8 workgroups, partial images + fixed-order reduction), timed with an event pair."""
+    import torch
     from larvanet_amd import kernels as K
     g = torch.Generator().manual_seed(6)
     dy = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 1e-3).to(dev)
@@ -148,11 +247,11 @@ def wgrad_block(dev, jobs=32, iters=20):
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / iters
-    achieved = CONV_FLOP * jobs / (ms * 1e-3) / 1e12
+    achieved = conv_flop(CH) * jobs / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "kernel": "wgrad3x3_pipe_kernel<48, 48> + wgrad_reduce_kernel, "
             "%d layers x %d workgroups, 16x48x48x48 fp32" % (jobs, 256 // jobs), "ms_per_launch_pair": ms,
-            "flop_per_layer": CONV_FLOP}
+            "flop_per_layer": conv_flop(CH)}
 
 
 def host_cores():
@@ -181,6 +280,8 @@ def host_cores():
 
 def cpu_baseline(budget_s=15.0):
     """The reference CPU path (torch CPU operators, all host cores) on the same workload."""
+    import numpy as np
+    import torch
     from oracle import larva_torch as T
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -210,87 +311,169 @@ def cpu_baseline(budget_s=15.0):
                       % (len(times), med * 1e3, torch.__version__, cores)}
 
 
+def full_image_block(dev):
+    """BASELINE config 5 at N = 1: whole-network inference of one 3 x 339 x 510 LR image (x4 ->
+    1356 x 2040), V1 and V2, device tensor in, device tensor out (upscale()'s H2D / D2H copies of
+    the reference API are not in the timed region)."""
+    import importlib
+    import torch
+    out = {"lr_image": list(FULL_IMAGE), "hr_pixels": 16 * FULL_IMAGE[1] * FULL_IMAGE[2]}
+    x = (torch.rand(1, *FULL_IMAGE, generator=torch.Generator().manual_seed(2)) * 255).to(dev)
+    for name in ("LarvaNet", "LarvaNetV2"):
+        m = importlib.import_module("larvanet_amd.models." + name).create_model()
+        m.parse_args(list(FLAGS))
+        torch.manual_seed(0)
+        m.prepare(is_training=False, scales=[SCALE])
+        with torch.no_grad():
+            for _ in range(3):
+                m.model(x)
+            torch.cuda.synchronize()
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                m.model(x)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+        out[name] = {"ms_per_image": ms, "value": out["hr_pixels"] / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s"}
+        del m
+    return out
+
+
+def timed_rounds(model, args, val, x, truth, steps, rounds, dist_on):
+    """`rounds` x (barrier + sync, `steps` steps, barrier + sync) -> seconds per round, max over ranks."""
+    import torch
+    import torch.distributed as td
+    secs = []
+    loss = None
+    for _ in range(rounds):
+        barrier_sync(dist_on)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = model.train_step_larva(args, val, x, truth)
+        barrier_sync(dist_on)
+        secs.append(time.perf_counter() - t0)
+    if dist_on:
+        t = torch.tensor(secs, dtype=torch.float64, device=model.device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        secs = [float(v) for v in t.cpu()]
+    return secs, loss
+
+
+def dry_run(a, rank, world, emit):
+    """LARVA_BENCH_DRY=1: the launcher / rendezvous / collective / JSON plumbing of a multi-rank run
+    with NO kernels (CPU, gloo) -- what the CPU tests drive with 2 and 8 ranks.  Not a measurement."""
+    import torch
+    import torch.distributed as td
+    if os.environ.get("LARVA_BENCH_DRY_FAIL_RANK") == str(rank):   # test hook: a rank that dies
+        sys.exit(7)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        td.barrier()
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+    if rank == 0:
+        emit({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+              "max_rank_plus_1": float(t.item()), "backend": td.get_backend() if world > 1 else None})
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rounds", type=int, default=5, help="the --steps loop is timed this many times; value = median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only time the dominant kernel (short run for rocprofv3 --pmc passes)")
     ap.add_argument("--sync-loss", action="store_true",
                     help="return loss.item() every step like the reference (host sync per step)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher BEFORE anything touches the GPU
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+
+    # stdout carries exactly ONE line, the JSON: everything else any library prints there -- the
+    # plugin's progress lines, Gloo's / RCCL's C-level connection messages -- goes to stderr (fd level)
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
+    import numpy as np
+    import torch
     from larvanet_amd import dist as ldist
-    rank, world = ldist.init_from_env()
+    dry = os.environ.get("LARVA_BENCH_DRY", "0") != "0"
+    rank, world = ldist.init_from_env(backend="gloo" if dry else None)
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % a.gpus)
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE is %d" % (a.gpus, world))
+    if dry:
+        return dry_run(a, rank, world, emit)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
     dev = torch.device("cuda", torch.cuda.current_device())
     if a.roofline_only:
-        print(json.dumps({"roofline": roofline_block(dev)}))
+        emit({"roofline": roofline_block(dev)})
         return
 
-    # stdout carries exactly ONE line, the JSON; the plugin's progress prints go to stderr
-    real_stdout = sys.stdout
-    sys.stdout = sys.stderr
     import importlib
+    import torch.distributed as td
     model = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
-    model.parse_args(["--num_modules=4", "--num_blocks=4,4,4,4"])
+    model.parse_args(list(FLAGS))
     torch.manual_seed(0)
     model.volume_per_step = PATCH * PATCH * BATCH * 3 * world
     model.prepare(is_training=True, scales=[SCALE])
     model.sync_loss = bool(a.sync_loss)
+    model.time_allreduce = world > 1
 
     g = torch.Generator().manual_seed(1000 + rank)
-    x = (torch.rand(BATCH, 3, PATCH, PATCH, generator=g) * 255).to(dev)
-    truth = (torch.rand(BATCH, 3, PATCH * SCALE, PATCH * SCALE, generator=g) * 255).to(dev)
+    x_fresh = (torch.rand(BATCH, 3, PATCH, PATCH, generator=g) * 255).to(dev)
+    truth_fresh = (torch.rand(BATCH, 3, PATCH * SCALE, PATCH * SCALE, generator=g) * 255).to(dev)
     args = types.SimpleNamespace(train_path="/tmp")
     val = TinyValLoader()
 
     for _ in range(max(a.warmup, 1)):
-        model.train_step_larva(args, val, x, truth)
+        model.train_step_larva(args, val, x_fresh, truth_fresh)
+    if model.hip_graph_fell_back:
+        # a 2.4x slower step must not pass for the captured one
+        sys.stderr.write("bench.py: hipGraph capture failed (%s)\n" % model.hip_graph_fell_back)
+        sys.exit(3)
     # the batch sits where a device-side producer (dataloaders/device_patch_loader, `out=`) puts it:
     # in the input buffers of the captured step, so the step does not copy it again
+    x, truth = x_fresh, truth_fresh
     bufs = model.input_buffers(x.shape, truth.shape)
     if bufs is not None:
         bufs[0].copy_(x)
         bufs[1].copy_(truth)
         x, truth = bufs
-    barrier_sync(world > 1)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = model.train_step_larva(args, val, x, truth)
-    barrier_sync(world > 1)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as td
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / a.steps * 1e3
+    if hasattr(model, "allreduce_events"):
+        model.allreduce_events.clear()
+    rounds = max(1, a.rounds)
+    secs, loss = timed_rounds(model, args, val, x, truth, a.steps, rounds, world > 1)
+    per_step = sorted(s / a.steps * 1e3 for s in secs)
+    ms_per_step = float(np.median(per_step))
     value = world * HR_PIX_PER_BATCH / (ms_per_step * 1e-3) / 1e6
+    final_loss = float(loss)
+    exposed = None
+    if world > 1 and getattr(model, "allreduce_events", None):
+        torch.cuda.synchronize()
+        gaps = sorted(s.elapsed_time(e) * 1e3 for s, e in model.allreduce_events)
+        exposed = {"median": gaps[len(gaps) // 2], "min": gaps[0], "max": gaps[-1], "steps": len(gaps),
+                   "definition": "HIP events on the compute stream: after the last weight-gradient kernel was "
+                                 "issued -> after the stream has joined the collectives (AdamW may start)",
+                   "overlap": bool(model.overlap_allreduce and getattr(model, "_early_lo", None))}
+    model.time_allreduce = False
 
     if rank != 0:
         if world > 1:
-            import torch.distributed as td
             td.barrier()  # rank 0 finishes its extra single-GPU measurements, then everybody leaves together
             td.destroy_process_group()
         return
-
-    # inference forward (extra information)
-    with torch.no_grad():
-        for _ in range(5):
-            model.model(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            model.model(x)
-        torch.cuda.synchronize()
-        infer_ms = (time.perf_counter() - t0) / 20 * 1e3
 
     line = {
         "metric": "HR Mpixels/s (LarvaNet x4 multi-exit train step, 48x48 LR patches)",
@@ -303,18 +486,51 @@ def main():
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                    "inputs": "resident in the captured step's input buffers" if bufs is not None else "resident in HBM",
                    "loss_sync_per_step": bool(a.sync_loss), "hip_graph": bool(model.use_hip_graph),
-                   "final_loss": float(loss)},
-        "roofline": roofline_block(dev),
-        "roofline_wgrad": wgrad_block(dev),
-        "infer": {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
-                  "unit": "HR Mpixels/s"},
+                   "final_loss": final_loss},
+        "rounds": {"n": rounds, "steps_each": a.steps, "ms_per_step_median": ms_per_step,
+                   "ms_per_step_min": per_step[0], "ms_per_step_max": per_step[-1],
+                   "value_is": "median round (max over ranks of each round's wall time)"},
     }
+    if world > 1:
+        line["rccl_ranks"] = td.get_world_size() if td.get_backend() == "nccl" else 0
+        line["dist_backend"] = td.get_backend()
+        line["allreduce_exposed_us"] = exposed
+
+    extras = world == 1 and not a.no_extras
+    if extras:
+        # the reference's per-step behaviour: a fresh batch handed over (copied into the step's
+        # inputs) and loss.item() -- a host sync -- every step (models/LarvaNet.py:139)
+        model.sync_loss = True
+        secs2, _ = timed_rounds(model, args, val, x_fresh, truth_fresh, a.steps, min(rounds, 3), False)
+        model.sync_loss = bool(a.sync_loss)
+        ms2 = float(np.median([s / a.steps * 1e3 for s in secs2]))
+        line["value_sync_loss"] = {"value": HR_PIX_PER_BATCH / (ms2 * 1e-3) / 1e6, "unit": "HR Mpixels/s",
+                                   "ms_per_step": ms2, "what": "loss.item() every step + fresh device tensors "
+                                   "copied into the step's inputs (the reference's hand-over, models/LarvaNet.py:139)"}
+
+    # inference forward (extra information)
+    with torch.no_grad():
+        for _ in range(5):
+            model.model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            model.model(x)
+        torch.cuda.synchronize()
+        infer_ms = (time.perf_counter() - t0) / 20 * 1e3
+    line["roofline"] = roofline_block(dev)
+    line["roofline_wgrad"] = wgrad_block(dev)
+    line["infer"] = {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
+                     "unit": "HR Mpixels/s"}
+    if extras:
+        line["roofline_c32"] = roofline_block(dev, 32, full=False)
+        line["roofline_c64"] = roofline_block(dev, 64, full=False)
+        del model
+        line["infer_full_image"] = full_image_block(dev)
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
-    sys.stdout = real_stdout
-    print(json.dumps(line), flush=True)
+    emit(line)
     if world > 1:
-        import torch.distributed as td
         td.barrier()
         td.destroy_process_group()
 

@@ -22,11 +22,14 @@ const char* larva_error_string(int code);
 
 /* ---- weight packing ------------------------------------------------------------------------
  * nn.Conv2d weights stay in PyTorch layout [cout][cin][3][3] (models/LarvaNet.py:210,212,227,
- * 256,258; models/LarvaNetV2.py:318).  The conv kernel consumes a packed image
- * [cin/16][9][16][stride(cout)]; the input-gradient pass consumes the tap-mirrored,
- * channel-transposed image [cout/16][9][16][stride(cin)].  `w_cin_total`/`w_cin_off` select a
- * channel slice [w_cin_off, w_cin_off+cin) of a wider weight; channels >= w_cin_total pack as 0
- * (3-channel head conv padded to 16).  Either output may be NULL. */
+ * 256,258; models/LarvaNetV2.py:318).  The conv kernel consumes a packed image of 8-channel K
+ * chunks, [cin/8][9][8][stride(cout)]; the input-gradient pass consumes the tap-mirrored,
+ * channel-transposed image [cout/8][9][8][stride(cin)]; stride(c) = c if c % 32 == 16 else
+ * c + 16 floats (LDS bank layout).  cin and cout are multiples of 8.
+ * larva_packed_weight_floats(cout, cin) = (cin/8) * 9 * 8 * stride(cout).
+ * `w_cin_total`/`w_cin_off` select a channel slice [w_cin_off, w_cin_off+cin) of a wider weight;
+ * channels >= w_cin_total pack as 0 (the 3-channel head conv is packed for a 16-channel, i.e.
+ * two-chunk, zero-padded input).  Either output may be NULL. */
 long long larva_packed_weight_floats(int cout, int cin);
 int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout, int cin,
                        int w_cin_total, int w_cin_off, void* stream);
@@ -45,7 +48,7 @@ int larva_pack_weights_batch(const float* const* w, float* const* wpk_fwd, float
  *   torch.cat(features)+merge_conv   models/LarvaNetV2.py:328-330  (n_src > 1)
  * and, fed with the `wpk_bwd` image, autograd's conv input-gradient with the ReLU-backward
  * mask (mask) and the skip-connection gradient adds (res0/res1) fused.
- * src: n_src (<= 8) tensors [N][cin_per_src][H][W] (cin_per_src % 16 == 0) read as one
+ * src: n_src (<= 8) tensors [N][cin_per_src][H][W] (cin_per_src % 8 == 0) read as one
  * channel-concatenated input.  cout in {32, 48, 64}.
  * Epilogue order: +bias -> relu -> (mask > 0 ? v : 0) -> +res0 -> +res1.
  * mode 0: out [N][cout][H][W]; supported fusions: none | relu | mask | res0 | res0+res1.

@@ -6,7 +6,8 @@
 //   * the matching INPUT HALO TILE is 5 rows x 50 columns per channel, staged in LDS as
 //     [channel][5][LDS_RS] with the first wanted column (x0-1) at index 3 so that column x0
 //     sits on a 16-byte boundary;
-//   * channels are processed in chunks of 16 (= 4 k-steps of v_mfma_f32_16x16x4_f32).
+//   * the conv kernel walks the input channels in K chunks of 8 (kCh in conv3x3_mfma.hip = 2
+//     k-steps of v_mfma_f32_16x16x4_f32 per tap).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,8 +19,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTileRows = 3;
 constexpr int kTileCols = 48;
 constexpr int kHaloRows = kTileRows + 2;
-constexpr int kPixGroups = kTileRows * (kTileCols / 16);  // 9
-constexpr int kChunk = 16;                                 // channels per K chunk
 constexpr int kMaxSrc = 8;                                 // channel-concatenated input tensors
 
 // LDS row stride of a staged halo row (floats): idx 3 = x0-1, idx 4..51 = x0..x0+47, idx 52 = x0+48.
@@ -40,32 +39,13 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return base + (b >> 3);
 }
 
-// LDS-DMA (global_load_lds_*): lane l's BYTES bytes at `gsrc` land at LDS byte address
-// lds_base + BYTES * l.  Issued through inline asm on purpose: with the compiler builtin in a
-// loop, hipcc (ROCm 7.2) turns every counted lgkmcnt(N) in front of the MFMAs into lgkmcnt(0),
-// i.e. waits for the operand reads it has only just issued.  The statement saves/restores M0
-// (compiler-reserved) and pads the SALU-write-M0 -> LDS-DMA hazard itself; the DMA is invisible
-// to hipcc's vmcnt bookkeeping, so callers count it by hand (s_waitcnt vmcnt(N)) and drain it
-// with vmcnt(0) before the workgroup ends.
-template <int BYTES>
-__device__ __forceinline__ void lds_dma(const void* gsrc, float* lds_dst_wave_uniform) {
-  static_assert(BYTES == 16 || BYTES == 4, "LDS-DMA widths used here");
-  const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
-      (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds_dst_wave_uniform));
-  unsigned keep;
-  if constexpr (BYTES == 16)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_addr)
-                 : "memory");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_addr)
-                 : "memory");
-}
-
-// The same through a raw buffer descriptor (4 SGPRs: base, stride 0, num_records 2^31-1): lane l's
+// LDS-DMA goes through inline asm on purpose: with the compiler builtin in a loop, hipcc (ROCm 7.2)
+// turns every counted lgkmcnt(N) in front of the MFMAs into lgkmcnt(0), i.e. waits for the operand
+// reads it has only just issued.  The statement saves/restores M0 (compiler-reserved) and pads the
+// SALU-write-M0 -> LDS-DMA hazard itself; the DMA is invisible to hipcc's vmcnt bookkeeping, so
+// callers count it by hand (s_waitcnt vmcnt(N)) and drain it with vmcnt(0) before the workgroup ends.
+//
+// Through a raw buffer descriptor (4 SGPRs: base, stride 0, num_records 2^31-1): lane l's
 // 16 bytes at base + soffset + voff land at LDS byte address lds_base + 16 l.  A lane whose voff is
 // out of range (>= 2^31, see kDmaZero) WRITES ZEROS (probed on gfx950: tools/probe_lds_dma.hip), so
 // padding costs no address select and no zero page.  Nothing here is per-lane arithmetic: the wave

@@ -9,6 +9,11 @@ every rank's ReduceLROnPlateau takes the same decision.
 """
 import os
 
+# dmabuf IPC (the only mode the host driver supports): must be in the environment BEFORE the
+# HIP/HSA runtime comes up, i.e. before the first torch.cuda call of the process -- importing this
+# module is early enough, init_from_env() after torch.cuda.set_device() would not be.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as td
 
@@ -35,14 +40,18 @@ def init_from_env(backend=None):
     if ws <= 1 or is_initialized():
         return rank(), world_size()
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_gpu = torch.cuda.is_available()
-    if use_gpu:
-        torch.cuda.set_device(local % torch.cuda.device_count())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count()   # (counting devices does not initialise the runtime)
+    use_gpu = ndev > 0
     # LARVA_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
-    # (RCCL refuses two ranks on one device)
     backend = backend or os.environ.get("LARVA_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+    if use_gpu:
+        if backend == "nccl" and local >= ndev:
+            # RCCL refuses two ranks on one device; mapping them there silently would only hang later
+            raise RuntimeError("larvanet_amd: LOCAL_RANK %d needs its own GPU but only %d device(s) are visible "
+                               "(one process per GPU; LARVA_DIST_BACKEND=gloo rehearses more ranks than GPUs)"
+                               % (local, ndev))
+        torch.cuda.set_device(local % ndev)
     td.init_process_group(backend=backend)
     return rank(), world_size()
 
@@ -93,6 +102,22 @@ def allreduce_scalar_sum(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if td.get_backend() == "nccl" else "cpu")
     td.all_reduce(t, op=td.ReduceOp.SUM)
     return float(t.item())
+
+
+def all_gather_tensor(t):
+    """[world][*t.shape]: every rank's tensor `t` (same shape and dtype everywhere), in rank order,
+    as ONE device collective (RCCL all-gather over xGMI; gloo for the CPU rehearsal) -- no pickling,
+    no host round trip."""
+    ws = world_size()
+    t = t.contiguous()
+    if ws == 1:
+        return t.unsqueeze(0)
+    out = torch.empty((ws,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    try:
+        td.all_gather_into_tensor(out, t)
+    except (RuntimeError, NotImplementedError):   # a backend without the flat form
+        td.all_gather(list(out.unbind(0)), t)
+    return out
 
 
 def seed_for_rank(base_seed):

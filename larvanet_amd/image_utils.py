@@ -51,6 +51,29 @@ def upscale_band(model, input_image, scale, r0, r1, halo):
     return out[:, (r0 - lo) * scale:(r1 - lo) * scale, :]
 
 
+def upscale_banded_device(model, input_image, scale, rank, world, all_gather, halo=None):
+    """upscale_banded with the bands moved by a DEVICE collective: rank r upscales band r (+ halo)
+    on its GPU, crops it on the GPU into a buffer of the tallest band's size, and
+    `all_gather(tensor) -> [world][...]` (larvanet_amd.dist.all_gather_tensor = one RCCL all-gather)
+    hands every rank all bands; the concatenation is a device tensor [C][scale*H][scale*W].  Nothing
+    is pickled and no band visits the host (upscale_banded gathers numpy arrays as Python objects:
+    a 33 MB DIV2K output would be pickled once per rank).  Bit-identical to the full-image forward
+    for halo >= model.receptive_halo()."""
+    import torch
+    halo = model.receptive_halo() if halo is None else halo
+    channels, height, width = input_image.shape
+    rows = band_rows(height, world)
+    tallest = max(b - a for a, b in rows)
+    r0, r1 = rows[rank]
+    buf = torch.zeros((channels, tallest * scale, width * scale), dtype=torch.float32, device=model.device)
+    if r1 > r0:
+        lo, hi = max(0, r0 - halo), min(height, r1 + halo)
+        out = model.upscale_tensor(input_list=[np.ascontiguousarray(input_image[:, lo:hi, :])])[0]
+        buf[:, :(r1 - r0) * scale] = out[:, (r0 - lo) * scale:(r1 - lo) * scale]
+    bands = all_gather(buf)
+    return torch.cat([bands[q, :, :(b - a) * scale] for q, (a, b) in enumerate(rows)], dim=1)
+
+
 def upscale_banded(model, input_image, scale, rank, world, gather, halo=None):
     """One image split into `world` row bands, band r computed by rank r, `gather(obj)` = every
     rank's object in rank order (larvanet_amd.dist.gather_objects).  Every rank returns the whole

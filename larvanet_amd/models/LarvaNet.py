@@ -25,6 +25,11 @@ from ..optim import FlatAdamW, flatten_parameters
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
 from .base import BaseModel
 
+# F.interpolate modes of the base image (models/LarvaNet.py:283-285) that have a HIP kernel.  The
+# reference hands any mode string to F.interpolate; here an unsupported one is refused when the
+# flags are parsed, not at the first forward.
+SUPPORTED_INTERPOLATE = ("bicubic",)
+
 NUM_FILTERS = 48  # = 3 * 4**2: PixelShuffle(4) of the leg output must give RGB (models/LarvaNet.py:226,261)
 
 
@@ -156,6 +161,9 @@ class LarvaNetModule(nn.Module):
         super().__init__()
         self.len = args.num_modules
         self.interpolate = args.interpolate
+        # inference on widths that are not a multiple of 4: row-padded activations (16-byte LDS-DMA
+        # staging) instead of the register-staged conv path; False only to test the latter
+        self.pad_odd_widths = True
         self.head = LarvaHead()
         for i, nb in enumerate(parse_num_blocks(args)):
             setattr(self, "body_%d" % i, LarvaBody(num_blocks=nb))
@@ -188,15 +196,16 @@ class LarvaNetModule(nn.Module):
     def base(self, x):
         """F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False) (models/LarvaNet.py:283-285)."""
         _require_hip(x)
-        if self.interpolate != "bicubic":
-            raise RuntimeError("larvanet_amd: only --interpolate=bicubic has a HIP kernel")
+        if self.interpolate not in SUPPORTED_INTERPOLATE:   # (parse_args already refuses it)
+            raise ValueError("larvanet_amd: --interpolate=%s has no HIP kernel; supported: %s"
+                             % (self.interpolate, ", ".join(SUPPORTED_INTERPOLATE)))
         with torch.no_grad():
             return K.bicubic4(x.detach().contiguous())
 
     def width_scope(self, x):
         """Row-padded activations for inference on widths that are not a multiple of 4."""
         w = int(x.shape[-1])
-        if w % 4 and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+        if w % 4 and self.pad_odd_widths and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             return PaddedWidth(w)
         return _NoScope()
 
@@ -219,6 +228,7 @@ class LarvaNet(BaseModel):
         self.volume_per_step = 0
         self.sync_loss = True
         self.use_hip_graph = os.environ.get("LARVA_HIP_GRAPH", "1") != "0"
+        self.hip_graph_fell_back = None   # reason, if a capture failed and the step went eager
         # Exits on a side stream: measured neutral-to-negative on MI355X at batch 16 (same-box A/B:
         # 2.36 ms without, 2.36 / 2.45 ms with, depending on the wgrad variant) -- opt-in.
         self.use_side_streams = os.environ.get("LARVA_SIDE_STREAMS", "0") != "0"
@@ -252,6 +262,9 @@ class LarvaNet(BaseModel):
         parser = argparse.ArgumentParser()
         self._add_args(parser)
         self.args, remaining_args = parser.parse_known_args(args=args)
+        if self.args.interpolate not in SUPPORTED_INTERPOLATE:
+            raise ValueError("larvanet_amd: --interpolate=%s has no HIP kernel; supported: %s"
+                             % (self.args.interpolate, ", ".join(SUPPORTED_INTERPOLATE)))
         return copy.deepcopy(self.args), remaining_args
 
     # ------------------------------------------------------------------ build
@@ -476,9 +489,12 @@ class LarvaNet(BaseModel):
                 try:
                     self._capture_step(input_tensor, truth_tensor)
                 except Exception as e:  # capture is an optimisation: fall back to plain launches
+                    if os.environ.get("LARVA_HIP_GRAPH_STRICT", "0") != "0":
+                        raise
                     print("WARNING: hipGraph capture failed (%s: %s); continuing with eager launches"
                           % (type(e).__name__, e))
                     self.use_hip_graph = False
+                    self.hip_graph_fell_back = "%s: %s" % (type(e).__name__, e)
                     torch.cuda.synchronize()
                     return self._forward_backward(input_tensor, truth_tensor)
             # (a producer that filled input_buffers() in place hands the very same storage back)
@@ -502,29 +518,47 @@ class LarvaNet(BaseModel):
         """Second half of a split backward + the data-parallel mean of the gradients
         (one flat bucket; the all-reduce of the half that is already complete runs on
         RCCL's stream beside the remaining weight-gradient kernels).  The 1/world_size of the
-        mean is applied inside the optimizer kernel (FlatAdamW.grad_scale)."""
+        mean is applied inside the optimizer kernel (FlatAdamW.mean_scale)."""
         late, self._late = getattr(self, "_late", None), None
         ws = ldist.world_size()
         bucket = getattr(self, "grad_bucket", None)
         if ws == 1 or bucket is None or not bucket.intact(self.model):
             if late is not None:
                 late()
-            ldist.allreduce_gradients(self.model, None)
+            ldist.allreduce_gradients(self.model, None)   # already the mean: no second 1/world in the optimizer
+            if isinstance(self.optim, FlatAdamW):
+                self.optim.mean_scale = 1.0
             return
         lo = getattr(self, "_early_lo", None)
+        timed = getattr(self, "time_allreduce", False) and self.device.type == "cuda"
         if late is None or lo is None or lo <= 0:
             if late is not None:
                 late()
+            t0 = self._mark(timed)
             ldist.allreduce_sum(bucket.flat)
         else:
             work = ldist.allreduce_sum(bucket.flat[lo:], async_op=True)
             late()
+            t0 = self._mark(timed)   # the last weight-gradient kernel has been issued: what follows is exposed
             ldist.allreduce_sum(bucket.flat[:lo])
             work.wait()
+        if timed:
+            self.allreduce_events.append((t0, self._mark(True)))
         if isinstance(self.optim, FlatAdamW):
-            self.optim.grad_scale = 1.0 / ws
+            self.optim.mean_scale = 1.0 / ws
         else:
             bucket.flat.mul_(1.0 / ws)
+
+    def _mark(self, on):
+        """Timing event on the current stream (bench.py: exposed all-reduce time per step = from the
+        end of the last weight-gradient kernel to the point where AdamW may start)."""
+        if not on:
+            return None
+        if not hasattr(self, "allreduce_events"):
+            self.allreduce_events = []
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
 
     def train_step_larva(self, args, val_dataloader, input_tensor, truth_tensor, summary=None):
         self.global_step += 1
@@ -551,8 +585,9 @@ class LarvaNet(BaseModel):
                 self._write_summary(summary, loss, input_tensor, out, truth_tensor)
 
         # the reference returns loss.item() (a host sync every step, models/LarvaNet.py:139);
-        # sync_loss=False hands back the 0-d device tensor instead so the host can run ahead
-        return loss.item() if self.sync_loss else loss.detach()
+        # sync_loss=False hands back a 0-d device tensor instead so the host can run ahead (a copy:
+        # the captured step's own loss tensor is overwritten by the next replay)
+        return loss.item() if self.sync_loss else loss.detach().clone()
 
     def _write_summary(self, summary, loss, input_tensor, out, truth_tensor):
         summary.add_scalar("loss", loss, self.global_step)
@@ -601,6 +636,11 @@ class LarvaNet(BaseModel):
         """list of CHW numpy images -> (N, 3, 4H, 4W) float32 numpy (models/LarvaNet.py:163-171)."""
         with torch.no_grad():
             return self.model(self._to_input_tensor(input_list)).detach().cpu().numpy()
+
+    def upscale_tensor(self, input_list):
+        """upscale() without the trip to the host: (N, 3, 4H, 4W) float32 on self.device."""
+        with torch.no_grad():
+            return self.model(self._to_input_tensor(input_list)).detach()
 
     def receptive_halo(self):
         """LR pixels beyond an output pixel's own LR pixel that can influence it: one per 3x3

@@ -33,7 +33,7 @@ class FlatAdamW(torch.optim.AdamW):
         self._v = torch.zeros_like(flat_params)
         self._t = 0
         self._plist = params
-        self.grad_scale = 1.0   # gradients are multiplied by this inside the step (1/world_size: mean over ranks)
+        self.mean_scale = 1.0   # (not "grad_scale": torch.optim reserves that attribute for AMP) gradients are multiplied by this inside the step (1/world_size: mean over ranks)
 
     def _flat_ok(self):
         if self._flat_p is None or self._bucket is None or not self._bucket.intact():
@@ -56,7 +56,7 @@ class FlatAdamW(torch.optim.AdamW):
         self._t += 1
         b1, b2 = g["betas"]
         K.adamw_step_host(self._flat_p, self._bucket.flat, self._m, self._v, self._t, float(g["lr"]), b1, b2,
-                          g["eps"], g["weight_decay"], self.grad_scale)
+                          g["eps"], g["weight_decay"], self.mean_scale)
         return None
 
     def training_state(self):
@@ -79,10 +79,11 @@ class FlatAdamW(torch.optim.AdamW):
             raise RuntimeError("larvanet_amd: flat optimizer state cannot be loaded into a per-tensor optimizer")
 
     def _fallback_step(self, closure):
-        if self.grad_scale != 1.0:
+        if self.mean_scale != 1.0:   # consumed once: the caller sets it again if it still applies
             for p in self._plist:
                 if p.grad is not None:
-                    p.grad.mul_(self.grad_scale)
+                    p.grad.mul_(self.mean_scale)
+            self.mean_scale = 1.0
         # hand the moments over to torch's per-tensor state once, then stay on torch's path
         if self._t > 0 and not self.state:
             off = 0

@@ -74,9 +74,11 @@ def main(argv=None):
                 lr, hr, name = loader.get_image_pair(image_index=index, scale=scale)
                 t0 = time.perf_counter()
                 if args.band_gpus:
-                    out = image_utils.upscale_banded(model, lr, scale, rank, world, ldist.gather_objects)
+                    # one row band per rank, moved by ONE device all-gather (RCCL over xGMI)
+                    out_dev = image_utils.upscale_banded_device(model, lr, scale, rank, world, ldist.all_gather_tensor)
                     if rank != 0:  # every rank holds the image now; rank 0 scores and saves it
                         continue
+                    out = out_dev.cpu().numpy()
                 elif args.chop_forward:
                     out = image_utils.upscale_with_chop_forward(model=model, input_image=lr, scale=scale,
                                                                 overlap_size=args.chop_overlap_size)

@@ -67,11 +67,61 @@ class FakeValLoader:
         return lr, hr, "img%d" % image_index
 
 
+def main_r2(only):
+    """Round-2 fixtures (headline configuration): F11 = the reference's own train_step_larva at
+    M4B4 on 16x3x48x48 (models/LarvaNet.py:98-114), F12 = the canonical forward after the
+    validate.py uint8 protocol (validate.py:17-27).  `python make_golden.py r2` writes only these."""
+    validate = importlib.import_module("validate")
+    argv = ["--num_modules=4", "--num_blocks=4,4,4,4"]
+    x = torch.rand(16, 3, 48, 48, generator=torch.Generator().manual_seed(0)) * 255
+    truth = torch.rand(16, 3, 192, 192, generator=torch.Generator().manual_seed(1)) * 255
+
+    if "f11" in only:
+        model = make_ref_model("LarvaNet", argv, seed=0)
+        attach_training(model)
+        model.volume_per_step = 48 * 48 * 16 * 3
+        val = FakeValLoader(7)
+        args = types.SimpleNamespace(train_path="/tmp")
+        losses, lrs, rec = [], [], {}
+        for step in range(3):
+            losses.append(model.train_step_larva(args, val, x, truth, None))
+            lrs.append(model.get_lr())
+            if step == 0:
+                for k, p in model.model.named_parameters():
+                    gnp = p.grad.detach().numpy()
+                    idx = np.random.RandomState(len(k)).choice(gnp.size, min(64, gnp.size), replace=False)
+                    rec["gidx." + k] = idx
+                    rec["gval." + k] = gnp.ravel()[idx].copy()
+                    rec["gmax." + k] = np.array(np.abs(gnp).max())
+                    rec["gabs." + k] = np.array(np.abs(gnp.astype(np.float64)).sum())
+                    rec["gsha." + k] = np.array(sha(gnp))
+        after = sd_to_np(model.model.state_dict())
+        flat_after = np.concatenate([after[k].ravel() for k in sorted(after)])
+        np.savez(os.path.join(OUT, "f11_m4b4_train_steps.npz"), losses=np.array(losses, np.float64),
+                 lrs=np.array(lrs, np.float64), after3_sample=flat_after[::211].copy(),
+                 after3_sha=np.array(sha(flat_after)), global_step=np.array(model.global_step),
+                 temp_volume=np.array(model.temp_volume), **rec)
+
+    if "f12" in only:
+        model = make_ref_model("LarvaNet", argv, seed=0)
+        with torch.no_grad():
+            y = model.model(x).numpy()
+        y8 = np.stack([validate._image_to_uint8(im) for im in y])
+        t8 = np.stack([validate._image_to_uint8(im) for im in truth.numpy()])
+        psnr = np.array([float(validate._image_psnr(output_image=y8[i], truth_image=t8[i])) for i in range(len(y8))],
+                        np.float64)
+        np.savez(os.path.join(OUT, "f12_m4b4_uint8.npz"), u8_sha=np.array(sha(y8)), u8_img0=y8[0], u8_img15=y8[15],
+                 psnr_vs_truth=psnr, out_img0_f32=y[0].astype(np.float32)[:, ::3, ::3].copy())
+
+
 def main():
     sys.path.insert(0, REF)
     sys.modules.setdefault("cv2", types.ModuleType("cv2"))
     torch.set_num_threads(4)
     torch.use_deterministic_algorithms(False)
+    if len(sys.argv) > 1 and sys.argv[1] == "r2":
+        main_r2(sys.argv[2:] or ["f11", "f12"])
+        return
 
     # ---------------- F1/F2: M2B2 weights, staged outputs on a 2x3x12x12 input ----------------
     model = make_ref_model("LarvaNet", ["--num_modules=2", "--num_blocks=2,2"], seed=0)

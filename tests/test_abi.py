@@ -33,8 +33,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.larva_abi_version() == 2
     # pure host-side size helpers need no device
-    assert lib.larva_packed_weight_floats(48, 48) == 3 * 9 * 16 * 48
-    assert lib.larva_packed_weight_floats(64, 64) == 4 * 9 * 16 * 80
+    def stride(c):   # cout_stride() of csrc/larva_common.h: == 16 (mod 32) floats
+        return c if c % 32 == 16 else c + 16
+
+    for cout, cin in ((48, 48), (64, 64), (32, 32), (48, 16), (48, 192), (48, 8)):
+        # [cin/8] chunks x 9 taps x 8 channels x stride(cout) -- the layout include/larva_hip.h documents
+        assert lib.larva_packed_weight_floats(cout, cin) == (cin // 8) * 9 * 8 * stride(cout), (cout, cin)
     assert lib.larva_wgrad_partial_floats(48, 48, 2) == 2 * (27 * 3 * 256 + 48)
 
 

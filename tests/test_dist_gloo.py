@@ -58,12 +58,56 @@ def _worker(rank, world, port, q):
             return lr, hr, str(image_index)
 
     avg = m.validate_for_train(None, Val())
+
+    # one image as one row band per rank, moved by a tensor all-gather (validate.py --band_gpus)
+    from larvanet_amd import image_utils
+
+    class Nearest:   # a 1-row-halo "network": x4 nearest upscale of a vertical 3-tap sum (zero padded)
+        device = torch.device("cpu")
+
+        def receptive_halo(self):
+            return 1
+
+        def upscale_tensor(self, input_list):
+            a = torch.from_numpy(np.asarray(input_list, np.float32))
+            p = torch.nn.functional.pad(a, (0, 0, 1, 1))
+            s = p[:, :, :-2] + p[:, :, 1:-1] + p[:, :, 2:]
+            return s.repeat_interleave(4, 2).repeat_interleave(4, 3)
+
+    img = np.random.RandomState(5).randint(0, 256, size=(3, 7, 5)).astype(np.float32)
+    banded = image_utils.upscale_banded_device(Nearest(), img, 4, rank, world, ldist.all_gather_tensor)
+    band_ok = bool(torch.equal(banded, Nearest().upscale_tensor([img])[0]))
+    gathered_t = ldist.all_gather_tensor(torch.full((2, 3), float(rank)))
+    band_ok = band_ok and gathered_t.shape == (world, 2, 3) and float(gathered_t[1, 0, 0]) == 1.0
+
+    # a data-parallel step whose gradient bucket gets detached mid-run (somebody called
+    # zero_grad(set_to_none=True)): the mean over ranks must be applied once, not 1/world twice
+    from larvanet_amd.optim import FlatAdamW
+    lin = torch.nn.Linear(2, 1, bias=False)
+    with torch.no_grad():
+        lin.weight.fill_(1.0)
+
+    class Bucket:
+        flat = torch.zeros(2)
+
+        def intact(self, module=None):
+            return False
+
+    opt = FlatAdamW(list(lin.parameters()), lin.weight.data.view(-1), Bucket(), lr=0.1, weight_decay=0.0)
+    m.optim, m.model, m.grad_bucket = opt, lin, Bucket()
+    opt.mean_scale = 1.0 / world   # left over from the steps that ran on the intact bucket
+    lin.weight.grad = torch.full_like(lin.weight, float(rank + 1))
+    m._finish_backward()
+    mean_grad = float(lin.weight.grad.flatten()[0])
+    opt.step()
+    scale_after = opt.mean_scale
     from larvanet_amd.dataloaders import synthetic_loader
     ld = synthetic_loader.create_loader()
     ld.parse_args(["--synthetic_images=4", "--synthetic_lr_size=24"])
     ld.prepare([4])
     first_patch = ld.get_patch_batch(1, 4, 12)[0][0]
-    q.put((rank, w0.numpy(), grads, psnr_sum, gathered, seen, float(avg), float(np.asarray(first_patch).sum())))
+    q.put((rank, w0.numpy(), grads, psnr_sum, gathered, seen, float(avg), float(np.asarray(first_patch).sum()),
+           band_ok, mean_grad, scale_after, float(lin.weight.grad.flatten()[0])))
     td.destroy_process_group()
 
 
@@ -79,7 +123,10 @@ def test_two_rank_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, w0, g0, s0, ga0, seen0, avg0, patch0), (r1, w1, g1, s1, ga1, seen1, avg1, patch1) = out
+    (r0, w0, g0, s0, ga0, seen0, avg0, patch0, *x0), (r1, w1, g1, s1, ga1, seen1, avg1, patch1, *x1) = out
+    assert x0[0] and x1[0]                               # row bands through the tensor all-gather == full image
+    assert x0[1] == x1[1] == 1.5 and x0[2] == 1.0        # mean of (1, 2) once; the stale 1/world is reset
+    assert x0[3] == 1.5                                  # ... and the optimizer did not scale it again
     assert np.array_equal(w0, w1)                       # broadcast from rank 0
     assert g0 == g1 == [1.5 * (i + 1) for i in range(4)]  # mean of (1, 2) x (i+1)
     assert s0 == s1 == 21.0

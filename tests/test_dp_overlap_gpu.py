@@ -32,16 +32,19 @@ class _Val:
                 rng.randint(0, 256, size=(3, 32, 48)).astype(np.float32), "v")
 
 
-def _worker(rank, world, port, q):
-    os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world),
-                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LARVA_DIST_BACKEND": "gloo"})
+def _worker(rank, world, port, q, backend="gloo"):
+    # gloo: both ranks share GPU 0 (the one-GPU test box); nccl (= RCCL): one GPU per rank
+    local = rank if backend == "nccl" else 0
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(local), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LARVA_DIST_BACKEND": backend})
     try:
         import torch.distributed as td
         from larvanet_amd import dist as ldist
         from larvanet_amd.autograd import DeferredWgrad
         from larvanet_amd.models import LarvaNet as L
-        ldist.init_from_env(backend="gloo")
-        dev = torch.device("cuda", 0)
+        ldist.init_from_env(backend=backend)
+        assert td.get_backend() == backend
+        dev = torch.device("cuda", local)
         DeferredWgrad.jobs_per_launch = 4  # a small network still ends backward in several launches
         g = torch.Generator().manual_seed(50 + rank)  # every rank trains on its own patches
         x = (torch.rand(2, 3, 12, 16, generator=g) * 255).to(dev)
@@ -68,11 +71,16 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_overlapped_allreduce_trains_like_one_collective(hip_device):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_overlapped_allreduce_trains_like_one_collective(hip_device, backend):
+    """backend nccl = RCCL over xGMI, one GPU per rank: needs two devices (skipped on the one-GPU
+    test box, where the gloo variant carries the same step with both ranks on GPU 0)."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank; this box has %d" % torch.cuda.device_count())
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r[0])

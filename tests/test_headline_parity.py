@@ -1,0 +1,217 @@
+"""Parity at the HEADLINE configuration -- the workload bench.py reports (BASELINE config 2/3:
+LarvaNet x4, --num_modules=4 --num_blocks=4,4,4,4, batch 16 x 3 x 48 x 48 -> 16 x 3 x 192 x 192)
+and the full-image inference of config 5 (3 x 339 x 510, V1 and V2).  At this size the training
+step issues the kernels in the shapes the benchmark times: wgrad3x3_pipe_kernel<48,48> as
+32 layers x 8 workgroups + 8 x 32, ExitsFn with 4 batched jobs of 256 workgroups, the K = 96
+JointBwd dgrad and the deferred weight-gradient queue.
+
+Checked against (1) fixtures generated from the imported reference (tests/golden/make_golden.py r2:
+F11 = its own train_step_larva for 3 steps, F12 = its forward after the validate.py uint8
+protocol) and (2) oracle/larva_torch.py (pinned against the same fixtures on the CPU by
+tests/test_oracle_golden.py) for every gradient element.
+
+Tolerances: losses 2e-5 relative; gradients 2e-4 of each tensor's largest element; fp32 forward
+2e-3 absolute on the 0-255 scale; PSNR after the uint8 protocol 1e-3 dB (north_star)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BLOCKS = [4, 4, 4, 4]
+FLAGS = ["--num_modules=4", "--num_blocks=4,4,4,4"]
+
+
+def _model(name, argv, training=False, seed=0):
+    import importlib
+    m = importlib.import_module("larvanet_amd.models." + name).create_model()
+    m.parse_args(argv)
+    torch.manual_seed(seed)
+    m.prepare(is_training=training, scales=[4])
+    return m
+
+
+class FakeValLoader:
+    """Same two pairs as tests/golden/make_golden.py: validate_for_train at global_step 1."""
+
+    def __init__(self, seed):
+        rng = np.random.RandomState(seed)
+        self.pairs = []
+        for (h, w) in ((10, 12), (9, 14)):
+            lr = rng.randint(0, 256, size=(3, h, w)).astype(np.float32)
+            hr = rng.randint(0, 256, size=(3, 4 * h + 1, 4 * w + 2)).astype(np.float32)
+            self.pairs.append((lr, hr))
+
+    def get_num_images(self):
+        return len(self.pairs)
+
+    def get_image_pair(self, image_index, scale):
+        lr, hr = self.pairs[image_index]
+        return lr, hr, "img%d" % image_index
+
+
+def _canonical_batch():
+    x = torch.rand(16, 3, 48, 48, generator=torch.Generator().manual_seed(0)) * 255
+    truth = torch.rand(16, 3, 192, 192, generator=torch.Generator().manual_seed(1)) * 255
+    return x, truth
+
+
+@pytest.fixture(scope="module")
+def oracle_step():
+    """One training step of the oracle at the headline size: loss + all 82 gradients (CPU, < 1 s)."""
+    from oracle import larva_torch as T
+    x, truth = _canonical_batch()
+    sd = T.init_state_dict(BLOCKS, seed=0)
+    losses, grads = T.train_steps(dict(sd), x, truth, BLOCKS, steps=1)
+    return losses[0], grads
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_headline_train_step_matches_reference_fixture_f11(hip_device, golden, oracle_step, use_graph):
+    """(a) + (b): the plugin's train_step_larva at M4B4 / 16x3x48x48 against the reference's own
+    three steps (F11) and, element for element, against the oracle's gradients."""
+    g = golden("f11_m4b4_train_steps.npz")
+    ref_loss, ref_grads = oracle_step
+    m = _model("LarvaNet", FLAGS, training=True)
+    m.use_hip_graph = use_graph
+    m.volume_per_step = 48 * 48 * 16 * 3
+    x, truth = _canonical_batch()
+    x, truth = x.to(hip_device), truth.to(hip_device)
+    args = types.SimpleNamespace(train_path="/tmp")
+    val = FakeValLoader(7)
+    losses = []
+    for step in range(3):
+        losses.append(m.train_step_larva(args, val, x, truth, None))
+        if step == 0:
+            assert abs(losses[0] - ref_loss) <= 2e-5 * abs(ref_loss)
+            names = [k for k, _ in m.model.named_parameters()]
+            assert len(names) == 82
+            for k, p in m.model.named_parameters():
+                got = p.grad.detach().cpu().numpy()
+                # the reference's own values (sampled) ...
+                tol = 2e-4 * max(float(g["gmax." + k]), 1e-30)
+                d = float(np.abs(got.ravel()[g["gidx." + k]] - g["gval." + k]).max())
+                assert d <= tol, ("fixture", k, d, tol)
+                gabs = float(np.abs(got.astype(np.float64)).sum())
+                assert abs(gabs - float(g["gabs." + k])) <= 2e-4 * float(g["gabs." + k]), ("fixture |g|", k)
+                # ... and every element against the oracle
+                ref = ref_grads[k].numpy()
+                d = float(np.abs(got - ref).max())
+                assert d <= 2e-4 * max(float(np.abs(ref).max()), 1e-30), ("oracle", k, d)
+    assert m.use_hip_graph == use_graph  # a capture failure would have switched it off silently
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5)
+    after = {k: v.cpu().numpy() for k, v in m.model.state_dict().items()}
+    flat = np.concatenate([after[k].ravel() for k in sorted(after)])
+    np.testing.assert_allclose(flat[::211], g["after3_sample"], rtol=0, atol=2e-5)
+    assert m.global_step == int(g["global_step"]) and m.temp_volume == int(g["temp_volume"])
+    np.testing.assert_allclose(m.get_lr(), g["lrs"][-1])
+
+
+def test_headline_wgrad_launch_shape_32_layers_by_8_splits(hip_device):
+    """The weight-gradient launch exactly as the step issues it (32 layers x 8 workgroups at
+    16x48x48x48, pipelined kernel + fixed-order reduction) against torch's CPU conv2d_weight."""
+    from larvanet_amd import kernels as K
+    gen = torch.Generator().manual_seed(31)
+    jobs, refs = [], []
+    for i in range(32):
+        dy = torch.randn(16, 48, 48, 48, generator=gen) * 1e-3
+        x = torch.randn(16, 48, 48, 48, generator=gen) * 20
+        jobs.append({"dy": dy.to(hip_device), "x": x.to(hip_device),
+                     "dw": torch.full((48, 48, 3, 3), float("nan"), device=hip_device),
+                     "db": torch.full((48,), float("nan"), device=hip_device)})
+        if i in (0, 13, 31):   # float64 references for three of the layers (the others: fp32 CPU)
+            dw = torch.nn.grad.conv2d_weight(x.double(), (48, 48, 3, 3), dy.double(), padding=1)
+            refs.append((i, dw.float().numpy(), dy.double().sum((0, 2, 3)).float().numpy(), 3e-5))
+        else:
+            dw = torch.nn.grad.conv2d_weight(x, (48, 48, 3, 3), dy, padding=1)
+            refs.append((i, dw.numpy(), dy.sum((0, 2, 3)).numpy(), 2e-4))
+    K.conv3x3_wgrad(jobs, 48, 48, 8)
+    torch.cuda.synchronize()
+    for i, dw_ref, db_ref, rel in refs:
+        dw, db = jobs[i]["dw"].cpu().numpy(), jobs[i]["db"].cpu().numpy()
+        assert np.isfinite(dw).all() and np.isfinite(db).all()
+        assert np.abs(dw - dw_ref).max() <= rel * np.abs(dw_ref).max(), i
+        assert np.abs(db - db_ref).max() <= rel * max(np.abs(db_ref).max(), 1e-30) + 1e-7, i
+
+
+def test_canonical_forward_uint8_protocol_f6_f12(hip_device, golden):
+    """(d): canonical-size inference forward: sampled fp32 values of the reference's output within
+    2e-3 (F6), and after the validate.py protocol (round half to even, clip, uint8) the image the
+    reference produces (F12): per-image PSNR against the synthetic truth within 1e-3 dB, uint8
+    pixels differing from the reference's only where fp32 summation order crosses a .5 boundary."""
+    from larvanet_amd import metrics
+    g6, g12 = golden("f6_m4b4_canonical.npz"), golden("f12_m4b4_uint8.npz")
+    m = _model("LarvaNet", FLAGS)
+    x, truth = _canonical_batch()
+    with torch.no_grad():
+        y = m.model(x.to(hip_device)).cpu().numpy()
+    d = np.abs(y.ravel()[g6["sample_idx"]] - g6["sample_val"])
+    assert float(d.max()) < 2e-3, float(d.max())
+    np.testing.assert_allclose(y[0][:, ::3, ::3], g12["out_img0_f32"], rtol=0, atol=2e-3)
+    y8 = np.stack([metrics.image_to_uint8(im) for im in y])
+    t8 = np.stack([metrics.image_to_uint8(im) for im in truth.numpy()])
+    psnr = np.array([float(metrics.image_psnr(y8[i], t8[i])) for i in range(16)])
+    assert np.abs(psnr - g12["psnr_vs_truth"]).max() < 1e-3, np.abs(psnr - g12["psnr_vs_truth"]).max()
+    for idx, key in ((0, "u8_img0"), (15, "u8_img15")):
+        diff = np.abs(y8[idx].astype(np.int16) - g12[key].astype(np.int16))
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-3, (idx, int(diff.max()), float((diff != 0).mean()))
+        # our image scored against the reference's image: > 80 dB means "the same picture"
+        assert float(metrics.image_psnr(y8[idx], g12[key])) > 80.0
+    # the device-side PSNR kernel (validate_for_train's path) gives the host protocol's number
+    from larvanet_amd import kernels as K
+    out0 = torch.from_numpy(y[3]).to(hip_device)
+    assert abs(K.psnr_u8(out0, torch.from_numpy(t8[3]).to(hip_device)) - psnr[3]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["LarvaNet", "LarvaNetV2"])
+@pytest.mark.parametrize("staging", ["pitched", "scalar"])
+def test_full_image_upscale_339x510_against_oracle(hip_device, name, staging):
+    """(c): BASELINE config 5 at N = 1: whole-network `upscale` of a DIV2K-val-sized LR image
+    (3 x 339 x 510 -> 3 x 1356 x 2040), V1 and V2, on both staging paths of the conv kernel (510 is
+    not a multiple of 4: `pitched` pads the rows to 512 and keeps the 16-byte LDS-DMA path, `scalar`
+    runs the register-staged path on the unpadded tensors), against oracle/larva_torch.py."""
+    from oracle import larva_torch as T
+    from larvanet_amd import metrics
+    v2 = name == "LarvaNetV2"
+    m = _model(name, FLAGS, seed=0)
+    m.model.pad_odd_widths = staging == "pitched"
+    rng = np.random.RandomState(510)
+    img = rng.randint(0, 256, size=(3, 339, 510)).astype(np.float32)
+    got = m.upscale([img], 4)[0]
+    assert got.shape == (3, 1356, 2040)
+    sd = {k: v.detach().cpu() for k, v in m.model.state_dict().items()}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        xt = torch.from_numpy(img)[None]
+        ref = (T.forward_v2(sd, xt, BLOCKS) if v2 else T.forward(sd, xt, BLOCKS))[0].numpy()
+    assert float(np.abs(got - ref).max()) <= 2e-3, float(np.abs(got - ref).max())
+    g8, r8 = metrics.image_to_uint8(got), metrics.image_to_uint8(ref)
+    diff = np.abs(g8.astype(np.int16) - r8.astype(np.int16))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+    hr = rng.randint(0, 256, size=(3, 1356, 2040)).astype(np.uint8)
+    assert abs(float(metrics.image_psnr(g8, hr)) - float(metrics.image_psnr(r8, hr))) < 1e-3
+
+
+def test_headline_v2_train_step_against_oracle(hip_device):
+    """LarvaNetV2 (tail exit over the un-materialised concatenation of 4 features, K = 192 merge
+    conv, (M+1)-way loss) at the headline batch: loss and all 88 gradients against the oracle."""
+    from oracle import larva_torch as T
+    m = _model("LarvaNetV2", FLAGS, training=True, seed=0)
+    sd = {k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()}
+    x, truth = _canonical_batch()
+    loss, _ = m._forward_backward(x.to(hip_device), truth.to(hip_device))
+    m._finish_backward()
+    torch.cuda.synchronize()
+    sd_req = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.set_num_threads(8)
+    ref_loss = T.multi_exit_loss(sd_req, x, truth, BLOCKS, v2=True)
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-5 * abs(float(ref_loss.detach()))
+    n = 0
+    for k, p in m.model.named_parameters():
+        ga, gb = p.grad.cpu().numpy(), sd_req[k].grad.numpy()
+        assert np.abs(ga - gb).max() <= 2e-4 * max(np.abs(gb).max(), 1e-30), k
+        n += 1
+    assert n == 88

@@ -25,6 +25,16 @@ def test_parse_args_chaining_returns_copy_and_leftovers():
     assert p2.val_volume == 3e9 and p2.lr == 1e-4 and p2.min_lr == 1e-7 and not hasattr(p2, "cooldown")
 
 
+def test_unsupported_interpolate_mode_is_refused_when_the_flags_are_parsed():
+    """The reference hands any --interpolate string to F.interpolate (models/LarvaNet.py:283-285);
+    only bicubic has a HIP kernel, and the refusal names what is supported."""
+    import importlib
+    m = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
+    with pytest.raises(ValueError, match="bicubic"):
+        m.parse_args(["--num_modules=1", "--num_blocks=1", "--interpolate=bilinear"])
+    m.parse_args(["--num_modules=1", "--num_blocks=1", "--interpolate=bicubic"])
+
+
 def test_prepare_validates_scales_and_block_list():
     m, _, _ = _make("LarvaNet", ["--num_modules=2", "--num_blocks=2,2"])
     with pytest.raises(ValueError):

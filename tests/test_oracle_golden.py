@@ -192,3 +192,50 @@ def test_upscale_psnr_f10(golden):
     np.testing.assert_allclose(up, g["up"], rtol=0, atol=2e-4)
     o8 = R.image_to_uint8(up)
     assert abs(R.image_psnr(o8, R.image_to_uint8(g["hr"])) - float(g["psnr"])) < 1e-3
+
+
+def _canonical_batch():
+    x = torch.rand(16, 3, 48, 48, generator=torch.Generator().manual_seed(0)) * 255
+    truth = torch.rand(16, 3, 192, 192, generator=torch.Generator().manual_seed(1)) * 255
+    return x, truth
+
+
+def test_torch_restatement_headline_train_steps_f11(golden):
+    """The oracle's training step at the HEADLINE configuration (M4B4, 16x3x48x48) against the
+    reference's own train_step_larva (models/LarvaNet.py:98-114): 3 losses, all 82 gradients of
+    step 1 (sampled values + |g| sums), weights after 3 AdamW steps."""
+    g = golden("f11_m4b4_train_steps.npz")
+    blocks = [4, 4, 4, 4]
+    torch.set_num_threads(4)
+    x, truth = _canonical_batch()
+    sd = T.init_state_dict(blocks, seed=0)
+    keys = [k[5:] for k in g.files if k.startswith("gidx.")]
+    assert sorted(keys) == sorted(sd) and len(keys) == 82
+    losses1, grads = T.train_steps(sd, x, truth, blocks, steps=1)
+    for k in keys:
+        gn = grads[k].numpy()
+        tol = 2e-5 * float(g["gmax." + k])
+        assert np.abs(gn.ravel()[g["gidx." + k]] - g["gval." + k]).max() <= tol, k
+        assert abs(np.abs(gn.astype(np.float64)).sum() - float(g["gabs." + k])) <= 1e-4 * float(g["gabs." + k]), k
+    np.testing.assert_allclose(losses1[0], g["losses"][0], rtol=1e-6)
+    sd = T.init_state_dict(blocks, seed=0)
+    losses, _ = T.train_steps(sd, x, truth, blocks, steps=3)
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-6)
+    flat = np.concatenate([sd[k].numpy().ravel() for k in sorted(sd)])
+    np.testing.assert_allclose(flat[::211], g["after3_sample"], rtol=0, atol=2e-6)
+
+
+def test_torch_restatement_canonical_uint8_protocol_f12(golden):
+    """Canonical forward -> validate.py uint8 protocol: image bytes and per-image PSNR against the
+    synthetic truth as the reference produces them."""
+    g = golden("f12_m4b4_uint8.npz")
+    torch.set_num_threads(4)
+    x, truth = _canonical_batch()
+    sd = T.init_state_dict([4, 4, 4, 4], seed=0)
+    with torch.no_grad():
+        y = T.forward(sd, x, [4, 4, 4, 4]).numpy()
+    y8 = np.stack([R.image_to_uint8(im) for im in y])
+    t8 = np.stack([R.image_to_uint8(im) for im in truth.numpy()])
+    assert np.array_equal(y8[0], g["u8_img0"]) and np.array_equal(y8[15], g["u8_img15"])
+    psnr = np.array([R.image_psnr(y8[i], t8[i]) for i in range(16)])
+    np.testing.assert_allclose(psnr, g["psnr_vs_truth"], rtol=0, atol=1e-6)
