@@ -162,7 +162,8 @@ def test_canonical_forward_uint8_protocol_f6_f12(hip_device, golden):
     # the device-side PSNR kernel (validate_for_train's path) gives the host protocol's number
     from larvanet_amd import kernels as K
     out0 = torch.from_numpy(y[3]).to(hip_device)
-    assert abs(K.psnr_u8(out0, torch.from_numpy(t8[3]).to(hip_device)) - psnr[3]) < 1e-9
+    # (exact integer sum on the device, float32 mean on the host: equal to ~1e-7 dB)
+    assert abs(K.psnr_u8(out0, torch.from_numpy(t8[3]).to(hip_device)) - psnr[3]) < 1e-5
 
 
 @pytest.mark.parametrize("name", ["LarvaNet", "LarvaNetV2"])

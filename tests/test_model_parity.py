@@ -102,9 +102,8 @@ def test_canonical_forward_f6(hip_device, golden):
         y = m.model(x).cpu().numpy()
     assert y.shape == (16, 3, 192, 192)
     d = np.abs(y.ravel()[g["sample_idx"]] - g["sample_val"])
-    assert float(d.max()) < 5e-3, float(d.max())
-    # PSNR of our output against the reference's own output, after the validate.py uint8 protocol,
-    # is not computable from samples; the sampled max error above bounds it (<< 1e-3 dB).
+    assert float(d.max()) < 2e-3, float(d.max())
+    # (the uint8-protocol image and its PSNR at this size: tests/test_headline_parity.py, fixture F12)
 
 
 def test_upscale_psnr_f10(hip_device, golden):
