@@ -77,6 +77,25 @@ int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int c
                             float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
                             void* stream);
 
+/* Strip tiles: the same convolution (bit-identical results) with the image cut into 5 x 16 and
+ * 4 x 16 pixel tiles instead of 3 x 48.  Half a training batch (8 x 48 x 48) is then 256 workgroups
+ * like the whole batch is with 3 x 48 tiles, so the two halves of a batch can run as two independent
+ * layer chains on two streams -- two workgroups per CU, out of phase, each chain's launch boundary,
+ * prologue and store burst hidden under the other's K loop (the reference's layer chain,
+ * models/LarvaNet.py:205-220,236-248, has no other independent work to offer).
+ * larva_strip_tile_table: host-side table of ONE H x W image's tiles (entry = y0 | x0 << 12 |
+ * five_rows << 31; the two heights alternate along the table, `phase` 0 / 1 = it starts with a
+ * 5-row / 4-row tile), returns the tile count (> cap: table truncated) or < 0 when H cannot be cut
+ * into 5s and 4s.  larva_conv3x3_fwd_strips: larva_conv3x3_fwd_pitched with `tile_tab` = a DEVICE
+ * copy of larva_strip_tile_table(H, pitch); cout 48 and the 16-byte staging path only
+ * (hipErrorNotSupported otherwise).  An image sub-range of a batch is addressed by offsetting the
+ * operand pointers and passing its image count as N. */
+int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap);
+int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                             const float* bias, const float* res0, const float* res1, const float* mask,
+                             const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                             int relu, int mode, const unsigned* tile_tab, int tiles_per_image, void* stream);
+
 /* Measurement only: the same launch `iters` times with kernel-attached events
  * (hipExtLaunchKernelGGL); mean/min kernel duration in ms.  Synchronises the stream. */
 int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,

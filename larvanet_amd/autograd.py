@@ -100,6 +100,91 @@ class SideStreams:
         cls._keep.clear()
 
 
+class DualChain:
+    """The dependent layer chain of a step (head -> 32 body convs forward, 32 dgrads backward) as TWO
+    independent chains, one per half of the batch, on two streams.
+
+    Why: at the training shape a conv launch is 256 workgroups = one per CU, and a lone workgroup
+    cannot hide its own prologue (argument fetch, first LDS-DMA chunks), store burst and the launch
+    boundary: 15.4 us per layer against 13.2 us of MFMA-paced K loop.  Images are independent, so the
+    two halves of the batch are two independent chains; with the conv kernel's strip tiles (5 x 16 /
+    4 x 16 pixels instead of 3 x 48, kernels.conv3x3(strips=...)) each half-batch layer is again a
+    256-workgroup launch, the two chains' launches share every CU two by two and run out of phase.
+    The second chain's tile table starts with the other tile height, so the two workgroups that meet
+    on a CU are a 5-row and a 4-row tile (4 + 3 MFMAs per k-step per SIMD, the 3 x 48 tile's 7):
+    13.8 us per full-batch layer (tools/bench_dual_chain.py).  Results are bit-identical to the
+    single chain (the K loop of every output pixel is unchanged).
+
+    Streams fork from the current stream at the first chained conv and join it again in join(): in
+    `lazy` mode (the plugin's step, whose graph has no other consumer in between) only where the
+    caller says so, otherwise at the end of every autograd node that used the chains.  Every tensor
+    a side stream touches is kept referenced until the join (the caching allocator would otherwise
+    hand its memory to a later allocation on the main stream)."""
+
+    enabled = False      # set by StepScope
+    lazy_fwd = False
+    lazy_bwd = False
+    max_workgroups = 512   # one full-batch launch with more 3 x 48 tiles than this already overlaps by itself
+    _streams = {}
+    _forked = False
+    _keep = []
+
+    @classmethod
+    def wants(cls, n, h, p):
+        """Should a conv over [n][*][h][p] run as two half-batch strip-tile launches?"""
+        if not cls.enabled or n < 2 or p % 4:
+            return False
+        if n * ((h + 2) // 3) * ((p + 47) // 48) > cls.max_workgroups:
+            return False
+        return K.strip_tile_table(h, p, torch.device("cuda", torch.cuda.current_device())) is not None
+
+    @classmethod
+    def _stream(cls, k):
+        key = (torch.cuda.current_device(), k)
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=key[0])
+        return cls._streams[key]
+
+    @classmethod
+    def conv(cls, srcs, wpk, cout, **kw):
+        """kernels.conv3x3 for a link of the chain (same arguments, `out` allocated here)."""
+        first = srcs if isinstance(srcs, torch.Tensor) else srcs[0]
+        n, _, h, p = (int(v) for v in first.shape)
+        if kw.get("logical_w") is not None or kw.get("shuffle") or not cls.wants(n, h, p):
+            if cls._forked:      # a link that does not split: back to one stream first
+                cls.join()
+            return K.conv3x3(srcs, wpk, cout, **kw)
+        out = torch.empty((n, cout, h, p), device=first.device, dtype=torch.float32)
+        cur = torch.cuda.current_stream()
+        if not cls._forked:
+            for k in range(2):
+                cls._stream(k).wait_stream(cur)
+            cls._forked = True
+        cls._keep.append(out)
+        cls._keep.extend([srcs] if isinstance(srcs, torch.Tensor) else list(srcs))
+        cls._keep.extend(t for t in (wpk, kw.get("bias"), kw.get("mask"), kw.get("res0"), kw.get("res1")) if t is not None)
+        half = n // 2
+        for k, rng in enumerate(((0, half), (half, n))):
+            with torch.cuda.stream(cls._stream(k)):
+                K.conv3x3(srcs, wpk, cout, out=out, images=rng, strips=2 if k else True, **kw)
+        return out
+
+    @classmethod
+    def join(cls):
+        if cls._forked:
+            cur = torch.cuda.current_stream()
+            for k in range(2):
+                cur.wait_stream(cls._stream(k))
+            cls._forked = False
+        cls._keep.clear()
+
+    @classmethod
+    def end_of_node(cls, backward):
+        """Called by an autograd node that used the chains, before it hands tensors back."""
+        if not (cls.lazy_bwd if backward else cls.lazy_fwd):
+            cls.join()
+
+
 class PackedConv:
     """Kernel-layout images of one conv weight in persistent device buffers.
 
@@ -406,8 +491,10 @@ class StepScope:
         return buf
 
     def __init__(self, side_streams=False, defer_wgrad=True, split_flush=False, joint_input_grads=True,
-                 seed_grad=None):
+                 seed_grad=None, dual_chain=False, lazy_chain_joins=(False, False)):
         self.seed_grad_value = seed_grad
+        self.dual_chain = dual_chain
+        self.lazy_chain_joins = lazy_chain_joins
         self.side_streams = side_streams
         self.defer_wgrad = defer_wgrad
         self.split_flush = split_flush
@@ -422,12 +509,15 @@ class StepScope:
         # (with side streams the exit and the next body run concurrently: keep them independent)
         JointInputGrad.active = bool(self.joint_input_grads) and gpu and not SideStreams.active
         JointInputGrad.reset()
+        DualChain.enabled = bool(self.dual_chain) and gpu and not SideStreams.active
+        DualChain.lazy_fwd, DualChain.lazy_bwd = (bool(v) and DualChain.enabled for v in self.lazy_chain_joins)
         StepScope.depth += 1
         StepScope.seed_grad = self.seed_grad_value
         return self
 
     def __exit__(self, exc_type, *exc):
         try:
+            DualChain.join()   # the dgrad chains end here; the queued weight gradients read what they wrote
             if SideStreams.active:
                 SideStreams.join()
             if exc_type is None:
@@ -441,6 +531,7 @@ class StepScope:
             StepScope.seed_grad = None
             DeferredWgrad._pending = {}
             SideStreams.active = False
+            DualChain.enabled = DualChain.lazy_fwd = DualChain.lazy_bwd = False
             DeferredWgrad.active = False
             JointInputGrad.active = False
             JointInputGrad.reset()
@@ -501,7 +592,8 @@ class HeadFn(torch.autograd.Function):
         x16 = StepScope.padded_input((N, 16, H, P), x.device)  # channels C..15 / columns W..P-1 stay zero
         x16[:, :C, :, :W] = x
         (fwd, _), = pc.get()
-        out = K.conv3x3(x16, fwd, int(weight.shape[0]), bias=bias.detach(), logical_w=_lw())
+        out = DualChain.conv(x16, fwd, int(weight.shape[0]), bias=bias.detach(), logical_w=_lw())
+        DualChain.end_of_node(False)
         ctx.save_for_backward(x16)
         ctx.wshape = tuple(weight.shape)
         ctx.pc = pc
@@ -513,6 +605,8 @@ class HeadFn(torch.autograd.Function):
         dy = dy.contiguous()
         cout, cin = ctx.wshape[0], ctx.wshape[1]
         tw, tb = _targets(ctx.pc)
+        if not (tw is not None and DeferredWgrad.active):
+            DualChain.join()   # dy comes off the two dgrad chains and is read right here
         (dw, db), = _wgrad([(dy, x16, ctx.wshape, 0, cin, tw, tb)], cout, 16, inplace=tw is not None)
         if tw is not None:
             return None, None, None, None
@@ -534,15 +628,16 @@ class BodyFn(torch.autograd.Function):
             (f1, _), = pcs[2 * j].get()
             (f2, _), = pcs[2 * j + 1].get()
             c = int(w1.shape[0])
-            h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True, logical_w=_lw())
+            h = DualChain.conv(fea, f1, c, bias=b1.detach(), relu=True, logical_w=_lw())
             if j == nb - 1:
-                nxt = K.conv3x3(h, f2, c, bias=b2.detach(), res0=fea, res1=x, logical_w=_lw())
+                nxt = DualChain.conv(h, f2, c, bias=b2.detach(), res0=fea, res1=x, logical_w=_lw())
             else:
-                nxt = K.conv3x3(h, f2, c, bias=b2.detach(), res0=fea, logical_w=_lw())
+                nxt = DualChain.conv(h, f2, c, bias=b2.detach(), res0=fea, logical_w=_lw())
             keep.append(h)
             if j < nb - 1:
                 keep.append(nxt)
             fea = nxt
+        DualChain.end_of_node(False)
         ctx.save_for_backward(*keep)
         ctx.pcs = pcs
         ctx.nb = nb
@@ -564,21 +659,25 @@ class BodyFn(torch.autograd.Function):
             h_j = keep[2 * j + 1]
             (_, bw1), = pcs[2 * j].get()
             (_, bw2), = pcs[2 * j + 1].get()
-            dh = K.conv3x3(g, bw2, c, mask=h_j)
+            dh = DualChain.conv(g, bw2, c, mask=h_j)
             jobs[2 * j + 1] = (g, h_j, ctx.wshape, 0, c) + _targets(pcs[2 * j + 1])
             jobs[2 * j] = (dh, fea_j, ctx.wshape, 0, c) + _targets(pcs[2 * j])
             if j > 0:
-                g = K.conv3x3(dh, bw1, c, res0=g)
+                g = DualChain.conv(dh, bw1, c, res0=g)
             else:
                 dh_leg = JointInputGrad.take(keep[0], pcs[0])
                 if dh_leg is None:
-                    dx = K.conv3x3(dh, bw1, c, res0=g, res1=dy)
+                    dx = DualChain.conv(dh, bw1, c, res0=g, res1=dy)
                 else:
                     # x is also read by the previous exit's leg, which left its last dgrad to us:
                     # d x = dgrad(conv1)(dh) + g + dy + dgrad(leg conv1)(dh_leg) as ONE launch over
                     # K = [dh ; dh_leg] with the two dgrad images stacked (JointBwd arena)
-                    dx = K.conv3x3([dh, dh_leg], pcs[0].joint.arena(dh.device), c, res0=g, res1=dy)
-        grads = _wgrad(jobs, c, c, inplace=all(_targets(pc)[0] is not None for pc in pcs))
+                    dx = DualChain.conv([dh, dh_leg], pcs[0].joint.arena(dh.device), c, res0=g, res1=dy)
+        inplace = all(_targets(pc)[0] is not None for pc in pcs)
+        if not (inplace and DeferredWgrad.active):
+            DualChain.join()       # the weight gradients are computed right here, on this stream
+        DualChain.end_of_node(True)
+        grads = _wgrad(jobs, c, c, inplace=inplace)
         flat = []
         for pc, (dw, db) in zip(pcs, grads):
             flat += [None, None] if _targets(pc)[0] is not None else [dw, db]

@@ -26,6 +26,7 @@
 // Roofline: fp32 MFMA (2*9*Cin*Cout FLOP per pixel; 41 472 at 48 channels) -- see DESIGN.md.
 #include "larva_common.h"
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 // Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
 // bit 0 = skip the MFMA blocks, bit 1 = skip the global->LDS staging, bit 2 = skip the
@@ -63,7 +64,32 @@ __device__ __forceinline__ void stamp(int) {}
 
 constexpr int kCh = 8;  // input channels per K chunk
 
-// Source of every LDS-DMA lane that falls outside the image (zero padding) or into layout padding.
+// Tile geometry of one workgroup: ROWS x COLS output pixels = ROWS * COLS/16 pixel groups of 16
+// consecutive pixels of a row; the input halo tile is (ROWS+2) rows of COLS+2 columns, staged with
+// the first wanted column (x0-1) at index 3 of a row of RS floats so that x0 sits on a 16-byte
+// boundary, channel planes PS floats apart (the smallest stride >= HALO*RS that is == 16 mod 32:
+// the two 16-lane halves of a ds_read_b32 group then land on disjoint banks).
+//   GeoWide  3 x 48: 9 pixel groups -- one workgroup per CU at the training shape (16 x 48 x 48:
+//            256 tiles), waves 7/7/7/6 of the 27 (cout group x pixel group) units;
+//   GeoS5 / GeoS4  5 x 16 and 4 x 16 "strip" tiles: 5 and 4 pixel groups, waves 4/4/4/3 and
+//            3/3/3/3 of 15 and 12 units -- the same 7 MFMAs per k-step per CU when one of each
+//            shares a CU.  Half a batch (8 x 48 x 48) is then ALSO 256 workgroups, so the two halves
+//            of a batch run as two independent layer chains on two streams, two workgroups per CU
+//            out of phase: one chain's prologue / store burst / launch boundary hides under the other
+//            chain's K loop (what a single dependent chain of 256-workgroup launches cannot do).
+template <int ROWS_, int COLS_>
+struct TileGeo {
+  static constexpr int ROWS = ROWS_, COLS = COLS_;
+  static constexpr int HALO = ROWS + 2;
+  static constexpr int PC = COLS / 16;
+  static constexpr int RS = COLS + 8;
+  static constexpr int PS = ((HALO * RS + 15) / 32) * 32 + 16;
+  static_assert(COLS % 16 == 0 && PS >= HALO * RS && PS % 32 == 16, "tile geometry");
+};
+using GeoWide = TileGeo<kTileRows, kTileCols>;
+using GeoS5 = TileGeo<5, 16>;
+using GeoS4 = TileGeo<4, 16>;
+static_assert(GeoWide::RS == kRS && GeoWide::PS == 304, "the 3 x 48 tile of larva_common.h");
 
 struct ConvArgs {
   const float* src[kMaxSrc];  // channel-concatenated inputs, each [N][cin_per_src][H][W]
@@ -81,6 +107,9 @@ struct ConvArgs {
                               // [W, pitch) of the inputs hold zeros and are written as zeros.
   int tiles_x, tiles_y;
   int nwg;                    // N * tiles_x * tiles_y = workgroups of this conv (gridDim.x)
+  // strip tiles (conv3x3_mfma_strip_kernel): tile_tab[t] = y0 | x0 << 12 | (5-row tile ? 1u << 31 : 0)
+  // for the tiles_x entries of ONE image (tiles_x = tiles per image, tiles_y = 1)
+  const unsigned* tile_tab;
   // ceil(2^40 / d) for d = tiles_x, tiles_y, cin_per_src / 8: the kernel's wave-uniform divisions
   // as one 64-bit multiply + shift (a runtime integer division is ~40 vector instructions, three of
   // them stood at the very start of every workgroup); exact while dividend * divisor < 2^40
@@ -105,14 +134,14 @@ enum Epi : int {
   kEpiCount = 7
 };
 
-template <int COUT>
+template <int COUT, typename G = GeoWide>
 struct ConvCfg {
   static constexpr int CT = COUT / 16;
   static constexpr int CS = cout_stride(COUT);
-  static constexpr int PS = 304;  // plane stride of a staged channel: >= 5*kRS and == 16 (mod 32)
-  // One stage = [8 channel planes, padded to 10 KiB][9*8 weight rows, padded to whole KiB]; every
-  // 1 KiB "piece" is what one wave-level LDS-DMA instruction writes.
-  static constexpr int IN_PIECES = 10;
+  static constexpr int PS = G::PS;  // plane stride of a staged channel
+  // One stage = [8 channel planes, padded to whole KiB][9*8 weight rows, padded to whole KiB]; every
+  // 1 KiB "piece" is what one wave-level LDS-DMA instruction writes.  (3 x 48 tile: 10 + 14 pieces.)
+  static constexpr int IN_PIECES = (kCh * PS + 255) / 256;
   static constexpr int IN_FLOATS = IN_PIECES * 256;
   static constexpr int IN_SLOTS_PER_PLANE = PS / 4;                         // 76 float4 slots
   static constexpr int W_USED = 9 * kCh * CS;
@@ -129,7 +158,7 @@ struct ConvCfg {
   static constexpr int THREADS_DMA = LOADER ? 320 : 256;
   static constexpr size_t LDS_BYTES_REG = 2 * STAGE_FLOATS * sizeof(float);
   // register-staged path
-  static constexpr int RIN_SLOTS = kCh * kHaloRows * (kRS / 4);             // 560 float4 slots
+  static constexpr int RIN_SLOTS = kCh * G::HALO * (G::RS / 4);             // 560 float4 slots (3 x 48)
   static constexpr int RIN_ITERS = (RIN_SLOTS + 255) / 256;
   static constexpr int RW_SLOTS = W_USED / 4;
   static constexpr int RW_ITERS = (RW_SLOTS + 255) / 256;
@@ -139,22 +168,22 @@ struct ConvCfg {
 // ---------------------------------------------------------------------------------------------
 // LDS-DMA staging (VEC path)
 // ---------------------------------------------------------------------------------------------
-template <int COUT>
+template <int COUT, typename G>
 struct DmaPlan {
   // Per piece i of this wave (piece index p = wave + 4 i, clamped): the lane's source offset in
   // BYTES relative to the chunk's image base (input pieces) or weight base (weight pieces), or
   // kDmaZero when the lane's 16 bytes are zero padding (the buffer range check then writes zeros).
   // Fixed for the whole kernel: chunks only move the two base addresses.
-  unsigned voff[ConvCfg<COUT>::NPW];
+  unsigned voff[ConvCfg<COUT, G>::NPW];
 };
 
 // WEIGHTS = the offsets of this wave's weight pieces (trivial: a linear image), else those of its
 // input pieces (halo tile decomposition + bounds).  Two passes so that the prologue can issue the
 // weight pieces before it has worked out the input pieces.
-template <int COUT, bool WEIGHTS>
+template <int COUT, typename G, bool WEIGHTS>
 __device__ __forceinline__ void make_plan(const ConvArgs& a, int wave, int lane, int y0, int x0,
-                                          DmaPlan<COUT>& pl) {
-  using C = ConvCfg<COUT>;
+                                          DmaPlan<COUT, G>& pl) {
+  using C = ConvCfg<COUT, G>;
 #pragma unroll
   for (int i = 0; i < C::NPW; ++i) {
     const int p = min(wave + 4 * i, C::PIECES - 1);  // surplus pieces repeat the last one (same bytes)
@@ -168,10 +197,10 @@ __device__ __forceinline__ void make_plan(const ConvArgs& a, int wave, int lane,
       const int slot = p * 64 + lane;
       const int ci = slot / C::IN_SLOTS_PER_PLANE;
       const int rem = slot - ci * C::IN_SLOTS_PER_PLANE;
-      const int r = rem / (kRS / 4);
-      const int q = rem - r * (kRS / 4);
+      const int r = rem / (G::RS / 4);
+      const int q = rem - r * (G::RS / 4);
       const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
-      const bool ok = ci < kCh && r < kHaloRows && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const bool ok = ci < kCh && r < G::HALO && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       if (!isw) pl.voff[i] = ok ? 4u * (unsigned)((ci * a.H + gy) * a.pitch + gx) : kDmaZero;
     }
   }
@@ -184,9 +213,9 @@ struct ChunkSrc {
   const float* wgt_ptr;
 };
 
-template <int COUT>
+template <int COUT, typename G>
 __device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int n) {
-  using C = ConvCfg<COUT>;
+  using C = ConvCfg<COUT, G>;
   const int c0 = chunk * kCh;
   const int s_idx = div_by_magic(chunk, a.magic_cps);
   const int c_in_src = c0 - s_idx * a.cin_per_src;
@@ -200,10 +229,10 @@ __device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int 
 
 // One 1 KiB piece: lane l's 16 bytes go to LDS byte address stage_addr + 1024 p + 16 l.  Scalar
 // work only: pick the descriptor, form the LDS address, issue.
-template <int COUT>
-__device__ __forceinline__ void dma_piece(const DmaPlan<COUT>& pl, int i, int wave, const ChunkSrc& cs,
+template <int COUT, typename G>
+__device__ __forceinline__ void dma_piece(const DmaPlan<COUT, G>& pl, int i, int wave, const ChunkSrc& cs,
                                           unsigned stage_addr) {
-  using C = ConvCfg<COUT>;
+  using C = ConvCfg<COUT, G>;
   const int p = min(wave + 4 * i, C::PIECES - 1);  // scalar; weight pieces follow the input pieces in LDS
   const bool isw = p >= C::IN_PIECES;
   i32x4 rsrc;
@@ -221,24 +250,24 @@ __device__ __forceinline__ void dma_piece(const DmaPlan<COUT>& pl, int i, int wa
 // has just vacated, and before the next barrier it waits until chunk c+1 has landed.  Chunks 0 and
 // 1 are still issued by the MFMA waves (four waves start the ring faster than one).
 // ---------------------------------------------------------------------------------------------
-template <int COUT>
+template <int COUT, typename G>
 struct LoaderPlan {
-  unsigned voff[ConvCfg<COUT>::PIECES];   // this lane's source offset of EVERY piece, or kDmaZero
+  unsigned voff[ConvCfg<COUT, G>::PIECES];   // this lane's source offset of EVERY piece, or kDmaZero
 };
 
-template <int COUT>
-__device__ __forceinline__ void make_loader_plan(const ConvArgs& a, int lane, int y0, int x0, LoaderPlan<COUT>& pl) {
-  using C = ConvCfg<COUT>;
+template <int COUT, typename G>
+__device__ __forceinline__ void make_loader_plan(const ConvArgs& a, int lane, int y0, int x0, LoaderPlan<COUT, G>& pl) {
+  using C = ConvCfg<COUT, G>;
 #pragma unroll
   for (int p = 0; p < C::PIECES; ++p) {
     if (p < C::IN_PIECES) {
       const int slot = p * 64 + lane;
       const int ci = slot / C::IN_SLOTS_PER_PLANE;
       const int rem = slot - ci * C::IN_SLOTS_PER_PLANE;
-      const int r = rem / (kRS / 4);
-      const int q = rem - r * (kRS / 4);
+      const int r = rem / (G::RS / 4);
+      const int q = rem - r * (G::RS / 4);
       const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
-      const bool ok = ci < kCh && r < kHaloRows && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const bool ok = ci < kCh && r < G::HALO && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       pl.voff[p] = ok ? 4u * (unsigned)((ci * a.H + gy) * a.pitch + gx) : kDmaZero;
     } else {
       const int ws = (p - C::IN_PIECES) * 64 + lane;
@@ -247,11 +276,11 @@ __device__ __forceinline__ void make_loader_plan(const ConvArgs& a, int lane, in
   }
 }
 
-template <int COUT>
+template <int COUT, typename G>
 __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int lane, int n, int y0, int x0) {
-  using C = ConvCfg<COUT>;
-  LoaderPlan<COUT> pl;
-  make_loader_plan<COUT>(a, lane, y0, x0, pl);
+  using C = ConvCfg<COUT, G>;
+  LoaderPlan<COUT, G> pl;
+  make_loader_plan<COUT, G>(a, lane, y0, x0, pl);
   const int last = a.n_chunks - 1;
   int stage = 0;
   for (int chunk = 0; chunk <= last; ++chunk) {
@@ -261,7 +290,7 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
     __builtin_amdgcn_sched_barrier(0);
     // past the end the last chunk is streamed again into a stage nobody reads: every wait stays
     // the same counted vmcnt(PIECES)
-    const ChunkSrc cs = chunk_src<COUT>(a, min(chunk + 2, last), n);
+    const ChunkSrc cs = chunk_src<COUT, G>(a, min(chunk + 2, last), n);
     const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
     const unsigned dst = lds_addr_of(smem + nstage * C::STAGE_FLOATS);
 #pragma unroll
@@ -276,24 +305,24 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
 // ---------------------------------------------------------------------------------------------
 // Register staging (!VEC path): same stage image, scalar global loads with per-element masks.
 // ---------------------------------------------------------------------------------------------
-template <int COUT>
+template <int COUT, typename G>
 struct RegStaging {
-  f32x4 in[ConvCfg<COUT>::RIN_ITERS];
-  f32x4 w[ConvCfg<COUT>::RW_ITERS];
+  f32x4 in[ConvCfg<COUT, G>::RIN_ITERS];
+  f32x4 w[ConvCfg<COUT, G>::RW_ITERS];
 };
 
-template <int COUT>
+template <int COUT, typename G>
 __device__ __forceinline__ void reg_load(const ConvArgs& a, const ChunkSrc& cs, int y0, int x0, int tid,
-                                         RegStaging<COUT>& st) {
-  using C = ConvCfg<COUT>;
+                                         RegStaging<COUT, G>& st) {
+  using C = ConvCfg<COUT, G>;
   const size_t plane = (size_t)a.H * a.pitch;
 #pragma unroll
   for (int i = 0; i < C::RIN_ITERS; ++i) {
     const int s = min(tid + i * 256, C::RIN_SLOTS - 1);
-    const int ci = s / (kHaloRows * (kRS / 4));
-    const int rem = s - ci * (kHaloRows * (kRS / 4));
-    const int r = rem / (kRS / 4);
-    const int q = rem - r * (kRS / 4);
+    const int ci = s / (G::HALO * (G::RS / 4));
+    const int rem = s - ci * (G::HALO * (G::RS / 4));
+    const int r = rem / (G::RS / 4);
+    const int q = rem - r * (G::RS / 4);
     const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
     const bool row_ok = gy >= 0 && gy < a.H;
     const float* row = cs.img_ptr + (size_t)ci * plane + (size_t)min(max(gy, 0), a.H - 1) * a.pitch;
@@ -314,18 +343,18 @@ __device__ __forceinline__ void reg_load(const ConvArgs& a, const ChunkSrc& cs, 
   }
 }
 
-template <int COUT>
-__device__ __forceinline__ void reg_store(float* stage, int tid, const RegStaging<COUT>& st) {
-  using C = ConvCfg<COUT>;
+template <int COUT, typename G>
+__device__ __forceinline__ void reg_store(float* stage, int tid, const RegStaging<COUT, G>& st) {
+  using C = ConvCfg<COUT, G>;
 #pragma unroll
   for (int i = 0; i < C::RIN_ITERS; ++i) {
     const int s = tid + i * 256;
     if (s < C::RIN_SLOTS) {
-      const int ci = s / (kHaloRows * (kRS / 4));
-      const int rem = s - ci * (kHaloRows * (kRS / 4));
-      const int r = rem / (kRS / 4);
-      const int q = rem - r * (kRS / 4);
-      *reinterpret_cast<f32x4*>(stage + ci * C::PS + r * kRS + 4 * q) = st.in[i];
+      const int ci = s / (G::HALO * (G::RS / 4));
+      const int rem = s - ci * (G::HALO * (G::RS / 4));
+      const int r = rem / (G::RS / 4);
+      const int q = rem - r * (G::RS / 4);
+      *reinterpret_cast<f32x4*>(stage + ci * C::PS + r * G::RS + 4 * q) = st.in[i];
     }
   }
 #pragma unroll
@@ -339,18 +368,18 @@ __device__ __forceinline__ void reg_store(float* stage, int tid, const RegStagin
 // MFMA block of one chunk
 // ---------------------------------------------------------------------------------------------
 // Operands of k-step `step` (= tap*2 + kk) of one chunk.
-template <int COUT, int NCT, int PG0, int NPG>
+template <int COUT, typename G, int NCT, int PG0, int NPG>
 __device__ __forceinline__ void read_operands(const float* a_base, const float* b_base, int step,
                                               float (&av)[NCT], float (&bv)[NPG]) {
-  using C = ConvCfg<COUT>;
+  using C = ConvCfg<COUT, G>;
   const int tap = step / (kCh / 4), kk = step % (kCh / 4);
   const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
   for (int c = 0; c < NCT; ++c) av[c] = a_base[(tap * kCh + kk * 4) * C::CS + c * 16];
 #pragma unroll
   for (int p = 0; p < NPG; ++p) {
-    const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
-    bv[p] = b_base[kk * 4 * C::PS + (prow + ky) * kRS + pcol * 16 + kx];
+    const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
+    bv[p] = b_base[kk * 4 * C::PS + (prow + ky) * G::RS + pcol * 16 + kx];
   }
 }
 
@@ -371,17 +400,17 @@ __device__ __forceinline__ void shadow_groups() {
 // (hipcc otherwise sinks every ds_read to just above its first use, lgkmcnt(0) per pair of
 // MFMAs; the sched_barriers pin "reads of s+1, [one LDS-DMA piece], MFMAs of s").
 // PREFETCH: the wave's NPW LDS-DMA pieces of the chunk two ahead are issued between k-steps.
-template <int COUT, int NCT, int PG0, int NPG, bool PREFETCH>
+template <int COUT, typename G, int NCT, int PG0, int NPG, bool PREFETCH>
 __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave, int lane,
-                                           f32x4 (&acc)[NCT][NPG], const DmaPlan<COUT>& pl, const ChunkSrc& nxt,
+                                           f32x4 (&acc)[NCT][NPG], const DmaPlan<COUT, G>& pl, const ChunkSrc& nxt,
                                            unsigned nxt_stage) {
-  using C = ConvCfg<COUT>;
+  using C = ConvCfg<COUT, G>;
   const int lr = lane & 15, lq = lane >> 4;
   const float* a_base = stage + C::IN_FLOATS + lq * C::CS + lr + ct0 * 16;
   const float* b_base = stage + lq * C::PS + lr + 3;
   constexpr int kEvery = C::STEPS / C::NPW > 0 ? C::STEPS / C::NPW : 1;
   float av[2][NCT], bv[2][NPG];
-  read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, 0, av[0], bv[0]);
+  read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, 0, av[0], bv[0]);
 #pragma unroll
   for (int step = 0; step < C::STEPS; ++step) {
 #if LARVA_SHADOW
@@ -392,7 +421,7 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
     // instead of in a block in front of them, and the LDS-DMA piece follows the first MFMA.
     __builtin_amdgcn_sched_barrier(0);
     if (step + 1 < C::STEPS)
-      read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+      read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
     constexpr int NMF = NCT * NPG;
     constexpr int NRD = NCT + NPG;
 #pragma unroll
@@ -401,19 +430,19 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
                                                                   acc[m / NPG][m % NPG], 0, 0, 0);
       if constexpr (PREFETCH) {
         if (m == 0 && step % kEvery == 0 && step / kEvery < C::NPW)
-          dma_piece<COUT>(pl, step / kEvery, wave, nxt, nxt_stage);
+          dma_piece<COUT, G>(pl, step / kEvery, wave, nxt, nxt_stage);
       }
     }
     shadow_groups<NMF, NRD, 0>();
     __builtin_amdgcn_sched_barrier(0);
 #else
     if (step + 1 < C::STEPS)
-      read_operands<COUT, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+      read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
     if constexpr (PREFETCH) {
       // unconditional (no branch inside the unrolled loop: a control-flow join makes hipcc wait
       // lgkmcnt(0), i.e. for the operand reads it has just issued)
       if (step % kEvery == 0 && step / kEvery < C::NPW)
-        dma_piece<COUT>(pl, step / kEvery, wave, nxt, nxt_stage);
+        dma_piece<COUT, G>(pl, step / kEvery, wave, nxt, nxt_stage);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -434,10 +463,10 @@ __device__ __forceinline__ void wait_and_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int COUT, bool VEC, int EPI, int NCT, int PG0, int NPG>
+template <int COUT, typename G, bool VEC, int EPI, int NCT, int PG0, int NPG>
 __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0, int wave, int n, int y0,
                                          int x0, int tid) {
-  using C = ConvCfg<COUT>;
+  using C = ConvCfg<COUT, G>;
   const int lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
 
@@ -467,7 +496,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
       for (int p = 0; p < NPG; ++p) {
-        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
         const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
         if constexpr (kShuffleEpi) {
           const int HH = 4 * a.H, WW = 4 * a.W;
@@ -505,28 +534,28 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     // flight.  Chunk c is followed in the ring by chunk c+1 and c+2; past the end the last chunk is
     // simply streamed again into a stage nobody reads any more, which keeps every wait the same
     // counted vmcnt and the MFMA loop free of branches.
-    DmaPlan<COUT> pl;
+    DmaPlan<COUT, G> pl;
     const int last = a.n_chunks - 1;
     if constexpr (!(LARVA_DIAG & 2)) {
-      const ChunkSrc cs0 = chunk_src<COUT>(a, 0, n);
+      const ChunkSrc cs0 = chunk_src<COUT, G>(a, 0, n);
       const unsigned st0 = lds_addr_of(smem), st1 = lds_addr_of(smem + C::STAGE_FLOATS);
       stamp(6);
-      make_plan<COUT, true>(a, wave, lane, y0, x0, pl);
+      make_plan<COUT, G, true>(a, wave, lane, y0, x0, pl);
 #pragma unroll
       for (int i = 0; i < C::NPW; ++i)
-        if (wave + 4 * i >= C::IN_PIECES) dma_piece<COUT>(pl, i, wave, cs0, st0);
+        if (wave + 4 * i >= C::IN_PIECES) dma_piece<COUT, G>(pl, i, wave, cs0, st0);
       __builtin_amdgcn_sched_barrier(0);
       stamp(7);
       load_early();
       stamp(14);
-      make_plan<COUT, false>(a, wave, lane, y0, x0, pl);
+      make_plan<COUT, G, false>(a, wave, lane, y0, x0, pl);
 #pragma unroll
       for (int i = 0; i < C::NPW; ++i)
-        if (wave + 4 * i < C::IN_PIECES) dma_piece<COUT>(pl, i, wave, cs0, st0);
+        if (wave + 4 * i < C::IN_PIECES) dma_piece<COUT, G>(pl, i, wave, cs0, st0);
       stamp(15);
-      const ChunkSrc cs1 = chunk_src<COUT>(a, min(1, last), n);
+      const ChunkSrc cs1 = chunk_src<COUT, G>(a, min(1, last), n);
 #pragma unroll
-      for (int i = 0; i < C::NPW; ++i) dma_piece<COUT>(pl, i, wave, cs1, st1);
+      for (int i = 0; i < C::NPW; ++i) dma_piece<COUT, G>(pl, i, wave, cs1, st1);
     }
     stamp(1);
     int stage = 0;
@@ -547,11 +576,11 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
       if constexpr (!(LARVA_DIAG & 1)) {
         if constexpr (!(LARVA_DIAG & 2) && !C::LOADER) {
-          const ChunkSrc nxt = chunk_src<COUT>(a, min(chunk + 2, last), n);
-          mfma_chunk<COUT, NCT, PG0, NPG, true>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt,
+          const ChunkSrc nxt = chunk_src<COUT, G>(a, min(chunk + 2, last), n);
+          mfma_chunk<COUT, G, NCT, PG0, NPG, true>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt,
                                                 lds_addr_of(smem + nstage * C::STAGE_FLOATS));
         } else {
-          mfma_chunk<COUT, NCT, PG0, NPG, false>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, ChunkSrc{},
+          mfma_chunk<COUT, G, NCT, PG0, NPG, false>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, ChunkSrc{},
                                                  0u);
         }
       }
@@ -562,10 +591,10 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     stamp(3);
   } else {
     // ---- register staging, 2 stages ------------------------------------------------------------
-    RegStaging<COUT> st;
+    RegStaging<COUT, G> st;
     if constexpr (!(LARVA_DIAG & 2)) {
-      reg_load<COUT>(a, chunk_src<COUT>(a, 0, n), y0, x0, tid, st);
-      reg_store<COUT>(smem, tid, st);
+      reg_load<COUT, G>(a, chunk_src<COUT, G>(a, 0, n), y0, x0, tid, st);
+      reg_store<COUT, G>(smem, tid, st);
     }
     __syncthreads();
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
@@ -573,12 +602,12 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       float* nxt = smem + ((chunk & 1) ^ 1) * C::STAGE_FLOATS;
       const bool more = chunk + 1 < a.n_chunks;
       if constexpr (!(LARVA_DIAG & 2)) {
-        if (more) reg_load<COUT>(a, chunk_src<COUT>(a, chunk + 1, n), y0, x0, tid, st);
+        if (more) reg_load<COUT, G>(a, chunk_src<COUT, G>(a, chunk + 1, n), y0, x0, tid, st);
       }
       if constexpr (!(LARVA_DIAG & 1))
-        mfma_chunk<COUT, NCT, PG0, NPG, false>(cur, ct0, wave, lane, acc, DmaPlan<COUT>{}, ChunkSrc{}, 0u);
+        mfma_chunk<COUT, G, NCT, PG0, NPG, false>(cur, ct0, wave, lane, acc, DmaPlan<COUT, G>{}, ChunkSrc{}, 0u);
       if constexpr (!(LARVA_DIAG & 2)) {
-        if (more) reg_store<COUT>(nxt, tid, st);
+        if (more) reg_store<COUT, G>(nxt, tid, st);
       }
       __syncthreads();
     }
@@ -604,7 +633,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
       for (int p = 0; p < NPG; ++p) {
-        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
         const int y = y0 + prow, x = x0 + pcol * 16 + lr;
         const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
         f32x4 v = acc[c][p] + bias[c];
@@ -617,7 +646,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
       for (int p = 0; p < NPG; ++p) {
-        const int pg = PG0 + p, prow = pg / 3, pcol = pg % 3;
+        const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
         const int y = y0 + prow, x = x0 + pcol * 16 + lr;
         const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
         const f32x4 v = acc[c][p] + bias[c];
@@ -646,46 +675,51 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
 #endif
 }
 
+// Fetch every kernel argument NOW, in one batch of scalar loads.  Left alone the compiler loads
+// each field in the block that first uses it: three dependent s_load round trips (~0.15 us each)
+// stood between kernel entry and the first LDS-DMA request.
+__device__ __forceinline__ void fetch_args(const ConvArgs& a) {
+  asm volatile("" ::"s"(a.src[0]), "s"(a.wpk), "s"(a.bias), "s"(a.out), "s"(a.cin_per_src), "s"(a.n_chunks), "s"(a.N),
+               "s"(a.H), "s"(a.W), "s"(a.pitch), "s"(a.tiles_x), "s"(a.tiles_y), "s"(a.magic_tx), "s"(a.magic_ty),
+               "s"(a.magic_cps), "s"(a.nwg), "s"(a.tile_tab));
+}
+
 // VEC: 2 workgroups per CU (launch bound 2 waves/SIMD caps the registers at 256).
 template <int COUT, bool VEC, int EPI>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
+  using G = GeoWide;
   if constexpr ((LARVA_DIAG & 8) != 0) return;
   stamp(0);
-  // Fetch every kernel argument NOW, in one batch of scalar loads.  Left alone the compiler loads
-  // each field in the block that first uses it: three dependent s_load round trips (~0.15 us each)
-  // stood between kernel entry and the first LDS-DMA request.
-  asm volatile("" ::"s"(a.src[0]), "s"(a.wpk), "s"(a.bias), "s"(a.out), "s"(a.cin_per_src), "s"(a.n_chunks), "s"(a.N),
-               "s"(a.H), "s"(a.W), "s"(a.pitch), "s"(a.tiles_x), "s"(a.tiles_y), "s"(a.magic_tx), "s"(a.magic_ty),
-               "s"(a.magic_cps), "s"(a.nwg));
+  fetch_args(a);
   const int tile = xcd_remap(blockIdx.x, a.nwg);
   const int t2 = div_by_magic(tile, a.magic_tx);
   const int tx = tile - t2 * a.tiles_x;
   const int n = div_by_magic(t2, a.magic_ty);
   const int ty = t2 - n * a.tiles_y;
-  const int x0 = tx * kTileCols, y0 = ty * kTileRows;
+  const int x0 = tx * G::COLS, y0 = ty * G::ROWS;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Convs form the dependent chain of a step; weight-gradient workgroups that share the CU run
   // at priority 0 and take the matrix pipe only when these waves cannot use it.
   __builtin_amdgcn_s_setprio(1);
 
-  if constexpr (VEC && ConvCfg<COUT>::LOADER) {
+  if constexpr (VEC && ConvCfg<COUT, G>::LOADER) {
     if (wave == 4) {
-      if constexpr (!(LARVA_DIAG & 2)) run_loader<COUT>(a, smem, tid & 63, n, y0, x0);
+      if constexpr (!(LARVA_DIAG & 2)) run_loader<COUT, G>(a, smem, tid & 63, n, y0, x0);
       return;
     }
   }
   // 9 pixel groups x CT cout groups, dealt to the 4 waves (one per SIMD) as evenly as a
   // rectangular (cout groups) x (pixel groups) ownership allows.
   if constexpr (COUT == 48) {  // 27 -> 7,7,7,6
-    if (wave < 3) run_role<COUT, VEC, EPI, 1, 0, 7>(a, smem, wave, wave, n, y0, x0, tid);
-    else run_role<COUT, VEC, EPI, 3, 7, 2>(a, smem, 0, wave, n, y0, x0, tid);
+    if (wave < 3) run_role<COUT, G, VEC, EPI, 1, 0, 7>(a, smem, wave, wave, n, y0, x0, tid);
+    else run_role<COUT, G, VEC, EPI, 3, 7, 2>(a, smem, 0, wave, n, y0, x0, tid);
   } else if constexpr (COUT == 32) {  // 18 -> 5,5,4,4
-    if (wave < 2) run_role<COUT, VEC, EPI, 1, 0, 5>(a, smem, wave, wave, n, y0, x0, tid);
-    else run_role<COUT, VEC, EPI, 1, 5, 4>(a, smem, wave - 2, wave, n, y0, x0, tid);
+    if (wave < 2) run_role<COUT, G, VEC, EPI, 1, 0, 5>(a, smem, wave, wave, n, y0, x0, tid);
+    else run_role<COUT, G, VEC, EPI, 1, 5, 4>(a, smem, wave - 2, wave, n, y0, x0, tid);
   } else {  // COUT == 64: 36 -> 9,9,9,9
     static_assert(COUT == 64, "unsupported channel count");
-    run_role<COUT, VEC, EPI, 1, 0, 9>(a, smem, wave, wave, n, y0, x0, tid);
+    run_role<COUT, G, VEC, EPI, 1, 0, 9>(a, smem, wave, wave, n, y0, x0, tid);
   }
 }
 
@@ -694,6 +728,39 @@ __global__ __launch_bounds__(VEC ? ConvCfg<COUT>::THREADS_DMA : 256, VEC ? 2 : 1
   extern __shared__ __attribute__((aligned(16))) float smem[];
   conv_tile<COUT, VEC, EPI>(a, smem);
 }
+
+// Strip tiles (48 output channels, LDS-DMA path): every workgroup looks its tile up in a table of
+// ONE image's tiles -- 5 x 16 or 4 x 16 pixels -- and runs the matching instantiation.  ROWS pixel
+// groups x 3 cout groups: waves 0..2 own one cout group x the first ROWS-1 pixel groups, wave 3 all
+// three cout groups of the last pixel group (15 units -> 4,4,4,3; 12 -> 3,3,3,3).
+template <int EPI, typename G>
+__device__ __forceinline__ void strip_roles(const ConvArgs& a, float* smem, int wave, int n, int y0, int x0, int tid) {
+  static_assert(ConvCfg<48, G>::LOADER, "the strip kernel is launched with a loader wave");
+  if (wave == 4) {
+    run_loader<48, G>(a, smem, tid & 63, n, y0, x0);
+    return;
+  }
+  if (wave < 3) run_role<48, G, true, EPI, 1, 0, G::ROWS - 1>(a, smem, wave, wave, n, y0, x0, tid);
+  else run_role<48, G, true, EPI, 3, G::ROWS - 1, 1>(a, smem, 0, wave, n, y0, x0, tid);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(320, 2) void conv3x3_mfma_strip_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  fetch_args(a);
+  const int tile = xcd_remap(blockIdx.x, a.nwg);
+  const int n = div_by_magic(tile, a.magic_tx);   // tiles_x = tiles per image
+  const unsigned e = a.tile_tab[tile - n * a.tiles_x];
+  const int y0 = (int)(e & 0xfffu), x0 = (int)((e >> 12) & 0xfffu);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_amdgcn_s_setprio(1);
+  if (e >> 31) strip_roles<EPI, GeoS5>(a, smem, wave, n, y0, x0, tid);
+  else strip_roles<EPI, GeoS4>(a, smem, wave, n, y0, x0, tid);
+}
+constexpr size_t kStripLdsBytes =
+    ConvCfg<48, GeoS5>::LDS_BYTES_DMA > ConvCfg<48, GeoS4>::LDS_BYTES_DMA ? ConvCfg<48, GeoS5>::LDS_BYTES_DMA
+                                                                          : ConvCfg<48, GeoS4>::LDS_BYTES_DMA;
 
 // Several INDEPENDENT convolutions of one shape and one epilogue in one launch (blockIdx.y = job).
 // A single conv launch at the training shape is one workgroup per CU and spends half of its time
@@ -843,6 +910,32 @@ static hipError_t launch_batch(const ConvBatch& b, int njobs, int epi, hipStream
     case kEpiRes2: return launch_batch_e<COUT, kEpiRes2>(b, njobs, stream);
     case kEpiShuffle: return launch_batch_e<COUT, kEpiShuffle>(b, njobs, stream);
     case kEpiShuffleBase: return launch_batch_e<COUT, kEpiShuffleBase>(b, njobs, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int EPI>
+static hipError_t launch_strip_e(const ConvArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_strip_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStripLdsBytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_mfma_strip_kernel<EPI>), dim3(a.nwg), dim3(320), kStripLdsBytes, stream, a);
+  return hipGetLastError();
+}
+
+static hipError_t launch_strip(const ConvArgs& a, int epi, hipStream_t stream) {
+  switch (epi) {
+    case kEpiPlain: return launch_strip_e<kEpiPlain>(a, stream);
+    case kEpiRelu: return launch_strip_e<kEpiRelu>(a, stream);
+    case kEpiMask: return launch_strip_e<kEpiMask>(a, stream);
+    case kEpiRes1: return launch_strip_e<kEpiRes1>(a, stream);
+    case kEpiRes2: return launch_strip_e<kEpiRes2>(a, stream);
+    case kEpiShuffle: return launch_strip_e<kEpiShuffle>(a, stream);
+    case kEpiShuffleBase: return launch_strip_e<kEpiShuffleBase>(a, stream);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1007,6 +1100,88 @@ int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int c
     case 48: return (int)launch_batch<48>(b, njobs, epi0, s);
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+// Strip tiles.  larva_strip_tile_table fills `tab` (host memory, `cap` entries) with the tiles of ONE
+// H x W image -- column strips 16 pixels wide, each cut into 5-row and 4-row tiles (their counts kept
+// as equal as the heights allow: a 5-row and a 4-row tile sharing a CU issue 4 + 3 MFMAs per k-step on
+// every SIMD, exactly what the 3 x 48 tile does) -- and returns their number (if it exceeds `cap`
+// nothing beyond `cap` is written), or a negative value for an H that cannot be cut (1, 2, 3, 6, 7,
+// 11).  Entry = y0 | x0 << 12 | (5 rows ? 1u << 31 : 0).  phase 0 / 1: the table starts with a
+// 5-row / 4-row tile.
+int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap) {
+  if (H <= 0 || W <= 0 || H >= 4096 || W >= 4096 || !tab || cap < 0) return -1;
+  const char* pref = getenv("LARVA_STRIP_PREFER");   // experiment: "4" = as many 4-row tiles as possible, "5" = 5-row
+  const int prefer = pref ? atoi(pref) : 0;
+  // pass 1: how each 16-column strip is cut (5 a + 4 b = H, the running counts of the two heights kept close)
+  int n5 = 0, n4 = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    int fives = 0, fours = 0, i5 = 0, i4 = 0;
+    for (int x0 = 0; x0 < W; x0 += 16) {
+      int best_a = -1, best_gap = 1 << 30;
+      for (int a5 = 0; 5 * a5 <= H; ++a5) {
+        if ((H - 5 * a5) % 4) continue;
+        const int b4 = (H - 5 * a5) / 4;
+        const int gap = (fives + a5) - (fours + b4);
+        int g = gap < 0 ? -gap : gap;
+        if (prefer == 4) g = a5;
+        if (prefer == 5) g = b4;
+        if (g < best_gap) { best_gap = g; best_a = a5; }
+      }
+      if (best_a < 0) return -2;
+      const int a5 = best_a, b4 = (H - 5 * a5) / 4;
+      fives += a5; fours += b4;
+      if (pass == 0) continue;
+      // pass 2: table slots.  The two heights ALTERNATE along the table as far as their counts allow
+      // (slot 2k = the k-th tile of the kind `phase` starts with, slot 2k+1 = the k-th of the other
+      // kind, the surplus kind behind): two launches whose tables start with different kinds put
+      // tiles of different heights at equal block indices.
+      int y = 0, ra = a5, rb = b4;
+      while (ra > 0 || rb > 0) {
+        const bool five = ra > 0 && (rb == 0 || (long long)ra * b4 >= (long long)rb * a5);
+        const int k = five ? i5++ : i4++;
+        const int mine = five ? n5 : n4, other = five ? n4 : n5;
+        const bool first = five == (phase == 0);   // does this kind take the even slots?
+        int slot;
+        if (k < other) slot = 2 * k + (first ? 0 : 1);
+        else slot = 2 * other + (k - other);       // surplus of the larger kind
+        (void)mine;
+        if (slot < cap) tab[slot] = (unsigned)y | ((unsigned)x0 << 12) | (five ? 0x80000000u : 0u);
+        y += five ? 5 : 4;
+        if (five) --ra; else --rb;
+      }
+    }
+    n5 = fives; n4 = fours;
+  }
+  return n5 + n4;
+}
+
+// larva_conv3x3_fwd_pitched on strip tiles: `tile_tab` = DEVICE copy of larva_strip_tile_table(H,
+// pitch) with `tiles_per_image` entries.  cout = 48 and the 16-byte staging path only (pitch % 4 == 0,
+// 16-byte aligned tensors), otherwise hipErrorNotSupported.  Results are bit-identical to
+// larva_conv3x3_fwd_pitched: every output's K loop runs in the same order, only the assignment of
+// pixels to workgroups differs.
+int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                             const float* bias, const float* res0, const float* res1, const float* mask,
+                             const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                             int relu, int mode, const unsigned* tile_tab, int tiles_per_image, void* stream) {
+  if (cout != 48) return (int)hipErrorNotSupported;
+  if (!tile_tab || tiles_per_image < 1) return (int)hipErrorInvalidValue;
+  ConvArgs a;
+  bool aligned;
+  int epi;
+  const int rc = conv_build(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, H, W, pitch, relu,
+                            mode, a, aligned, epi);
+  if (rc) return rc;
+  if (!aligned) return (int)hipErrorNotSupported;
+  if ((long long)N * tiles_per_image >= (1ll << 20)) return (int)hipErrorInvalidValue;  // div_by_magic range
+  a.tile_tab = tile_tab;
+  a.tiles_x = tiles_per_image;
+  a.tiles_y = 1;
+  a.magic_tx = div_magic(tiles_per_image);
+  a.magic_ty = div_magic(1);
+  a.nwg = N * tiles_per_image;
+  return (int)launch_strip(a, epi, (hipStream_t)stream);
 }
 
 #if LARVA_DIAG & 32

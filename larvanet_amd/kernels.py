@@ -87,14 +87,45 @@ def pack_weights_batch(jobs):
         hip_lib.check(code, "larva_pack_weights_batch")
 
 
+_STRIP_TABLES = {}
+
+
+def strip_tile_table(H, P, device, phase=0):
+    """Device copy of the library's strip-tile table of one H x P image (cached per shape and
+    device; built and uploaded outside any stream capture) -> (tensor, tiles per image) or None when
+    the height cannot be cut into 5- and 4-row tiles."""
+    key = (int(H), int(P), str(device), int(phase))
+    hit = _STRIP_TABLES.get(key)
+    if hit is None:
+        lib = hip_lib.load()
+        cap = 4 * ((H + 3) // 4) * ((P + 15) // 16) + 16
+        buf = (ctypes.c_uint * cap)()
+        n = int(lib.larva_strip_tile_table(int(H), int(P), int(phase), buf, cap))
+        if n <= 0 or n > cap:
+            hit = False
+        else:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("larvanet_amd: strip-tile table for %dx%d requested during stream capture "
+                                   "(run the step once outside the capture first)" % (H, P))
+            import numpy as np
+            # (entries use bit 31: the raw 32-bit patterns travel as int32)
+            hit = (torch.from_numpy(np.frombuffer(buf, dtype=np.int32, count=n).copy()).to(device), n)
+        _STRIP_TABLES[key] = hit
+    return hit or None
+
+
 def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=None,
-            shuffle=False, base=None, out=None, logical_w=None):
+            shuffle=False, base=None, out=None, logical_w=None, images=None, strips=False):
     """Fused 3x3 conv over the channel concatenation of `srcs` (list of [N][c][H][P]).
 
     shuffle=False: returns [N][cout][H][P]; shuffle=True: returns PixelShuffle(4) layout
     [N][cout/16][4H][4W] (+ base).  logical_w: the image is W = logical_w <= P columns wide and
     the tensors' rows are padded to the pitch P (columns [W, P) hold zeros) -- lets widths that
-    are not a multiple of 4 use the 16-byte staging path."""
+    are not a multiple of 4 use the 16-byte staging path.
+    images=(lo, hi): only images [lo, hi) of the batch are computed (every operand is the full-batch
+    tensor; the other images of `out` are left untouched).  strips=True (or 2: the tile table
+    starts with the other tile height): 5 x 16 / 4 x 16 tiles instead of 3 x 48 (same results bit for
+    bit; see larva_conv3x3_fwd_strips) where the shape allows, else the regular tiles."""
     lib = hip_lib.load()
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
@@ -116,10 +147,28 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     if out is None:
         out = torch.empty(hr if shuffle else full, device=srcs[0].device, dtype=torch.float32)
     _chk(out, "out", hr if shuffle else full)
-    code = lib.larva_conv3x3_fwd_pitched(
-        hip_lib.ptr_array(ptrs), len(srcs), cps, wpk.data_ptr(), _opt(bias, "bias", (cout,)),
-        _opt(res0, "res0", full), _opt(res1, "res1", full), _opt(mask, "mask", full),
-        _opt(base, "base", hr), out.data_ptr(), N, cout, H, W, P, 1 if relu else 0, 1 if shuffle else 0, _stream())
+    lo, hi = (0, N) if images is None else (int(images[0]), int(images[1]))
+    if not 0 <= lo < hi <= N:
+        raise RuntimeError("larvanet_amd: image range [%d, %d) outside the batch of %d" % (lo, hi, N))
+
+    def at(ptr, per_image_floats):   # the same operand, starting at image `lo`
+        return None if ptr is None else ptr + 4 * lo * per_image_floats
+
+    lr_img, hr_img = H * P, 16 * H * W
+    args = (hip_lib.ptr_array([at(p, cps * lr_img) for p in ptrs]), len(srcs), cps, wpk.data_ptr(),
+            _opt(bias, "bias", (cout,)), at(_opt(res0, "res0", full), cout * lr_img),
+            at(_opt(res1, "res1", full), cout * lr_img), at(_opt(mask, "mask", full), cout * lr_img),
+            at(_opt(base, "base", hr), (cout // 16) * hr_img),
+            at(out.data_ptr(), (cout // 16) * hr_img if shuffle else cout * lr_img),
+            hi - lo, cout, H, W, P, 1 if relu else 0, 1 if shuffle else 0)
+    if strips and cout == 48:
+        tab = strip_tile_table(H, P, out.device, phase=1 if strips == 2 else 0)
+        if tab is not None:
+            code = lib.larva_conv3x3_fwd_strips(*args, tab[0].data_ptr(), tab[1], _stream())
+            if code != 801:   # hipErrorNotSupported: unaligned operands -> the regular tiles below
+                hip_lib.check(code, "larva_conv3x3_fwd_strips")
+                return out
+    code = lib.larva_conv3x3_fwd_pitched(*args, _stream())
     hip_lib.check(code, "larva_conv3x3_fwd")
     return out
 

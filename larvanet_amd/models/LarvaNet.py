@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .. import dist as ldist
 from .. import kernels as K
-from ..autograd import (BodyFn, ExitFn, ExitsFn, GradBucket, HeadFn, L1LossFn, LegFn, LossTerm, PackedConv, PaddedWidth, mean_of_terms,
+from ..autograd import (BodyFn, DualChain, ExitFn, ExitsFn, GradBucket, HeadFn, L1LossFn, LegFn, LossTerm, PackedConv, PaddedWidth, mean_of_terms,
                         SideStreams, StepScope, pack_all)
 from ..optim import FlatAdamW, flatten_parameters
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
@@ -242,6 +242,8 @@ class LarvaNet(BaseModel):
         self.l1_grad_in_forward = os.environ.get("LARVA_L1_GRAD_FWD", "1") != "0"
         # data parallel: all-reduce the first half of the bucket beside the second half's wgrad kernels
         self.overlap_allreduce = os.environ.get("LARVA_OVERLAP_ALLREDUCE", "1") != "0"
+        # the body chain as two half-batch chains of strip-tile launches on two streams (autograd.DualChain)
+        self.dual_chain = os.environ.get("LARVA_DUAL_CHAIN", "1") != "0"
 
     # ------------------------------------------------------------------ flags
     def _add_args(self, parser):
@@ -375,14 +377,15 @@ class LarvaNet(BaseModel):
         """Forward through every exit (models/LarvaNet.py:102-109). Returns (loss, last output)."""
         net = self.model
         net.refresh_packed_weights()
+        base = net.base(input_tensor)   # (before the head: the layer chain that starts there may fork into two streams)
         fea = net.head(input_tensor)
-        base = net.base(input_tensor)
         if self._exits_batched():
             # the exits do not feed the bodies: run the body chain first, then all exits together
             feas = []
             for i in range(self.args.num_modules):
                 fea = getattr(net, "body_%d" % i)(fea)
                 feas.append(fea)
+            DualChain.join()   # the two half-batch chains meet again: the exits read whole tensors
             out, terms = self._all_exits(feas, base, truth_tensor)
             return mean_of_terms(terms), out
         terms = []
@@ -402,9 +405,20 @@ class LarvaNet(BaseModel):
 
     def _scope(self):
         # seed_grad: _forward_backward seeds loss.backward() with _grad_one and nothing scales the loss
+        # chains are joined only after the body loop (forward) / at the end of backward when nothing
+        # else reads a chain tensor in between: batched exits after the bodies; and in backward one
+        # consumer per body output (joint input gradients) with every weight gradient deferred
+        lazy_fwd = self._exits_batched()
+        lazy_bwd = (lazy_fwd and self.joint_input_grads and self.defer_wgrad and self._single_consumer_features()
+                    and getattr(self, "grad_bucket", None) is not None and self.grad_bucket.intact(self.model))
         return StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad,
                          split_flush=self._split_backward(), joint_input_grads=self.joint_input_grads,
-                         seed_grad=1.0 if self.l1_grad_in_forward else None)
+                         seed_grad=1.0 if self.l1_grad_in_forward else None,
+                         dual_chain=self.dual_chain and not self.use_side_streams, lazy_chain_joins=(lazy_fwd, lazy_bwd))
+
+    def _single_consumer_features(self):
+        """Is every body output read by its exit and the next body only (V2's tail reads them too)?"""
+        return True
 
     def _split_backward(self):
         """Data parallel with in-place gradients: backward ends in two halves so that the

@@ -11,7 +11,7 @@ state_dict adds tail.merge_conv.{weight,bias} and tail.recon_block.{0,2}.{weight
 import torch
 import torch.nn as nn
 
-from ..autograd import LegFn, MergeFn, PackedConv, mean_of_terms
+from ..autograd import DualChain, LegFn, MergeFn, PackedConv, mean_of_terms
 from . import LarvaNet as V1
 from .LarvaNet import NUM_FILTERS, _conv, _require_hip, init_conv
 
@@ -95,18 +95,22 @@ class LarvaNet(V1.LarvaNet):
     def _num_loss_terms(self):
         return self.args.num_modules + 1
 
+    def _single_consumer_features(self):
+        return False   # the tail's merge conv reads every body output: autograd adds its gradient on the main stream
+
     def _exit_losses(self, input_tensor, truth_tensor):
         """models/LarvaNetV2.py:104-123: every exit plus the tail, / (M + 1)."""
         net = self.model
         net.refresh_packed_weights()
+        base = net.base(input_tensor)   # (before the head: the layer chain that starts there may fork into two streams)
         fea = net.head(input_tensor)
-        base = net.base(input_tensor)
         terms = []
         feats = []
         if self._exits_batched():
             for i in range(self.args.num_modules):
                 fea = getattr(net, "body_%d" % i)(fea)
                 feats.append(fea)
+            DualChain.join()
             _, terms = self._all_exits(feats, base, truth_tensor)
         else:
             for i in range(self.args.num_modules):

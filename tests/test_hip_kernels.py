@@ -594,3 +594,50 @@ def test_wgrad_seeded_shape_fuzz(hip_device):
             tag = "case %d job %d N%d H%d W%d %dx%d splits %d" % (case, i, N, H, W, cout, cin, splits)
             _report(tag + " dw", j["dw"].cpu().numpy(), dw_ref, 5e-5)
             _report(tag + " db", j["db"].cpu().numpy(), db_ref, 5e-5)
+
+
+@pytest.mark.parametrize("N,H,W,kind,images", [(4, 48, 48, "relu", None), (4, 48, 48, "res2", (1, 3)),
+                                                (3, 13, 20, "mask", (0, 2)), (2, 17, 36, "shuffle", None),
+                                                (5, 9, 52, "res1", (2, 5)), (2, 48, 48, "k96", None),
+                                                (16, 48, 48, "relu", (8, 16)), (2, 8, 16, "plain", None)])
+def test_strip_tiles_and_image_ranges_match_the_wide_tiles_bit_for_bit(hip_device, N, H, W, kind, images):
+    """larva_conv3x3_fwd_strips (5 x 16 / 4 x 16 tiles, what the two half-batch chains of the training
+    step run) against the 3 x 48 tiles: the K loop of every output runs in the same order, so the
+    results are identical bit for bit; an image range leaves the other images of `out` untouched."""
+    from larvanet_amd import kernels as K
+    rng = np.random.default_rng(N * 100 + H + W)
+    C = 48
+    n_src = 2 if kind == "k96" else 1
+    xs = [_dev(_rand(rng, (N, C, H, W), 20.0), hip_device) for _ in range(n_src)]
+    w = _dev(_rand(rng, (C, C * n_src, 3, 3), 0.05), hip_device)
+    b = _dev(_rand(rng, (C,), 1.0), hip_device)
+    fwd, _ = K.pack_weights(w, want_bwd=False)
+    kw = {"bias": b}
+    if kind == "relu":
+        kw["relu"] = True
+    elif kind == "mask":
+        kw["mask"] = _dev(_rand(rng, (N, C, H, W), 1.0), hip_device)
+    elif kind in ("res1", "res2", "k96"):
+        kw["res0"] = _dev(_rand(rng, (N, C, H, W), 5.0), hip_device)
+        if kind != "res1":
+            kw["res1"] = _dev(_rand(rng, (N, C, H, W), 5.0), hip_device)
+    elif kind == "shuffle":
+        kw["shuffle"] = True
+        kw["base"] = _dev(_rand(rng, (N, 3, 4 * H, 4 * W), 50.0), hip_device)
+    assert K.strip_tile_table(H, W, hip_device) is not None
+    ref = K.conv3x3(xs, fwd, C, **kw)
+    shape = ref.shape
+    out = torch.full(shape, -7.0, device=hip_device)
+    K.conv3x3(xs, fwd, C, out=out, images=images, strips=True, **kw)
+    torch.cuda.synchronize()
+    lo, hi = images or (0, N)
+    assert torch.equal(out[lo:hi], ref[lo:hi])
+    if lo > 0:
+        assert bool((out[:lo] == -7.0).all())
+    if hi < N:
+        assert bool((out[hi:] == -7.0).all())
+    # the same image range on the regular tiles
+    out2 = torch.full(shape, -7.0, device=hip_device)
+    K.conv3x3(xs, fwd, C, out=out2, images=images, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)

@@ -388,3 +388,31 @@ def test_forward_and_train_step_shape_fuzz_against_the_cpu_restatement(hip_devic
         for k, prm in m.model.named_parameters():
             ga, gb = prm.grad.cpu().numpy(), sd_req[k].grad.numpy()
             assert np.abs(ga - gb).max() <= 2e-4 * max(np.abs(gb).max(), 1e-30), (case, name, blocks, k)
+
+
+@pytest.mark.parametrize("name,flags,use_graph", [("LarvaNet", ["--num_modules=3", "--num_blocks=2,1,2"], False),
+                                                  ("LarvaNet", ["--num_modules=2", "--num_blocks=2,2"], True),
+                                                  ("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,2"], False),
+                                                  ("LarvaNetV2", ["--num_modules=2", "--num_blocks=2,1"], True)])
+def test_two_half_batch_chains_train_exactly_like_one_chain(hip_device, name, flags, use_graph):
+    """autograd.DualChain: the body chain as two half-batch chains of strip-tile launches on two
+    streams is the same arithmetic as one chain of full-batch launches -- losses and weights after
+    three steps are identical bit for bit (eager launches and hipGraph replay; V1 joins lazily, V2
+    after every body in backward).  Batch of 5: the halves are 2 and 3 images."""
+    g = torch.Generator().manual_seed(37)
+    x = (torch.rand(5, 3, 16, 20, generator=g) * 255).to(hip_device)
+    t = (torch.rand(5, 3, 64, 80, generator=g) * 255).to(hip_device)
+    args = types.SimpleNamespace(train_path="/tmp")
+    from larvanet_amd.autograd import DualChain
+    results = []
+    for dual in (False, True):
+        m = _model(name, flags, training=True, seed=5)
+        m.use_hip_graph = use_graph
+        m.dual_chain = dual
+        losses = [m.train_step_larva(args, FakeValLoader(7), x, t) for _ in range(3)]
+        assert m.use_hip_graph == use_graph
+        assert not DualChain._forked and not DualChain._keep
+        results.append((losses, {k: v.cpu().numpy().copy() for k, v in m.model.state_dict().items()}))
+    assert results[0][0] == results[1][0]
+    for k in results[0][1]:
+        assert np.array_equal(results[0][1][k], results[1][1][k]), k
