@@ -19,7 +19,9 @@ ms_per_step are the MEDIAN round, min / max are reported beside it.
 
 The JSON line also carries
   roofline            fp32-MFMA roofline of the dominant kernel (fused conv3x3+ReLU, 48->48,
-                      16x48x48), timed live with events on the launch stream (in-graph chain)
+                      16x48x48) the way the step runs it: two concurrent half-batch strip-tile
+                      launches per layer, timed live with events around a captured graph
+  roofline_single_chain   the same layer as one whole-batch launch (round 1's dominant kernel)
   roofline_c32/_c64   the same kernel at 32 and 64 channels (BASELINE configs 2 and 5)
   roofline_wgrad      the weight-gradient launch as the step issues it
   cpu_baseline        the same training step in the torch CPU restatement (oracle/, kind "port") on
@@ -174,6 +176,61 @@ def chain_time_ms(dev, c, chain=40, reps=10):
     return sorted(best)[1]
 
 
+def dual_chain_time_ms(dev, c=CH, chain=40, reps=10):
+    """The same layers the way the training step now runs its layer chain (autograd.DualChain): two
+    half-batch chains of strip-tile launches (5 x 16 / 4 x 16 pixel tiles, 256 workgroups per launch)
+    on two streams inside one captured graph; per FULL-BATCH layer = replay time / chain."""
+    import torch
+    from larvanet_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(BATCH, c, PATCH, PATCH, generator=g) * 20).to(dev)
+    w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.zeros(c, device=dev)
+    fwd, _ = K.pack_weights(w)
+    bufs = [x.clone() * 0.0 + 1.0, torch.empty_like(x)]
+    wsmall = fwd * 0.05
+    for phase in (0, 1):
+        if K.strip_tile_table(PATCH, PATCH, dev, phase) is None:
+            return None
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    parts = ((0, BATCH // 2), (BATCH // 2, BATCH))
+
+    def body():
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            st.wait_stream(cur)
+        for i in range(chain):
+            for k, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    K.conv3x3(bufs[i & 1], wsmall, c, bias=b, relu=True, out=bufs[(i + 1) & 1], images=parts[k],
+                              strips=2 if k else True)
+        for st in streams:
+            cur.wait_stream(st)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        body()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    best = []
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            graph.replay()
+        e.record()
+        torch.cuda.synchronize()
+        best.append(s.elapsed_time(e) / (reps * chain))
+    return sorted(best)[1]
+
+
 def time_dominant_kernel(dev, iters=50):
     """Isolated launches of the same kernel, two ways: kernel-attached HIP events
     (hipExtLaunchKernelGGL start/stop = the kernel's own begin/end) and a plain event pair around
@@ -201,22 +258,42 @@ def time_dominant_kernel(dev, iters=50):
     return k_mean, k_min, float(np.mean(pair))
 
 
-def roofline_block(dev, c=CH, full=True):
-    graph_ms = chain_time_ms(dev, c)
-    # priced on the in-graph time per launch (what the step pays, boundaries included), which is
-    # also what rocprofv3 reports for this kernel inside the captured step
+def roofline_block(dev, c=CH, full=True, dual=False):
+    """fp32-MFMA roofline of the fused conv3x3+ReLU layer at 16 x c x 48 x 48.  dual=False: one
+    chain of whole-batch launches (3 x 48 tiles, conv3x3_mfma_kernel).  dual=True: the layer as the
+    training step runs it since round 2 -- two concurrent half-batch launches of
+    conv3x3_mfma_strip_kernel; `avg_ms` is then the time per FULL-BATCH layer (= per pair of
+    launches), `flop_per_launch` one launch's half."""
+    graph_ms = dual_chain_time_ms(dev, c) if dual else chain_time_ms(dev, c)
+    if graph_ms is None:
+        return None
+    # priced on the in-graph time per layer (what the step pays, boundaries included)
     flop = conv_flop(c)
     achieved = flop / (graph_ms * 1e-3) / 1e12
+    alg_bytes = 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c)
     blk = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-           "traffic": HBM_TRAFFIC_PER_LAUNCH if c == CH else None,
-           "kernel": "conv3x3_mfma_kernel<%d, true, 1> (fused conv3x3+bias+ReLU), 16x%dx48x48 fp32" % (c, c),
-           "flop_per_launch": flop, "avg_ms": graph_ms,
-           "timing": "HIP event pair around 10 replays of a captured chain of 40 dependent launches, per launch "
-                     "(median of 3)",
-           "algorithmic_bytes_per_launch": 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c)}
-    if c == CH:
-        blk["traffic_source"] = HBM_TRAFFIC_SOURCE
+           "traffic": HBM_TRAFFIC_PER_LAUNCH if (c == CH and not dual) else None,
+           "avg_ms": graph_ms}
+    if dual:
+        blk.update({
+            "kernel": "conv3x3_mfma_strip_kernel<1> (fused conv3x3+bias+ReLU, 5x16 / 4x16 pixel tiles), two concurrent "
+                      "half-batch launches (8x%dx48x48 each) = one 16x%dx48x48 fp32 layer" % (c, c),
+            "launches_per_layer": 2, "flop_per_launch": flop // 2, "flop_per_layer": flop,
+            "algorithmic_bytes_per_layer": alg_bytes,
+            "timing": "HIP event pair around 10 replays of a captured graph of two 40-launch half-batch chains on two "
+                      "streams; avg_ms = replay time / 40 = time per full-batch layer (median of 3).  Under rocprofv3 "
+                      "the two chains do not overlap (the profiler makes the multi-stream graph launch host-bound): "
+                      "its per-launch durations are those of a launch running alone"})
+    else:
+        blk.update({
+            "kernel": "conv3x3_mfma_kernel<%d, true, 1> (fused conv3x3+bias+ReLU), 16x%dx48x48 fp32" % (c, c),
+            "flop_per_launch": flop,
+            "timing": "HIP event pair around 10 replays of a captured chain of 40 dependent launches, per launch "
+                      "(median of 3)",
+            "algorithmic_bytes_per_launch": alg_bytes})
+        if c == CH:
+            blk["traffic_source"] = HBM_TRAFFIC_SOURCE
     if full:
         k_mean_ms, k_min_ms, pair_ms = time_dominant_kernel(dev)
         blk.update({"isolated_kernel_attached_ms": k_mean_ms, "isolated_min_ms": k_min_ms,
@@ -418,7 +495,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device")
     dev = torch.device("cuda", torch.cuda.current_device())
     if a.roofline_only:
-        emit({"roofline": roofline_block(dev)})
+        emit({"roofline": roofline_block(dev), "roofline_dual": roofline_block(dev, full=False, dual=True)})
         return
 
     import importlib
@@ -486,6 +563,7 @@ def main():
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                    "inputs": "resident in the captured step's input buffers" if bufs is not None else "resident in HBM",
                    "loss_sync_per_step": bool(a.sync_loss), "hip_graph": bool(model.use_hip_graph),
+                   "dual_chain": bool(model.dual_chain),
                    "final_loss": final_loss},
         "rounds": {"n": rounds, "steps_each": a.steps, "ms_per_step_median": ms_per_step,
                    "ms_per_step_min": per_step[0], "ms_per_step_max": per_step[-1],
@@ -518,7 +596,12 @@ def main():
             model.model(x)
         torch.cuda.synchronize()
         infer_ms = (time.perf_counter() - t0) / 20 * 1e3
-    line["roofline"] = roofline_block(dev)
+    single = roofline_block(dev)
+    dual = roofline_block(dev, full=False, dual=True) if model.dual_chain else None
+    # the dominant kernel as the step runs it: the pair of strip-tile launches when the layer chain
+    # runs as two half-batch chains, else the whole-batch launch
+    line["roofline"] = dual if dual is not None else single
+    line["roofline_single_chain"] = single
     line["roofline_wgrad"] = wgrad_block(dev)
     line["infer"] = {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
                      "unit": "HR Mpixels/s"}

@@ -77,6 +77,22 @@ int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int c
                             float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
                             void* stream);
 
+/* njobs (2..4) exits of the training step, each scored by nn.L1Loss inside the conv launch
+ * (models/LarvaNet.py:104-109: out_i = leg(fea_i, base); loss += L1(out_i, truth)): the image
+ * PixelShuffle(4)(conv) + base is compared with `truth` in the accumulators; partial[j] receives
+ * larva_exit_l1_partials(N, H, pitch) partial sums of |out - truth| (added in index order by
+ * larva_loss_from_partials: reproducible), grad[j] the gradient sign(out - truth) * gval
+ * (sign(0) = 0) in the pixel-unshuffled layout [N][cout][H][pitch]; out[j] ([N][cout/16][4H][4W])
+ * may be NULL when the image itself is not wanted.  Replaces larva_conv3x3_fwd_batch(mode 1) +
+ * larva_l1_partial_grad_batch: one launch and four 14 MB sweeps less per step.  cout 48, 16-byte
+ * staging path only (801 otherwise). */
+int larva_exit_l1_partials(int N, int H, int pitch);
+int larva_conv3x3_exit_l1_batch(int njobs, const float* const* src, int n_src, int cin_per_src,
+                                const float* const* wpk, const float* const* bias, const float* const* base,
+                                const float* const* truth, float* const* out, float* const* grad,
+                                float* const* partial, float gval, int N, int cout, int H, int W, int pitch,
+                                void* stream);
+
 /* Strip tiles: the same convolution (bit-identical results) with the image cut into 5 x 16 and
  * 4 x 16 pixel tiles instead of 3 x 48.  Half a training batch (8 x 48 x 48) is then 256 workgroups
  * like the whole batch is with 3 x 48 tiles, so the two halves of a batch can run as two independent

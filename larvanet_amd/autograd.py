@@ -812,6 +812,8 @@ class ExitsFn(torch.autograd.Function):
     Backward leaves the input gradient of every exit whose leg shares its input with the next
     body's first conv to that body (JointInputGrad)."""
 
+    fuse_l1 = os.environ.get("LARVA_FUSE_EXIT_L1", "1") != "0"   # L1 inside the pixel-shuffle conv launch
+
     @staticmethod
     def forward(ctx, base, truth, legs, divisor, *args):
         M = len(legs)  # legs: [[PackedConv conv1, PackedConv conv2]] per exit
@@ -820,21 +822,39 @@ class ExitsFn(torch.autograd.Function):
         c2 = int(params[2].shape[0])
         hs = _conv_group([{"srcs": feas[i], "wpk": legs[i][0].get()[0][0], "bias": params[4 * i + 1].detach()}
                           for i in range(M)], c, relu=True)
-        outs = _conv_group([{"srcs": hs[i], "wpk": legs[i][1].get()[0][0], "bias": params[4 * i + 3].detach(),
-                             "base": base} for i in range(M)], c2, shuffle=True)
         ctx.gscale = float(np.float32(1.0) / np.float32(divisor))
         ctx.have_dyl = StepScope.seed_grad is not None
-        parts, third = [], []
-        if ctx.have_dyl:  # gradient value known now: one sweep over (out_i, truth) does both, all exits at once
-            for i in range(0, M, 8):
-                p8, _, g8 = K.l1_partial_grad_batch(outs[i:i + 8], truth, StepScope.seed_grad, ctx.gscale)
-                parts += p8
-                third += g8
-        else:
-            for out in outs:
-                part, _ = K.l1_partial(out, truth)
-                parts.append(part)
-                third.append(out)
+        shuffle_jobs = [{"srcs": hs[i], "wpk": legs[i][1].get()[0][0], "bias": params[4 * i + 3].detach(), "base": base}
+                        for i in range(M)]
+        outs, parts, third = [None] * M, [None] * M, [None] * M
+        fused = ctx.have_dyl and ExitsFn.fuse_l1
+        if fused:
+            # gradient value known now: every exit is scored inside its pixel-shuffle conv launch (partial
+            # sums of |out - truth| and the sign gradient straight from the accumulators); only the last
+            # exit's image is stored at all
+            i = 0
+            while i < M and fused:
+                n = 3 if M - i == 5 else min(4, M - i)   # launches of 2..4 exits (5 left = 3 + 2)
+                res = K.conv3x3_exit_l1_batch(shuffle_jobs[i:i + n], c2, truth, StepScope.seed_grad, ctx.gscale,
+                                              [i + k == M - 1 for k in range(n)]) if n > 1 else None
+                if res is None:
+                    fused = False
+                else:
+                    outs[i:i + n], parts[i:i + n], third[i:i + n] = res
+                    i += n
+        if not fused:
+            outs = _conv_group(shuffle_jobs, c2, shuffle=True)
+            parts, third = [], []
+            if ctx.have_dyl:  # one sweep over (out_i, truth) computes the partial sums and the gradient, all exits at once
+                for i in range(0, M, 8):
+                    p8, _, g8 = K.l1_partial_grad_batch(outs[i:i + 8], truth, StepScope.seed_grad, ctx.gscale)
+                    parts += p8
+                    third += g8
+            else:
+                for out in outs:
+                    part, _ = K.l1_partial(out, truth)
+                    parts.append(part)
+                    third.append(out)
         ctx.save_for_backward(truth, *feas, *hs, *third)
         ctx.legs, ctx.M = legs, M
         ctx.wshape = tuple(params[0].shape)

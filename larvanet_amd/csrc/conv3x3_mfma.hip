@@ -110,6 +110,12 @@ struct ConvArgs {
   // strip tiles (conv3x3_mfma_strip_kernel): tile_tab[t] = y0 | x0 << 12 | (5-row tile ? 1u << 31 : 0)
   // for the tiles_x entries of ONE image (tiles_x = tiles per image, tiles_y = 1)
   const unsigned* tile_tab;
+  // kEpiShuffleL1 (an exit of the training step scored by nn.L1Loss in the same launch):
+  const float* truth;         // [N][COUT/16][4H][4W], the image the exit is compared with
+  float* grad;                // [N][COUT][H][pitch]: sign(out - truth) * gval, pixel-unshuffled
+  float* partial;             // [4 * nwg]: sum |out - truth| of every MFMA wave's share of its tile
+  float gval;                 // d loss / d out element = seed * (1/M) / numel
+                              // (`out` may be null with this epilogue: the exit's image is not wanted)
   // ceil(2^40 / d) for d = tiles_x, tiles_y, cin_per_src / 8: the kernel's wave-uniform divisions
   // as one 64-bit multiply + shift (a runtime integer division is ~40 vector instructions, three of
   // them stood at the very start of every workgroup); exact while dividend * divisor < 2^40
@@ -131,7 +137,9 @@ enum Epi : int {
   kEpiRes2 = 4,         // out = ((acc + bias) + res0) + res1
   kEpiShuffle = 5,      // pixel-shuffle(4) store
   kEpiShuffleBase = 6,  // pixel-shuffle(4) store, + base
-  kEpiCount = 7
+  kEpiShuffleL1 = 7,    // + base, then L1 against `truth`: partial sums of |out - truth| and the sign
+                        // gradient in pixel-unshuffled layout from the registers (image store optional)
+  kEpiCount = 8
 };
 
 template <int COUT, typename G = GeoWide>
@@ -488,8 +496,9 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   // land under the whole K loop instead of being waited for after it (the mask / residual
   // variants ran 1-1.3 us longer than plain ReLU).  They are older than every LDS-DMA piece, so
   // the first counted wait of the ring covers them too.
-  constexpr bool kShuffleEpi = (EPI == kEpiShuffle || EPI == kEpiShuffleBase);
-  constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiShuffleBase) ? 1 : (EPI == kEpiRes2 ? 2 : 0);
+  constexpr bool kShuffleEpi = (EPI == kEpiShuffle || EPI == kEpiShuffleBase || EPI == kEpiShuffleL1);
+  constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiShuffleBase)
+                           ? 1 : ((EPI == kEpiRes2 || EPI == kEpiShuffleL1) ? 2 : 0);
   f32x4 aux[NAUX > 0 ? NAUX : 1][NCT][NPG];
   auto load_aux = [&]() {
 #pragma unroll
@@ -502,6 +511,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
           const int HH = 4 * a.H, WW = 4 * a.W;
           const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
           aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.base + idx);
+          if constexpr (EPI == kEpiShuffleL1) aux[1][c][p] = *reinterpret_cast<const f32x4*>(a.truth + idx);
         } else {
           const size_t plane = (size_t)a.H * a.pitch;
           const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
@@ -625,7 +635,40 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
 
   // Epilogue.  Lane (lr, lq) holds, in acc[c][p][r], output channel (ct0+c)*16 + lq*4 + r of
   // pixel (y0 + pg/3, x0 + (pg%3)*16 + lr).
-  if constexpr (EPI == kEpiShuffle || EPI == kEpiShuffleBase) {
+  if constexpr (EPI == kEpiShuffleL1) {
+    // The exit's image never has to reach memory to be scored: out = shuffle(conv) + base sits in
+    // the accumulators in exactly the (16C + 4i + j) channel order its L1 gradient is consumed in
+    // by the leg's dgrad / wgrad (models/LarvaNet.py:107-109 + autograd of :261).  sign(0) = 0 as
+    // in ATen's l1 backward.  The |out - truth| sum of this wave's share goes to partial[4 tile + wave]
+    // (fixed order everywhere: the loss is reproducible run to run).
+    const int HH = 4 * a.H, WW = 4 * a.W;
+    const size_t plane = (size_t)a.H * a.pitch;
+    const float g = a.gval;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
+        const int y = y0 + prow, x = x0 + pcol * 16 + lr;
+        const f32x4 v = (acc[c][p] + bias[c]) + aux[0][c][p];
+        if (y < a.H && x < a.W) {
+          if (a.out) {
+            const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
+          }
+          const f32x4 d = v - aux[1][c][p];
+          s += fabsf(d[0]) + fabsf(d[1]) + fabsf(d[2]) + fabsf(d[3]);
+          const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __builtin_nontemporal_store(d[r] > 0.f ? g : (d[r] < 0.f ? -g : 0.f), &a.grad[idx0 + r * plane]);
+        }
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) a.partial[4 * blockIdx.x + wave] = s;
+  } else if constexpr (EPI == kEpiShuffle || EPI == kEpiShuffleBase) {
     // PixelShuffle(4): out[n, C, 4y+i, 4x+j] = conv[n, 16C + 4i + j, y, x]; here C = ct0+c,
     // i = lq, j = r -> one aligned 16-byte store per lane (models/LarvaNet.py:261,265-266).
     const int HH = 4 * a.H, WW = 4 * a.W;
@@ -910,6 +953,9 @@ static hipError_t launch_batch(const ConvBatch& b, int njobs, int epi, hipStream
     case kEpiRes2: return launch_batch_e<COUT, kEpiRes2>(b, njobs, stream);
     case kEpiShuffle: return launch_batch_e<COUT, kEpiShuffle>(b, njobs, stream);
     case kEpiShuffleBase: return launch_batch_e<COUT, kEpiShuffleBase>(b, njobs, stream);
+    case kEpiShuffleL1:
+      if constexpr (COUT == 48) return launch_batch_e<COUT, kEpiShuffleL1>(b, njobs, stream);
+      return hipErrorNotSupported;
     default: return hipErrorInvalidValue;
   }
 }
@@ -1100,6 +1146,44 @@ int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int c
     case 48: return (int)launch_batch<48>(b, njobs, epi0, s);
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+// njobs (2..4) EXITS of the training step in one launch (models/LarvaNet.py:104-109 for several i):
+// out_j = PixelShuffle(4)(conv(src_j)) + base_j scored against truth_j by nn.L1Loss, without a pass
+// over the images: every MFMA wave adds up |out - truth| of its share of the tile
+// (partial[j]: 4 * N * tiles floats, see larva_exit_l1_partials) and writes
+// grad[j] = sign(out - truth) * gval in the pixel-unshuffled [N][cout][H][pitch] layout the leg's
+// dgrad / wgrad read (= larva_l1_bwd_unshuffle4 bit for bit).  out[j] may be NULL (image not wanted).
+// cout = 48, 16-byte staging path only (hipErrorNotSupported otherwise).
+int larva_exit_l1_partials(int N, int H, int pitch) {
+  return 4 * N * ((pitch + kTileCols - 1) / kTileCols) * ((H + kTileRows - 1) / kTileRows);
+}
+
+int larva_conv3x3_exit_l1_batch(int njobs, const float* const* src, int n_src, int cin_per_src,
+                                const float* const* wpk, const float* const* bias, const float* const* base,
+                                const float* const* truth, float* const* out, float* const* grad,
+                                float* const* partial, float gval, int N, int cout, int H, int W, int pitch,
+                                void* stream) {
+  if (njobs < 2 || njobs > kMaxConvJobs || !src || !wpk || !base || !truth || !out || !grad || !partial)
+    return (int)hipErrorInvalidValue;
+  if (cout != 48) return (int)hipErrorNotSupported;
+  ConvBatch b{};
+  for (int j = 0; j < njobs; ++j) {
+    bool aligned;
+    int epi;
+    if (!base[j] || !truth[j] || !grad[j] || !partial[j]) return (int)hipErrorInvalidValue;
+    const int rc = conv_build(src + (size_t)j * n_src, n_src, cin_per_src, wpk[j], bias ? bias[j] : nullptr, nullptr,
+                              nullptr, nullptr, base[j], grad[j], N, H, W, pitch, 0, 1, b.job[j], aligned, epi);
+    if (rc) return rc;
+    if (!aligned || ((reinterpret_cast<uintptr_t>(truth[j]) | reinterpret_cast<uintptr_t>(base[j])) & 15))
+      return (int)hipErrorNotSupported;
+    b.job[j].out = out[j];
+    b.job[j].truth = truth[j];
+    b.job[j].grad = grad[j];
+    b.job[j].partial = partial[j];
+    b.job[j].gval = gval;
+  }
+  return (int)launch_batch<48>(b, njobs, kEpiShuffleL1, (hipStream_t)stream);
 }
 
 // Strip tiles.  larva_strip_tile_table fills `tab` (host memory, `cap` entries) with the tiles of ONE

@@ -221,6 +221,47 @@ def conv3x3_batch(jobs, cout, relu=False, shuffle=False, logical_w=None):
     return outs
 
 
+def conv3x3_exit_l1_batch(jobs, cout, truth, gvalue, gscale, want_image):
+    """2..4 exits scored by L1 inside their pixel-shuffle conv launch.  jobs: dicts {srcs, wpk, bias,
+    base}; truth [N][cout/16][4H][4W]; the gradient of every image element is sign(out - truth) *
+    (gvalue * gscale) / numel; want_image[j]: also store exit j's image.  Returns (images (None where
+    not wanted), partial-sum vectors, gradients [N][cout][H][W]) or None when the launch does not
+    apply (unaligned operands, cout != 48): the caller then runs the conv and the L1 sweep separately."""
+    lib = hip_lib.load()
+    if not 2 <= len(jobs) <= 4 or cout != 48:
+        return None
+    norm = [dict(j, srcs=[j["srcs"]] if isinstance(j["srcs"], torch.Tensor) else list(j["srcs"])) for j in jobs]
+    n_src = len(norm[0]["srcs"])
+    N, cps, H, P = (int(v) for v in norm[0]["srcs"][0].shape)
+    hr = (N, cout // 16, 4 * H, 4 * P)
+    _chk(truth, "truth", hr)
+    numel = float(truth.numel())
+    import numpy as np
+    gval = float((np.float32(gvalue) * np.float32(gscale)) * (np.float32(1.0) / np.float32(numel)))
+    npart = int(lib.larva_exit_l1_partials(N, H, P))
+    src_ptrs, outs, grads, parts = [], [], [], []
+    for j, want in zip(norm, want_image):
+        if len(j["srcs"]) != n_src:
+            raise RuntimeError("larvanet_amd: batched exits must share one shape")
+        src_ptrs += [_chk(t, "src", (N, cps, H, P)) for t in j["srcs"]]
+        _chk(j["wpk"], "wpk", (packed_weight_floats(cout, cps * n_src),))
+        _chk(j["bias"], "bias", (cout,))
+        _chk(j["base"], "base", hr)
+        outs.append(torch.empty(hr, device=truth.device, dtype=torch.float32) if want else None)
+        grads.append(torch.empty((N, cout, H, P), device=truth.device, dtype=torch.float32))
+        parts.append(torch.empty(npart, device=truth.device, dtype=torch.float32))
+    code = lib.larva_conv3x3_exit_l1_batch(
+        len(norm), hip_lib.ptr_array(src_ptrs), n_src, cps, hip_lib.ptr_array([j["wpk"].data_ptr() for j in norm]),
+        hip_lib.ptr_array([j["bias"].data_ptr() for j in norm]), hip_lib.ptr_array([j["base"].data_ptr() for j in norm]),
+        hip_lib.ptr_array([truth.data_ptr()] * len(norm)), hip_lib.ptr_array([None if o is None else o.data_ptr() for o in outs]),
+        hip_lib.ptr_array([g.data_ptr() for g in grads]), hip_lib.ptr_array([p.data_ptr() for p in parts]),
+        gval, N, cout, H, P, P, _stream())
+    if code == 801:
+        return None
+    hip_lib.check(code, "larva_conv3x3_exit_l1_batch")
+    return outs, parts, grads
+
+
 def conv3x3_relu_timed(x, wpk, cout, bias, out, iters):
     """Measurement only: (mean_ms, min_ms) of the fused conv+ReLU launch, from kernel-attached
     events (the kernel's own begin/end timestamps)."""

@@ -641,3 +641,41 @@ def test_strip_tiles_and_image_ranges_match_the_wide_tiles_bit_for_bit(hip_devic
     K.conv3x3(xs, fwd, C, out=out2, images=images, **kw)
     torch.cuda.synchronize()
     assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("njobs,N,H,W", [(4, 2, 9, 48), (2, 3, 7, 20), (3, 16, 48, 48)])
+def test_exits_scored_inside_the_conv_launch(hip_device, njobs, N, H, W):
+    """larva_conv3x3_exit_l1_batch (conv -> PixelShuffle(4) -> + base -> L1 against the truth, all in
+    the conv's epilogue) against the separate launches it replaces: images and the pixel-unshuffled
+    sign gradient bit for bit (sign(0) = 0 included), the |out - truth| sum to fp32 rounding (another
+    grouping of the same addends) and against a float64 sum."""
+    from larvanet_amd import kernels as K
+    rng = np.random.default_rng(njobs * 1000 + H)
+    jobs = []
+    for _ in range(njobs):
+        w = _dev(_rand(rng, (48, 48, 3, 3), 0.05), hip_device)
+        jobs.append({"srcs": _dev(_rand(rng, (N, 48, H, W), 20.0), hip_device), "wpk": K.pack_weights(w, want_bwd=False)[0],
+                     "bias": _dev(_rand(rng, (48,), 1.0), hip_device), "base": _dev(_rand(rng, (N, 3, 4 * H, 4 * W), 50.0), hip_device)})
+    imgs = K.conv3x3_batch(jobs, 48, shuffle=True)
+    truth = _dev(_rand(rng, (N, 3, 4 * H, 4 * W), 60.0), hip_device)
+    truth[:, :, ::5, ::3] = imgs[0][:, :, ::5, ::3]          # exact ties for exit 0: gradient 0 there
+    gvalue, gscale = 1.0, float(np.float32(1.0) / np.float32(njobs))
+    ref_parts, _, ref_grads = K.l1_partial_grad_batch(imgs, truth, gvalue, gscale)
+    want = [j == njobs - 1 for j in range(njobs)]
+    res = K.conv3x3_exit_l1_batch(jobs, 48, truth, gvalue, gscale, want)
+    assert res is not None
+    outs, parts, grads = res
+    torch.cuda.synchronize()
+    assert outs[0] is None and torch.equal(outs[-1], imgs[-1])
+    t64 = truth.double()
+    for j in range(njobs):
+        assert torch.equal(grads[j], ref_grads[j]), j
+        exact = float((imgs[j].double() - t64).abs().sum())
+        got, old = float(parts[j].double().sum()), float(ref_parts[j].double().sum())
+        assert abs(got - exact) <= 2e-6 * exact and abs(got - old) <= 2e-6 * exact, (j, got, old, exact)
+    assert int((grads[0] == 0).sum()) >= int(truth[:, :, ::5, ::3].numel())
+    # run to run: the same bits
+    res2 = K.conv3x3_exit_l1_batch(jobs, 48, truth, gvalue, gscale, want)
+    torch.cuda.synchronize()
+    for j in range(njobs):
+        assert torch.equal(res2[1][j], parts[j])

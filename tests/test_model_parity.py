@@ -197,9 +197,11 @@ def test_joint_input_gradient_launch_matches_separate_launches(hip_device, name,
                                         ("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,2"])])
 def test_exits_as_one_batched_node_match_one_node_per_exit(hip_device, name, flags):
     """ExitsFn (all exits after the body chain, batched launches, joint input gradients) against
-    the reference's interleaved order with one autograd node per exit: same loss bit for bit
-    (forward arithmetic is identical), gradients to fp32 rounding (the joint dgrad sums in one
-    K chain what the other path adds afterwards)."""
+    the reference's interleaved order with one autograd node per exit: the same last image bit for
+    bit (forward arithmetic is identical), the loss to fp32 rounding (the batched exits add up
+    |out - truth| per conv workgroup inside the conv launch, the per-exit path per block of a
+    separate sweep), gradients to fp32 rounding (the joint dgrad sums in one K chain what the other
+    path adds afterwards)."""
     g = torch.Generator().manual_seed(29)
     x = (torch.rand(2, 3, 12, 16, generator=g) * 255).to(hip_device)
     t = (torch.rand(2, 3, 48, 64, generator=g) * 255).to(hip_device)
@@ -212,7 +214,7 @@ def test_exits_as_one_batched_node_match_one_node_per_exit(hip_device, name, fla
         torch.cuda.synchronize()
         results.append((float(loss.detach()), out.detach().cpu().numpy().copy(),
                         {k: p.grad.cpu().numpy().copy() for k, p in m.model.named_parameters()}))
-    assert results[0][0] == results[1][0]
+    assert abs(results[0][0] - results[1][0]) <= 1e-6 * abs(results[0][0])
     assert np.array_equal(results[0][1], results[1][1])
     for k, ga in results[0][2].items():
         gb = results[1][2][k]
