@@ -331,6 +331,57 @@ def wgrad_block(dev, jobs=32, iters=20):
             "flop_per_layer": conv_flop(CH)}
 
 
+def wgrad_in_step(model, x, truth, reps=30):
+    """What the weight gradients cost INSIDE the training step: the captured forward+backward replayed
+    with and without its deferred weight-gradient launches (32 + 8 layers, the 3 -> 48 head, one
+    reduction); the difference is their time at the clocks and cache state the step gives them (an
+    isolated back-to-back loop of the same launch runs ~10 % slower: sustained fp32-MFMA load pulls
+    the clock down)."""
+    import torch
+    from larvanet_amd.autograd import DeferredWgrad
+
+    def body(with_wgrad):
+        model._zero_grad()
+        with model._scope():
+            loss, _ = model._exit_losses(x, truth)
+            loss.backward(model._grad_one(loss))
+            if not with_wgrad:
+                DeferredWgrad.drop()
+
+    times = {}
+    for with_wgrad in (True, False):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            body(with_wgrad)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            body(with_wgrad)
+        for _ in range(5):
+            graph.replay()
+        torch.cuda.synchronize()
+        runs = []
+        for _ in range(3):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                graph.replay()
+            e.record()
+            torch.cuda.synchronize()
+            runs.append(s.elapsed_time(e) / reps)
+        times[with_wgrad] = sorted(runs)[1]
+    layers = sum(BLOCKS) * 2 + 2 * len(BLOCKS)                      # 40 C->C layers
+    flop = layers * conv_flop(CH) + 2 * 9 * 3 * CH * BATCH * PATCH * PATCH   # + the 3 -> 48 head
+    ms = times[True] - times[False]
+    achieved = flop / (ms * 1e-3) / 1e12
+    return {"ms_all_weight_gradients": ms, "fwd_bwd_ms": times[True], "fwd_bwd_without_wgrad_ms": times[False],
+            "layers": layers, "flop": flop, "achieved": achieved, "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+            "what": "captured forward+backward replayed with and without its deferred weight-gradient launches "
+                    "(HIP events, median of 3 x %d replays)" % reps}
+
+
 def host_cores():
     """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (a GPU
     box hands each job a share of a large host; 256 threads on a 16-CPU share thrash)."""
@@ -403,12 +454,12 @@ def full_image_block(dev):
         m.prepare(is_training=False, scales=[SCALE])
         with torch.no_grad():
             for _ in range(3):
-                m.model(x)
+                m.fwd_runtime(x)
             torch.cuda.synchronize()
             reps = 10
             t0 = time.perf_counter()
             for _ in range(reps):
-                m.model(x)
+                m.fwd_runtime(x)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / reps * 1e3
         out[name] = {"ms_per_image": ms, "value": out["hr_pixels"] / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s"}
@@ -589,11 +640,11 @@ def main():
     # inference forward (extra information)
     with torch.no_grad():
         for _ in range(5):
-            model.model(x)
+            model.fwd_runtime(x)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(20):
-            model.model(x)
+            model.fwd_runtime(x)
         torch.cuda.synchronize()
         infer_ms = (time.perf_counter() - t0) / 20 * 1e3
     single = roofline_block(dev)
@@ -603,6 +654,8 @@ def main():
     line["roofline"] = dual if dual is not None else single
     line["roofline_single_chain"] = single
     line["roofline_wgrad"] = wgrad_block(dev)
+    if extras:
+        line["roofline_wgrad"]["in_step"] = wgrad_in_step(model, x, truth)
     line["infer"] = {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
                      "unit": "HR Mpixels/s"}
     if extras:

@@ -77,6 +77,14 @@ int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int c
                             float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
                             void* stream);
 
+/* LarvaHead.forward (models/LarvaNet.py:223-233: nn.Conv2d(3, 48, 3, 1, 1), no activation) as a
+ * direct convolution: x [N][3][H][W] unpadded, w [cout][3][3][3] in PyTorch layout (no packed image),
+ * bias [cout] or NULL, out [N][cout][H][pitch] with columns [W, pitch) zeroed; cout % 16 == 0.
+ * Bandwidth-bound (0.44 MB in, 7.08 MB out at 16x3x48x48): A/B against the same layer on the MFMA
+ * kernel (image zero-padded to 16 channels) in profiles/. */
+int larva_head_conv3_direct(const float* x, const float* w, const float* bias, float* out, int N, int cout,
+                            int H, int W, int pitch, void* stream);
+
 /* njobs (2..4) exits of the training step, each scored by nn.L1Loss inside the conv launch
  * (models/LarvaNet.py:104-109: out_i = leg(fea_i, base); loss += L1(out_i, truth)): the image
  * PixelShuffle(4)(conv) + base is compared with `truth` in the accumulators; partial[j] receives

@@ -582,19 +582,36 @@ class _NullCtx:
 
 
 class HeadFn(torch.autograd.Function):
-    """LarvaHead.forward (models/LarvaNet.py:223-233): conv3x3 3->48, no activation.  The
-    3-channel image is zero-padded to one 16-channel K chunk and runs on the same MFMA kernel."""
+    """LarvaHead.forward (models/LarvaNet.py:223-233): conv3x3 3->48, no activation.
+    Forward: the MFMA conv kernel on the image zero-padded to two 8-channel K chunks (13/16 of its
+    multiplies are zeros, still the faster one) or, LARVA_HEAD_DIRECT=1, the direct K = 27 kernel on
+    the raw 3-channel image (larva_head_conv3_direct; rocprof A/B in profiles/).
+    The weight gradient (M = 48, N = 27, K = all pixels: a real GEMM) stays on the MFMA wgrad kernel,
+    which reads the 16-channel padded image -- so that copy is made whenever a backward will follow."""
+
+    # rocprofv3 A/B at 16 x 3 x 48 x 48 (profiles/README.md, r02_head_*): padded-MFMA launch 7.2 us, direct
+    # kernel 9.0 us (LDS-broadcast weights; 12.8 us with scalar-loaded weights) -> MFMA is the default
+    direct = os.environ.get("LARVA_HEAD_DIRECT", "0") != "0"
 
     @staticmethod
     def forward(ctx, x, weight, bias, pc):
         N, C, H, W = x.shape
         P = PaddedWidth.pitch_of(W) if _lw() is not None else W
-        x16 = StepScope.padded_input((N, 16, H, P), x.device)  # channels C..15 / columns W..P-1 stay zero
-        x16[:, :C, :, :W] = x
-        (fwd, _), = pc.get()
-        out = DualChain.conv(x16, fwd, int(weight.shape[0]), bias=bias.detach(), logical_w=_lw())
-        DualChain.end_of_node(False)
-        ctx.save_for_backward(x16)
+        cout = int(weight.shape[0])
+        training = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])   # a weight gradient will be asked for
+        use_direct = HeadFn.direct and C == 3 and cout % 16 == 0
+        x16 = None
+        if training or not use_direct:
+            x16 = StepScope.padded_input((N, 16, H, P), x.device)  # channels C..15 / columns W..P-1 stay zero
+            x16[:, :C, :, :W] = x
+        if use_direct:
+            out = K.head_conv3_direct(x, weight.detach(), bias.detach(), pitch=P)
+        else:
+            (fwd, _), = pc.get()
+            out = DualChain.conv(x16, fwd, cout, bias=bias.detach(), logical_w=_lw())
+            DualChain.end_of_node(False)
+        if x16 is not None:
+            ctx.save_for_backward(x16)
         ctx.wshape = tuple(weight.shape)
         ctx.pc = pc
         return out

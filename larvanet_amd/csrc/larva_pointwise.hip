@@ -71,6 +71,81 @@ __global__ void bicubic4_kernel(const float* __restrict__ in, float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// LarvaHead (models/LarvaNet.py:223-233): conv3x3 3 -> COUT, bias, no activation, as a DIRECT
+// convolution.  K = 27: on the MFMA kernel the image is zero-padded to 16 channels (two 8-channel
+// K chunks, 13/16 of the multiplies are zeros) and the launch costs what a quarter of a 48 -> 48
+// layer costs; here the layer is what it is -- 0.44 MB in, 7.08 MB out, bandwidth-bound.  One thread
+// = one output pixel x 16 output channels: its 27 inputs in registers (neighbouring lanes share them
+// through L1), the 16 x 27 weights wave-uniform (scalar loads), 16 coalesced dword stores per thread.
+// `x` is the unpadded [N][3][H][W] image; `out` rows are `pitch` >= W floats apart, columns [W, pitch)
+// written as zeros (the layout the next layer's 16-byte staging path expects).
+// ---------------------------------------------------------------------------------------------
+constexpr int kHeadCoutsPerThread = 16;
+
+__global__ __launch_bounds__(256) void head_conv3_direct_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ out, int N, int cout, int H,
+                                                                int W, int pitch) {
+  // this block's 16 x 27 weights (+ bias) -> LDS, rows padded to 28 floats: every lane then reads the
+  // same address (a broadcast, no bank conflict).  Scalar loads were tried first: 16 dependent
+  // s_load round trips per thread, 12.8 us for the launch.
+  __shared__ __attribute__((aligned(16))) float wl[kHeadCoutsPerThread][28];
+  const int co0 = blockIdx.y * kHeadCoutsPerThread;
+  for (int i = threadIdx.x; i < kHeadCoutsPerThread * 28; i += 256) {
+    const int j = i / 28, k = i - j * 28;
+    wl[j][k] = k < 27 ? w[(co0 + j) * 27 + k] : (bias ? bias[co0 + j] : 0.f);   // slot 27 = the bias
+  }
+  __syncthreads();
+  const int total = N * H * pitch;                      // (< 2^31: checked by the launcher)
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= total) return;
+  const int xx = pix % pitch;
+  const int t = pix / pitch;
+  const int y = t % H;
+  const int n = t / H;
+  // the 3 x 3 window: clamped row / column offsets + validity, shared by the three channels
+  int roff[3], coff[3];
+  bool rok[3], cok[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int yy = y + k - 1, xc = xx + k - 1;
+    rok[k] = yy >= 0 && yy < H;
+    cok[k] = xc >= 0 && xc < W;
+    roff[k] = min(max(yy, 0), H - 1) * W;
+    coff[k] = min(max(xc, 0), W - 1);
+  }
+  const float* xb = x + (size_t)n * 3 * H * W;
+  const int cplane = H * W;
+  float v[27];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float val = xb[c * cplane + roff[ky] + coff[kx]];
+        v[(c * 3 + ky) * 3 + kx] = (rok[ky] && cok[kx]) ? val : 0.f;
+      }
+  const size_t plane = (size_t)H * pitch;
+  float* o = out + ((size_t)n * cout + co0) * plane + (size_t)y * pitch + xx;
+  const bool real = xx < W;
+#pragma unroll
+  for (int j = 0; j < kHeadCoutsPerThread; ++j) {
+    float wj[28];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wl[j][4 * q]);
+      wj[4 * q] = w4[0]; wj[4 * q + 1] = w4[1]; wj[4 * q + 2] = w4[2]; wj[4 * q + 3] = w4[3];
+    }
+    float acc = wj[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc = fmaf(v[k], wj[k], acc);
+    o[j * plane] = real ? acc : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // L1 loss (nn.L1Loss(), models/LarvaNet.py:85,108): sum |a - b| -> per-block partials -> a
 // one-block launch adds them in index order (reproducible) and writes sum / numel.
 // ---------------------------------------------------------------------------------------------
@@ -413,6 +488,20 @@ int larva_bicubic4_fwd(const float* in, float* out, int N, int C, int H, int W, 
   const long long work = (long long)N * C * 4 * H * W;
   hipLaunchKernelGGL(bicubic4_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
                      N * C, H, W);
+  return (int)hipGetLastError();
+}
+
+// Direct 3 -> cout head convolution (cout % 16 == 0): x [N][3][H][W], w [cout][3][3][3] (PyTorch layout,
+// no packing), bias [cout] or NULL, out [N][cout][H][pitch] with columns [W, pitch) zeroed.
+int larva_head_conv3_direct(const float* x, const float* w, const float* bias, float* out, int N, int cout,
+                            int H, int W, int pitch, void* stream) {
+  if (pitch == 0) pitch = W;
+  if (!x || !w || !out || N <= 0 || cout <= 0 || cout % kHeadCoutsPerThread || H <= 0 || W <= 0 || pitch < W)
+    return (int)hipErrorInvalidValue;
+  const long long total = (long long)N * H * pitch;
+  if (total >= (1ll << 31) - 256 || (long long)N * 3 * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(head_conv3_direct_kernel, dim3((unsigned)((total + 255) / 256), cout / kHeadCoutsPerThread), dim3(256),
+                     0, (hipStream_t)stream, x, w, bias, out, N, cout, H, W, pitch);
   return (int)hipGetLastError();
 }
 

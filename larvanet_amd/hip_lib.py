@@ -32,6 +32,8 @@ SIGNATURES = {
     "larva_conv3x3_fwd_batch": (ctypes.c_int, [ctypes.c_int, _c_pp, ctypes.c_int, ctypes.c_int, _c_pp, _c_pp, _c_pp, _c_pp,
                                                _c_pp, _c_pp, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_head_conv3_direct": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_exit_l1_partials": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "larva_conv3x3_exit_l1_batch": (ctypes.c_int, [ctypes.c_int, _c_pp, ctypes.c_int, ctypes.c_int, _c_pp, _c_pp, _c_pp, _c_pp,
                                                    _c_pp, _c_pp, _c_pp, ctypes.c_float, ctypes.c_int, ctypes.c_int,

@@ -221,6 +221,23 @@ def conv3x3_batch(jobs, cout, relu=False, shuffle=False, logical_w=None):
     return outs
 
 
+def head_conv3_direct(x, w, bias=None, pitch=None):
+    """nn.Conv2d(3, cout, 3, 1, 1) on the raw image: x [N][3][H][W], w [cout][3][3][3] -> [N][cout][H][P]
+    (P = pitch or W; columns [W, P) zero)."""
+    lib = hip_lib.load()
+    N, C, H, W = (int(v) for v in x.shape)
+    cout = int(w.shape[0])
+    if C != 3 or tuple(w.shape[1:]) != (3, 3, 3) or cout % 16:
+        raise RuntimeError("larvanet_amd: the direct head conv takes a 3-channel image and [cout][3][3][3] weights")
+    _chk(x, "x")
+    _chk(w, "w")
+    P = W if pitch is None else int(pitch)
+    out = torch.empty((N, cout, H, P), device=x.device, dtype=torch.float32)
+    hip_lib.check(lib.larva_head_conv3_direct(x.data_ptr(), w.data_ptr(), _opt(bias, "bias", (cout,)), out.data_ptr(),
+                                              N, cout, H, W, P, _stream()), "larva_head_conv3_direct")
+    return out
+
+
 def conv3x3_exit_l1_batch(jobs, cout, truth, gvalue, gscale, want_image):
     """2..4 exits scored by L1 inside their pixel-shuffle conv launch.  jobs: dicts {srcs, wpk, bias,
     base}; truth [N][cout/16][4H][4W]; the gradient of every image element is sign(out - truth) *

@@ -5,6 +5,7 @@ return that body's exit (k = num_modules is the full network, k = 0 returns the 
 image alone) -- models/LarvaLeg.py:52, 275, 289-300.  Training is unchanged (all exits)."""
 import torch
 
+from ..autograd import DualChain
 from . import LarvaNet as V1
 from .LarvaNetV2 import LarvaNet as _V2Wrapper
 
@@ -28,6 +29,7 @@ class LarvaNetModule(V1.LarvaNetModule):
             fea = self.head(x)
             for i in range(self.leg):
                 fea = getattr(self, "body_%d" % i)(fea)
+            DualChain.join()
             return getattr(self, "body_%d" % (self.leg - 1)).leg(fea, base)
 
 

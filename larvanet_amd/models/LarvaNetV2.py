@@ -66,8 +66,10 @@ class LarvaNetModule(V1.LarvaNetModule):
 
     def forward(self, x):
         with self.width_scope(x):
+            base = self.base(x)
             feats = self.features(x)
-            return self.tail(feats, self.base(x))
+            DualChain.join()
+            return self.tail(feats, base)
 
 
 class LarvaNet(V1.LarvaNet):

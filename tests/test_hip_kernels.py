@@ -679,3 +679,31 @@ def test_exits_scored_inside_the_conv_launch(hip_device, njobs, N, H, W):
     torch.cuda.synchronize()
     for j in range(njobs):
         assert torch.equal(res2[1][j], parts[j])
+
+
+@pytest.mark.parametrize("N,H,W,pitch", [(16, 48, 48, None), (1, 9, 13, 16), (2, 5, 7, None), (1, 339, 510, 512)])
+def test_direct_head_conv_against_oracle_and_mfma_path(hip_device, N, H, W, pitch):
+    """larva_head_conv3_direct (LarvaHead, K = 27) against the C oracle and against the same layer on
+    the MFMA kernel (image zero-padded to 16 channels); padding columns of a pitched output are zero."""
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(H * 31 + W)
+    x = _rand(rng, (N, 3, H, W), 70.0)
+    w = _rand(rng, (48, 3, 3, 3), 0.1)
+    b = _rand(rng, (48,), 1.0)
+    out = K.head_conv3_direct(_dev(x, hip_device), _dev(w, hip_device), _dev(b, hip_device), pitch=pitch)
+    torch.cuda.synchronize()
+    P = pitch or W
+    assert tuple(out.shape) == (N, 48, H, P)
+    got = out.cpu().numpy()
+    if P > W:
+        assert not got[..., W:].any()
+    if N * H * W <= 16 * 48 * 48:
+        _report("head", got[..., :W], R.conv3x3(x, w, b), 2e-5)
+    x16 = torch.zeros((N, 16, H, P), device=hip_device)
+    x16[:, :3, :, :W] = _dev(x, hip_device)
+    fwd, _ = K.pack_weights(_dev(w, hip_device), cin_pad=16, want_bwd=False)
+    ref = K.conv3x3(x16, fwd, 48, bias=_dev(b, hip_device), logical_w=W if P > W else None)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((out - ref).abs().max()) <= 1e-5 * scale

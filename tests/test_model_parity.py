@@ -418,3 +418,28 @@ def test_two_half_batch_chains_train_exactly_like_one_chain(hip_device, name, fl
     assert results[0][0] == results[1][0]
     for k in results[0][1]:
         assert np.array_equal(results[0][1][k], results[1][1][k]), k
+
+
+@pytest.mark.parametrize("name,flags", [("LarvaNet", ["--num_modules=2", "--num_blocks=2,1"]),
+                                        ("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,2"])])
+def test_repeated_inference_shape_replays_a_graph_with_the_eager_result(hip_device, name, flags, tmp_path):
+    """A batch shape seen twice is captured (two half-batch chains inside) and replayed: same bits as
+    the eager forward, also after the weights change under the captured graph (restore / repack)."""
+    m = _model(name, flags, seed=3)
+    rng = np.random.RandomState(5)
+    batch = [rng.randint(0, 256, size=(3, 16, 20)).astype(np.float32) for _ in range(4)]
+    eager = m.upscale(batch, 4)                       # first sight: eager
+    assert not getattr(m, "_infer_graphs", None)
+    second = m.upscale(batch, 4)                      # second sight: captured + replayed
+    assert len(m._infer_graphs) == 1 and all(v is not False for v in m._infer_graphs.values())
+    third = m.upscale(batch, 4)
+    assert np.array_equal(eager, second) and np.array_equal(eager, third)
+    other = m.upscale([b[:, :9, :13] for b in batch], 4)   # another shape: eager, cache untouched
+    assert other.shape == (4, 3, 36, 52) and len(m._infer_graphs) == 1
+    m2 = _model(name, flags, training=True, seed=11)
+    path = m2.save(str(tmp_path))
+    m.restore(path)
+    replayed = m.upscale(batch, 4)
+    fresh = _model(name, flags, seed=99)
+    fresh.restore(path)
+    assert np.array_equal(replayed, fresh.upscale(batch, 4)) and not np.array_equal(replayed, eager)
