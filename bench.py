@@ -58,8 +58,10 @@ FULL_IMAGE = (3, 339, 510)                               # DIV2K-val-like LR ima
 # HBM bytes per launch of the dominant kernel: NOT measured by this run (counters need rocprofv3);
 # taken from the committed PMC passes -- FETCH_SIZE doubled per the guide's gfx950 correction +
 # WRITE_SIZE, both in KB.  roofline.traffic_source names the file.
-HBM_TRAFFIC_PER_LAUNCH = (2 * 3919.0 + 7149.6) * 1024
-HBM_TRAFFIC_SOURCE = "profiles/r01_h_pmc_conv3x3_relu_final.csv (rocprofv3 --pmc passes; constant, not measured by this run)"
+HBM_TRAFFIC_PER_LAUNCH = (2 * 3919.5 + 6982.4) * 1024          # one whole-batch launch (3 x 48 tiles)
+HBM_TRAFFIC_PER_STRIP_LAUNCH = (2 * 2227.0 + 3457.1) * 1024     # one half-batch strip launch (two per layer)
+HBM_TRAFFIC_SOURCE = ("profiles/r02_pmc_conv_strip_vs_wide.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                      "`bench.py --roofline-only`, tools/pmc_conv.sh; a constant, not measured by this run)")
 
 
 def conv_flop(c):
@@ -273,13 +275,16 @@ def roofline_block(dev, c=CH, full=True, dual=False):
     alg_bytes = 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c)
     blk = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-           "traffic": HBM_TRAFFIC_PER_LAUNCH if (c == CH and not dual) else None,
+           "traffic": (2 * HBM_TRAFFIC_PER_STRIP_LAUNCH if dual else HBM_TRAFFIC_PER_LAUNCH) if c == CH else None,
            "avg_ms": graph_ms}
+    if c == CH:
+        blk["traffic_source"] = HBM_TRAFFIC_SOURCE
     if dual:
         blk.update({
             "kernel": "conv3x3_mfma_strip_kernel<1> (fused conv3x3+bias+ReLU, 5x16 / 4x16 pixel tiles), two concurrent "
                       "half-batch launches (8x%dx48x48 each) = one 16x%dx48x48 fp32 layer" % (c, c),
             "launches_per_layer": 2, "flop_per_launch": flop // 2, "flop_per_layer": flop,
+            "traffic_is": "HBM-side bytes per LAYER (two launches)",
             "algorithmic_bytes_per_layer": alg_bytes,
             "timing": "HIP event pair around 10 replays of a captured graph of two 40-launch half-batch chains on two "
                       "streams; avg_ms = replay time / 40 = time per full-batch layer (median of 3).  Under rocprofv3 "
@@ -292,8 +297,6 @@ def roofline_block(dev, c=CH, full=True, dual=False):
             "timing": "HIP event pair around 10 replays of a captured chain of 40 dependent launches, per launch "
                       "(median of 3)",
             "algorithmic_bytes_per_launch": alg_bytes})
-        if c == CH:
-            blk["traffic_source"] = HBM_TRAFFIC_SOURCE
     if full:
         k_mean_ms, k_min_ms, pair_ms = time_dominant_kernel(dev)
         blk.update({"isolated_kernel_attached_ms": k_mean_ms, "isolated_min_ms": k_min_ms,
