@@ -39,6 +39,15 @@ int larva_pack_weights_batch(const float* const* w, float* const* wpk_fwd, float
                              const int* cout, const int* cin, const int* w_cin_total,
                              const int* w_cin_off, int njobs, void* stream);
 
+/* Everything train_step_larva does before its first convolution, in one launch: the packed images of
+ * njobs (<= 64) weights (the optimizer has just changed them, models/LarvaNet.py:114), the head's
+ * input zero-padded to 16 channels (x16 [N][16][H][W]: channels [0, C) are written, the others must
+ * already be zero) and the bicubic x4 base image (models/LarvaNet.py:283-285; base [N][C][4H][4W]).
+ * x16 and base may be NULL (base needs x16). */
+int larva_step_prologue(const float* const* w, float* const* wpk_fwd, float* const* wpk_bwd, const int* cout,
+                        const int* cin, const int* w_cin_total, const int* w_cin_off, int njobs, const float* x,
+                        float* x16, float* base, int N, int C, int H, int W, void* stream);
+
 /* ---- fused 3x3 convolution (forward and input-gradient) -----------------------------------
  * Replaces nn.Conv2d(k=3,s=1,p=1) plus its elementwise neighbours:
  *   conv+ReLU                 models/LarvaNet.py:210-211, 256-257

@@ -322,6 +322,26 @@ class JointInputGrad:
         return hit[0]
 
 
+def step_prologue(pcs, x):
+    """One launch for what precedes a training step's first conv: every conv's packed images (pack_all),
+    the head's 16-channel padded input and the bicubic x4 base image -> (x16, base), or None when the
+    shape / job count does not fit that launch (the caller then issues the three steps separately)."""
+    jobs = []
+    for pc in pcs:
+        jobs += pc.jobs()
+    N, C, H, W = (int(v) for v in x.shape)
+    if len(jobs) > 64 or C > 16 or PaddedWidth.current is not None or not x.is_contiguous():
+        return None
+    x16 = StepScope.padded_input((N, 16, H, W), x.device)
+    base = torch.empty((N, C, 4 * H, 4 * W), device=x.device, dtype=torch.float32)
+    with torch.no_grad():
+        K.step_prologue(jobs, x.detach(), x16, base)
+    for pc in pcs:
+        pc._mark_packed()
+        pc._prepacked = True
+    return x16, base
+
+
 def pack_all(pcs):
     """One launch (per 64 jobs) packing every conv of a network; each PackedConv then skips its
     own repack at its next refresh()."""
@@ -594,14 +614,15 @@ class HeadFn(torch.autograd.Function):
     direct = os.environ.get("LARVA_HEAD_DIRECT", "0") != "0"
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pc):
+    def forward(ctx, x, weight, bias, pc, x16=None):
         N, C, H, W = x.shape
         P = PaddedWidth.pitch_of(W) if _lw() is not None else W
         cout = int(weight.shape[0])
         training = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])   # a weight gradient will be asked for
         use_direct = HeadFn.direct and C == 3 and cout % 16 == 0
-        x16 = None
-        if training or not use_direct:
+        if x16 is not None:      # prepared by the step's prologue launch (step_prologue)
+            pass
+        elif training or not use_direct:
             x16 = StepScope.padded_input((N, 16, H, P), x.device)  # channels C..15 / columns W..P-1 stay zero
             x16[:, :C, :, :W] = x
         if use_direct:
@@ -626,8 +647,8 @@ class HeadFn(torch.autograd.Function):
             DualChain.join()   # dy comes off the two dgrad chains and is read right here
         (dw, db), = _wgrad([(dy, x16, ctx.wshape, 0, cin, tw, tb)], cout, 16, inplace=tw is not None)
         if tw is not None:
-            return None, None, None, None
-        return None, dw, db, None
+            return None, None, None, None, None
+        return None, dw, db, None, None
 
 
 class BodyFn(torch.autograd.Function):
@@ -903,8 +924,10 @@ class ExitsFn(torch.autograd.Function):
             if JointInputGrad.can_park(pc1):
                 JointInputGrad.park(feas[i], dhs[i], pc1)  # the next body adds it to its own input gradient
             else:
-                dfeas[i] = K.conv3x3(dhs[i], pc1.get()[0][1], c)
+                # (the last exit: its input gradient is the first link of the backward layer chain)
+                dfeas[i] = DualChain.conv(dhs[i], pc1.get()[0][1], c)
             jobs += [(dhs[i], feas[i], ctx.wshape, 0, c) + _targets(pc1), (dyls[i], hs[i], ctx.wshape, 0, c) + _targets(pc2)]
+        DualChain.end_of_node(True)
         inplace = all(_targets(pc)[0] is not None for i in live for pc in legs[i])
         for k, (dw, db) in enumerate(_wgrad(jobs, c, c, inplace=inplace) if jobs else []):
             i, which = live[k // 2], k % 2

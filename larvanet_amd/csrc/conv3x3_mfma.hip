@@ -25,6 +25,7 @@
 //
 // Roofline: fp32 MFMA (2*9*Cin*Cout FLOP per pixel; 41 472 at 48 channels) -- see DESIGN.md.
 #include "larva_common.h"
+#include "larva_bicubic.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 
@@ -848,12 +849,11 @@ __host__ __device__ constexpr int packed_floats(int cout, int cin) {
 
 // All layers of a network in one launch (blockIdx.y = layer): 41 packs per training step would
 // otherwise be 41 launch boundaries for 3 us of work each.
-__global__ void pack_weights_batch_kernel(PackBatch b) {
-  const PackJob& j = b.job[blockIdx.y];
+__device__ __forceinline__ void pack_job(const PackJob& j, int first, int stride) {
   const int csf = cout_stride(j.cout), csb = cout_stride(j.cin);
   const int nf = packed_floats(j.cout, j.cin);
   const int nb = packed_floats(j.cin, j.cout);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += gridDim.x * blockDim.x) {
+  for (int i = first; i < nf + nb; i += stride) {
     if (i < nf) {
       if (!j.fwd) continue;
       const int co = i % csf;
@@ -878,6 +878,42 @@ __global__ void pack_weights_batch_kernel(PackBatch b) {
         v = j.w[((size_t)(chunk * kCh + k) * j.w_cin_total + j.w_cin_off + ci) * 9 + (8 - tap)];
       j.bwd[q] = v;
     }
+  }
+}
+
+__global__ void pack_weights_batch_kernel(PackBatch b) {
+  pack_job(b.job[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// Everything a training step does before its first convolution, in ONE launch (blockIdx.y = role):
+// the kernel-layout weight images of all layers (the optimizer has just changed the weights), the
+// head's input zero-padded to 16 channels (HeadFn) and the bicubic x4 base image
+// (models/LarvaNet.py:283-285).  As three launches these were 8 + 4 + 7 us of launch-latency-bound
+// work in front of the layer chain.
+constexpr int kProloguePadSlices = 2, kPrologueBicSlices = 8;
+struct PrologueArgs {
+  PackBatch packs;
+  int npack;
+  const float* x;     // [N][C][H][W], C <= 16
+  float* x16;         // [N][16][H][W]: channels [0, C) copied (the rest stay zero: written once by the host)
+  float* base;        // [N][C][4H][4W]
+  int N, C, H, W;
+};
+
+__global__ __launch_bounds__(256) void step_prologue_kernel(PrologueArgs a) {
+  const int y = blockIdx.y;
+  const int tid = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+  if (y < a.npack) {
+    pack_job(a.packs.job[y], tid, nthr);
+  } else if (y < a.npack + kProloguePadSlices) {
+    const int plane = a.H * a.W, per_img = a.C * plane, total = a.N * per_img;
+    for (int i = (y - a.npack) * nthr + tid; i < total; i += nthr * kProloguePadSlices) {
+      const int n = i / per_img, r = i - n * per_img;
+      a.x16[(size_t)n * 16 * plane + r] = a.x[i];
+    }
+  } else {
+    const int slice = y - a.npack - kProloguePadSlices;
+    bicubic4_body(a.x, a.base, a.N * a.C, a.H, a.W, (long long)slice * nthr + tid, (long long)nthr * kPrologueBicSlices);
   }
 }
 
@@ -1011,6 +1047,31 @@ int larva_pack_weights_batch(const float* const* w, float* const* wpk_fwd, float
   }
   hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((max_total + 255) / 256, njobs), dim3(256), 0,
                      (hipStream_t)stream, b);
+  return (int)hipGetLastError();
+}
+
+// Training-step prologue in one launch: larva_pack_weights_batch of njobs (<= 64) weights + the head's
+// 16-channel padded copy of x ([N][C][H][W], C <= 16; x16 [N][16][H][W], channels >= C untouched) + the
+// bicubic x4 base image of x (base [N][C][4H][4W]).  x16 / base may be NULL to skip that part.
+int larva_step_prologue(const float* const* w, float* const* wpk_fwd, float* const* wpk_bwd, const int* cout,
+                        const int* cin, const int* w_cin_total, const int* w_cin_off, int njobs, const float* x,
+                        float* x16, float* base, int N, int C, int H, int W, void* stream) {
+  if (njobs < 0 || njobs > kMaxPackJobs || !x || N <= 0 || C <= 0 || C > 16 || H <= 0 || W <= 0)
+    return (int)hipErrorInvalidValue;
+  if ((long long)N * 16 * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
+  if (base && (reinterpret_cast<uintptr_t>(base) & 15)) return (int)hipErrorInvalidValue;
+  PrologueArgs a{};
+  for (int i = 0; i < njobs; ++i) {
+    if (!w[i] || cout[i] % kCh || cin[i] % kCh || cout[i] <= 0 || cin[i] <= 0) return (int)hipErrorInvalidValue;
+    a.packs.job[i] = PackJob{w[i], wpk_fwd[i], wpk_bwd[i], cout[i], cin[i], w_cin_total[i], w_cin_off[i]};
+  }
+  a.npack = njobs;
+  a.x = x; a.x16 = x16; a.base = base;
+  a.N = N; a.C = C; a.H = H; a.W = W;
+  const int roles = njobs + (x16 ? kProloguePadSlices : 0) + (base ? kPrologueBicSlices : 0);
+  if (!x16 && base) return (int)hipErrorInvalidValue;   // (roles are positional: pad slices precede the bicubic ones)
+  if (roles == 0) return 0;
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(192, roles), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

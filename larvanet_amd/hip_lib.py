@@ -21,6 +21,9 @@ SIGNATURES = {
                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_pack_weights_batch": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p,
                                                 ctypes.c_int, ctypes.c_void_p]),
+    "larva_step_prologue": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, ctypes.c_int,
+                                           _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_void_p]),
     "larva_conv3x3_fwd": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
                                          _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

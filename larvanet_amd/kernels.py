@@ -114,6 +114,32 @@ def strip_tile_table(H, P, device, phase=0):
     return hit or None
 
 
+def step_prologue(jobs, x, x16, base):
+    """pack_weights_batch(jobs) (<= 64 jobs) + x16[:, :C] = x + base = bicubic4(x) in one launch."""
+    lib = hip_lib.load()
+    if len(jobs) > 64:
+        raise RuntimeError("larvanet_amd: at most 64 pack jobs per prologue launch")
+    N, C, H, W = (int(v) for v in x.shape)
+    _chk(x, "x")
+    _chk(x16, "x16", (N, 16, H, W))
+    _chk(base, "base", (N, C, 4 * H, 4 * W))
+    ws, fs, bs, couts, cins, totals, offs = [], [], [], [], [], [], []
+    for (w, fwd, bwd, cout, cin_k, cin_off) in jobs:
+        _chk(w, "w")
+        ws.append(w.data_ptr())
+        fs.append(_chk(fwd, "wpk_fwd", (packed_weight_floats(cout, cin_k),)))
+        bs.append(None if bwd is None else _chk(bwd, "wpk_bwd", (packed_weight_floats(cin_k, cout),)))
+        couts.append(cout)
+        cins.append(cin_k)
+        totals.append(int(w.shape[1]))
+        offs.append(cin_off)
+    code = lib.larva_step_prologue(hip_lib.ptr_array(ws), hip_lib.ptr_array(fs), hip_lib.ptr_array(bs),
+                                   hip_lib.int_array(couts), hip_lib.int_array(cins), hip_lib.int_array(totals),
+                                   hip_lib.int_array(offs), len(jobs), x.data_ptr(), x16.data_ptr(), base.data_ptr(),
+                                   N, C, H, W, _stream())
+    hip_lib.check(code, "larva_step_prologue")
+
+
 def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=None,
             shuffle=False, base=None, out=None, logical_w=None, images=None, strips=False):
     """Fused 3x3 conv over the channel concatenation of `srcs` (list of [N][c][H][P]).

@@ -21,6 +21,7 @@ from .. import dist as ldist
 from .. import kernels as K
 from ..autograd import (BodyFn, DualChain, ExitFn, ExitsFn, GradBucket, HeadFn, L1LossFn, LegFn, LossTerm, PackedConv, PaddedWidth, mean_of_terms,
                         SideStreams, StepScope, pack_all)
+from ..autograd import step_prologue as autograd_step_prologue
 from ..optim import FlatAdamW, flatten_parameters
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
 from .base import BaseModel
@@ -94,11 +95,11 @@ class LarvaHead(nn.Module):
         init_conv(self.feature_extraction)
         self._pc = PackedConv(self.feature_extraction.weight, self.feature_extraction.bias, cin_pad=16)
 
-    def forward(self, x):
+    def forward(self, x, x16=None):
         _require_hip(x)
         c = self.feature_extraction
         self._pc.refresh()
-        return HeadFn.apply(x.contiguous(), c.weight, c.bias, self._pc)
+        return HeadFn.apply(x.contiguous(), c.weight, c.bias, self._pc, x16)
 
 
 class LarvaLeg(nn.Module):
@@ -192,6 +193,16 @@ class LarvaNetModule(nn.Module):
     def refresh_packed_weights(self):
         """Rebuild every conv's kernel-layout image with one batched launch (training forward)."""
         pack_all(self.packed_convs())
+
+    def step_prologue(self, x):
+        """refresh_packed_weights() + base(x) + the head's padded input as ONE launch -> (base, x16);
+        x16 is None when the fused launch does not apply (the head then pads its input itself)."""
+        _require_hip(x)
+        res = autograd_step_prologue(self.packed_convs(), x) if self.interpolate == "bicubic" else None
+        if res is None:
+            self.refresh_packed_weights()
+            return self.base(x), None
+        return res[1], res[0]
 
     def base(self, x):
         """F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False) (models/LarvaNet.py:283-285)."""
@@ -377,9 +388,9 @@ class LarvaNet(BaseModel):
     def _exit_losses(self, input_tensor, truth_tensor):
         """Forward through every exit (models/LarvaNet.py:102-109). Returns (loss, last output)."""
         net = self.model
-        net.refresh_packed_weights()
-        base = net.base(input_tensor)   # (before the head: the layer chain that starts there may fork into two streams)
-        fea = net.head(input_tensor)
+        # weight images + bicubic base + the head's padded input in one launch, before the layer chain forks
+        base, x16 = net.step_prologue(input_tensor)
+        fea = net.head(input_tensor, x16)
         if self._exits_batched():
             # the exits do not feed the bodies: run the body chain first, then all exits together
             feas = []

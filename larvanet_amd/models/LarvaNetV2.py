@@ -103,9 +103,8 @@ class LarvaNet(V1.LarvaNet):
     def _exit_losses(self, input_tensor, truth_tensor):
         """models/LarvaNetV2.py:104-123: every exit plus the tail, / (M + 1)."""
         net = self.model
-        net.refresh_packed_weights()
-        base = net.base(input_tensor)   # (before the head: the layer chain that starts there may fork into two streams)
-        fea = net.head(input_tensor)
+        base, x16 = net.step_prologue(input_tensor)
+        fea = net.head(input_tensor, x16)
         terms = []
         feats = []
         if self._exits_batched():

@@ -707,3 +707,31 @@ def test_direct_head_conv_against_oracle_and_mfma_path(hip_device, N, H, W, pitc
     torch.cuda.synchronize()
     scale = float(ref.abs().max())
     assert float((out - ref).abs().max()) <= 1e-5 * scale
+
+
+def test_step_prologue_equals_its_three_launches(hip_device):
+    """larva_step_prologue (weight images of all layers + the head's padded input + the bicubic base in
+    one launch) against pack_weights_batch, the padded copy and bicubic4: identical bits."""
+    from larvanet_amd import kernels as K
+    rng = np.random.default_rng(3)
+    ws = [_dev(_rand(rng, (48, 48, 3, 3), 0.05), hip_device) for _ in range(5)] + [_dev(_rand(rng, (48, 3, 3, 3), 0.1), hip_device)]
+    def bufs():
+        out = []
+        for w in ws:
+            cin_k = 16 if w.shape[1] == 3 else 48
+            f = torch.full((K.packed_weight_floats(48, cin_k),), -1.0, device=hip_device)
+            b = None if w.shape[1] == 3 else torch.full((K.packed_weight_floats(cin_k, 48),), -1.0, device=hip_device)
+            out.append((w, f, b, 48, cin_k, 0))
+        return out
+    ref_jobs, got_jobs = bufs(), bufs()
+    x = _dev(_rand(rng, (5, 3, 13, 20), 80.0), hip_device)
+    K.pack_weights_batch(ref_jobs)
+    ref_base = K.bicubic4(x)
+    x16 = torch.zeros((5, 16, 13, 20), device=hip_device)
+    base = torch.empty_like(ref_base)
+    K.step_prologue(got_jobs, x, x16, base)
+    torch.cuda.synchronize()
+    for (_, f0, b0, *_), (_, f1, b1, *_) in zip(ref_jobs, got_jobs):
+        assert torch.equal(f0, f1) and (b0 is None or torch.equal(b0, b1))
+    assert torch.equal(base, ref_base)
+    assert torch.equal(x16[:, :3], x) and not bool(x16[:, 3:].any())

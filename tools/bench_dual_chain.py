@@ -95,3 +95,35 @@ print("  four quarter-batch chains                           %.2f" % timed(graph
 print("  four quarter-batch chains, staggered                %.2f" % timed(graphed(lambda: multi([(0, 4), (4, 8), (8, 12), (12, 16)], 1))))
 print("  two chains 9 + 7 images                             %.2f" % timed(graphed(lambda: multi([(0, 9), (9, 16)]))))
 print("  two chains, complementary tile tables               %.2f" % timed(graphed(lambda: multi([(0, 8), (8, 16)], 0, True))))
+
+
+# the same two chains the way a training step sees them: every layer writes a tensor of its own (kept for
+# backward) and reads weights of its own, with the step's epilogue mix (ReLU / +res0 / +res0+res1)
+acts = [bufs[0]] + [torch.empty_like(bufs[0]) for _ in range(LAYERS)]
+wpks = [K.pack_weights((torch.randn(C, C, 3, 3, generator=g) * 0.02).to(dev))[0] for _ in range(LAYERS)]
+
+
+def step_like(parts, epi_mix, distinct, own_weights=True):
+    cur = torch.cuda.current_stream()
+    for k, rng in enumerate(parts):
+        st = streams[k]
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            for i in range(LAYERS):
+                src = acts[i] if distinct else bufs[i & 1]
+                dst = acts[i + 1] if distinct else bufs[(i + 1) & 1]
+                kw = {"relu": True}
+                if epi_mix and i % 2 == 1:
+                    prev = acts[i - 1] if distinct else bufs[(i - 1) & 1]
+                    kw = {"res0": prev} if i % 8 != 7 else {"res0": prev, "res1": acts[max(i - 7, 0)] if distinct else bufs[0]}
+                K.conv3x3(src, wpks[i] if (distinct and own_weights) else fwd, C, bias=b, out=dst, images=rng, strips=2 if k else True, **kw)
+    for k in range(len(parts)):
+        cur.wait_stream(streams[k])
+
+
+HALVES = [(0, 8), (8, 16)]
+print("  two chains, ReLU only, ping-pong buffers               %.2f" % timed(graphed(lambda: step_like(HALVES, False, False))))
+print("  two chains, ReLU only, a tensor + weights per layer    %.2f" % timed(graphed(lambda: step_like(HALVES, False, True))))
+print("  two chains, step's epilogue mix, ping-pong             %.2f" % timed(graphed(lambda: step_like(HALVES, True, False))))
+print("  two chains, step's epilogue mix, tensor per layer      %.2f" % timed(graphed(lambda: step_like(HALVES, True, True))))
+print("  two chains, ReLU only, tensor per layer, ONE weight image  %.2f" % timed(graphed(lambda: step_like(HALVES, False, True, False))))
