@@ -149,6 +149,17 @@ int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* co
                         const int* cin_valid, const int* w_cin_total, int njobs, int splits,
                         int N, int cout, int cin, int H, int W, void* stream);
 
+/* Phase 1 as ONE grid of nwg workgroups over all njobs (<= 64) layers: their tiles form one sequence
+ * cut evenly over the workgroups (no CU idles at any layer count; a workgroup whose share crosses a
+ * layer boundary contributes a partial image to both layers).  48 -> 48 channels, W % 4 == 0, 16-byte
+ * aligned tensors (hipErrorNotSupported otherwise).  splits_out[i] = partial images of layer i for
+ * larva_wgrad_reduce; partial[i] holds larva_wgrad_flat_max_splits(njobs, nwg, tiles per layer) images
+ * (tiles per layer = N * ceil(H/3) * ceil(W/48)). */
+int larva_wgrad_flat_max_splits(int njobs, int nwg, int tiles_per_layer);
+int larva_conv3x3_wgrad_partial_flat(const float* const* dy, const float* const* x, float* const* partial,
+                                     int njobs, int nwg, int N, int cout, int cin, int H, int W,
+                                     int* splits_out, void* stream);
+
 /* The two phases separately: partial images for njobs (<= 64) layers, and the fixed-order
  * reduction of up to 64 layers' partial images (each with its own split count and kernel shape)
  * in one launch. */

@@ -427,10 +427,15 @@ class DeferredWgrad:
 
     _late = []      # launches held back by a split flush: [(cout, cin, jobs)]
 
+    # one grid over all layers of a launch (kernels.conv3x3_wgrad_partial_flat) where the shape allows
+    flat = os.environ.get("LARVA_WGRAD_FLAT", "1") != "0"
+
     @classmethod
-    def _launches(cls):
+    def _launches(cls, split=False):
         pending, cls._pending = cls._pending, {}
         cap = max(1, min(cls.jobs_per_launch, K.max_wgrad_jobs()))
+        if cls.flat and not split:
+            cap = K.max_wgrad_jobs()   # a flat grid has no preferred layer count: as many layers per launch as fit
         out = []
         for (cout, cin), jobs in pending.items():
             # from the end of the gradient bucket downwards (= roughly the order backward produced
@@ -448,6 +453,10 @@ class DeferredWgrad:
         of them (each layer with its own split count and kernel shape)."""
         reduce_jobs = []
         for cout, cin, chunk in launches:
+            res = K.conv3x3_wgrad_partial_flat(chunk, cout, cin, _WGRAD_WORKGROUPS) if DeferredWgrad.flat else None
+            if res is not None:
+                reduce_jobs += [dict(j, partial=p, splits=s, cout=cout, cin=cin) for j, p, s in zip(chunk, *res)]
+                continue
             parts, used = K.conv3x3_wgrad_partial(chunk, cout, cin, _splits(len(chunk)))
             reduce_jobs += [dict(j, partial=p, splits=used, cout=cout, cin=cin) for j, p in zip(chunk, parts)]
         for i in range(0, len(reduce_jobs), 64):
@@ -460,7 +469,7 @@ class DeferredWgrad:
         waits for flush_late(), so that a data-parallel caller can start all-reducing the first
         half while the second is still being computed.  Returns the tensors the issued launches
         write (dw, db ...) when split, else None."""
-        launches = cls._launches()
+        launches = cls._launches(split)
         n_early = max(1, len(launches) // 2) if split else len(launches)
         cls._issue(launches[:n_early])
         cls._late = launches[n_early:]

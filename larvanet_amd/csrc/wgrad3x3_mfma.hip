@@ -56,6 +56,11 @@ struct WgradBatch {
   int N, H, W;
   int tiles_x, tiles_y;
   int vec_ok;
+  // flat launch (wgrad3x3_pipe_flat_kernel): the tiles of all njobs layers form one sequence that is
+  // cut evenly over the workgroups; first_wg[j] = the first workgroup whose share touches layer j
+  // (its partial image for that layer is image 0, the next workgroup's image 1, ...)
+  int njobs;
+  short first_wg[kMaxJobs];
 };
 
 template <int COUT, int CIN>
@@ -550,9 +555,10 @@ __device__ __forceinline__ void pipe_first_tile(const WgradBatch& b, const PipeG
   }
 }
 
+// Tiles [t_begin, t_end) of layer `j` -> the partial image at `part`.
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV>
-__device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob& j, float* smem, int split,
-                                             int splits, int tid) {
+__device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob& j, float* smem, int t_begin,
+                                             int t_end, float* part, int tid) {
   using C = WgCfg<COUT, CIN>;
   using P = WgPipe<COUT, CIN>;
   const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -566,10 +572,6 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob
 #pragma unroll
   for (int c = 0; c < C::CT; ++c) bacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int total = b.N * b.tiles_x * b.tiles_y;
-  // (64-bit divisions run on the vector ALU: bring the wave-uniform results back to SGPRs)
-  const int t_begin = __builtin_amdgcn_readfirstlane((int)(((long long)total * split) / splits));
-  const int t_end = __builtin_amdgcn_readfirstlane((int)(((long long)total * (split + 1)) / splits));
   const int plane = b.H * b.W;
 
   PipeGeom<COUT, CIN> geom;
@@ -627,7 +629,6 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob
 
   // (the compiler does not see the asm MFMAs: cover their write-back before the accumulators are read)
   if constexpr (WG_ASM_MFMA && !WG_DIAG) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-  float* part = j.partial + (size_t)split * C::PARTIAL_FLOATS;
 #pragma unroll
   for (int c = 0; c < C::CT; ++c)
 #pragma unroll
@@ -643,6 +644,19 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob
 }
 
 template <int COUT, int CIN>
+__device__ __forceinline__ void wg_pipe_waves(const WgradBatch& b, const WgradJob& j, float* smem, int t_begin, int t_end,
+                                              float* part, int tid, int wave) {
+  using C = WgCfg<COUT, CIN>;
+  constexpr int NB = C::NB;
+  constexpr int W0 = (NB + 3) / 4, W1 = (NB + 2) / 4, W2 = (NB + 1) / 4, W3 = NB / 4;
+  // the bias sums ride on the last wave: it owns the fewest (ci group, tap) operands
+  if (wave == 0) wg_role_pipe<COUT, CIN, 0, W0, false, 0>(b, j, smem, t_begin, t_end, part, tid);
+  else if (wave == 1) wg_role_pipe<COUT, CIN, W0, W1, false, 1>(b, j, smem, t_begin, t_end, part, tid);
+  else if (wave == 2) wg_role_pipe<COUT, CIN, W0 + W1, W2, false, 2>(b, j, smem, t_begin, t_end, part, tid);
+  else wg_role_pipe<COUT, CIN, W0 + W1 + W2, W3, true, 3>(b, j, smem, t_begin, t_end, part, tid);
+}
+
+template <int COUT, int CIN>
 __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_kernel(WgradBatch b) {
   using C = WgCfg<COUT, CIN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -650,13 +664,41 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_kernel(WgradBatch b) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x, splits = gridDim.x;
-  constexpr int NB = C::NB;
-  constexpr int W0 = (NB + 3) / 4, W1 = (NB + 2) / 4, W2 = (NB + 1) / 4, W3 = NB / 4;
-  // the bias sums ride on the last wave: it owns the fewest (ci group, tap) operands
-  if (wave == 0) wg_role_pipe<COUT, CIN, 0, W0, false, 0>(b, j, smem, split, splits, tid);
-  else if (wave == 1) wg_role_pipe<COUT, CIN, W0, W1, false, 1>(b, j, smem, split, splits, tid);
-  else if (wave == 2) wg_role_pipe<COUT, CIN, W0 + W1, W2, false, 2>(b, j, smem, split, splits, tid);
-  else wg_role_pipe<COUT, CIN, W0 + W1 + W2, W3, true, 3>(b, j, smem, split, splits, tid);
+  const int total = b.N * b.tiles_x * b.tiles_y;
+  // (64-bit divisions run on the vector ALU: bring the wave-uniform results back to SGPRs)
+  const int t_begin = __builtin_amdgcn_readfirstlane((int)(((long long)total * split) / splits));
+  const int t_end = __builtin_amdgcn_readfirstlane((int)(((long long)total * (split + 1)) / splits));
+  wg_pipe_waves<COUT, CIN>(b, j, smem, t_begin, t_end, j.partial + (size_t)split * C::PARTIAL_FLOATS, tid, wave);
+}
+
+// One grid over ALL layers of a launch: the njobs x (tiles per layer) tiles form one sequence, workgroup w
+// owns [G w / nwg, G (w+1) / nwg) of it.  Where that share crosses a layer boundary the workgroup finishes
+// the layer (writes its partial image), restarts its staging pipeline on the next layer and goes on: no
+// CU idles at any layer count (40 layers on 256 CUs: 40 tiles each; as 32 x 8 + 8 x 32 workgroups the
+// second launch ran at 12.8 us per layer against 11.6), and a step writes 256 + (layers - 1) partial
+// images instead of 2 x 256.
+template <int COUT, int CIN>
+__global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_flat_kernel(WgradBatch b) {
+  using C = WgCfg<COUT, CIN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = blockIdx.x, nwg = gridDim.x;
+  const int total = b.N * b.tiles_x * b.tiles_y;
+  const long long G = (long long)total * b.njobs;
+  int g = __builtin_amdgcn_readfirstlane((int)((G * w) / nwg));
+  const int g_end = __builtin_amdgcn_readfirstlane((int)((G * (w + 1)) / nwg));
+  int jb = __builtin_amdgcn_readfirstlane(g / total);
+  while (g < g_end) {   // one pass per layer this workgroup touches (bounded: at most njobs)
+    const int base = jb * total;
+    const int seg_end = min(g_end, base + total);
+    const WgradJob& j = b.job[jb];
+    float* part = j.partial + (size_t)(w - b.first_wg[jb]) * C::PARTIAL_FLOATS;
+    wg_pipe_waves<COUT, CIN>(b, j, smem, g - base, seg_end - base, part, tid, wave);
+    __syncthreads();    // every wave is done with the tile buffers before the next layer restages them
+    g = seg_end;
+    ++jb;
+  }
 }
 
 template <int COUT, int CIN, bool VEC>
@@ -773,11 +815,75 @@ static hipError_t launch_wgrad(const WgradBatch& b, int njobs, int splits, hipSt
   return hipGetLastError();
 }
 
+template <int COUT, int CIN>
+static hipError_t launch_wgrad_flat(const WgradBatch& b, int nwg, hipStream_t stream) {
+  using P = WgPipe<COUT, CIN>;
+  static_assert(P::FITS, "the flat launch exists for the pipelined kernel only");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_pipe_flat_kernel<COUT, CIN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad3x3_pipe_flat_kernel<COUT, CIN>), dim3(nwg), dim3(256), P::LDS_BYTES, stream, b);
+  return hipGetLastError();
+}
+
 }  // namespace larva
 
 using namespace larva;
 
 extern "C" {
+
+// Phase 1 as ONE grid of `nwg` workgroups over all njobs (<= 64) layers (48 -> 48 channels, W % 4 == 0,
+// 16-byte aligned tensors; hipErrorNotSupported otherwise: use larva_conv3x3_wgrad_partial).  The layers'
+// tiles form one sequence cut evenly over the workgroups; a workgroup whose share crosses a layer boundary
+// contributes a partial image to both layers.  splits_out[i] = the number of partial images of layer i
+// (what larva_wgrad_reduce needs); partial[i] must hold larva_wgrad_flat_max_splits(njobs, nwg, tiles)
+// images.  Deterministic like the per-layer launch.
+int larva_wgrad_flat_max_splits(int njobs, int nwg, int tiles_per_layer) {
+  if (njobs < 1 || nwg < 1 || tiles_per_layer < 1) return 0;
+  const long long G = (long long)njobs * tiles_per_layer;
+  if (nwg > G) nwg = (int)G;
+  const long long smallest = G / nwg;                                   // the smallest share (>= 1)
+  return (int)((tiles_per_layer + smallest - 1) / smallest + 1);        // shares that can touch one layer
+}
+
+int larva_conv3x3_wgrad_partial_flat(const float* const* dy, const float* const* x, float* const* partial,
+                                     int njobs, int nwg, int N, int cout, int cin, int H, int W,
+                                     int* splits_out, void* stream) {
+  if (njobs < 1 || njobs > kMaxJobs || nwg < 1 || nwg > 32767 || N <= 0 || H <= 0 || W <= 0 || !splits_out)
+    return (int)hipErrorInvalidValue;
+  if (cout != 48 || cin != 48 || W % 4 || !wgrad_use_pipe()) return (int)hipErrorNotSupported;
+  WgradBatch b{};
+  for (int i = 0; i < njobs; ++i) {
+    if (!dy[i] || !x[i] || !partial[i]) return (int)hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(dy[i]) | reinterpret_cast<uintptr_t>(x[i])) & 15) return (int)hipErrorNotSupported;
+    b.job[i] = WgradJob{dy[i], x[i], partial[i]};
+  }
+  b.N = N; b.H = H; b.W = W;
+  b.tiles_x = (W + kTileCols - 1) / kTileCols;
+  b.tiles_y = (H + kTileRows - 1) / kTileRows;
+  b.vec_ok = 1;
+  b.njobs = njobs;
+  const long long total = (long long)N * b.tiles_x * b.tiles_y;
+  const long long G = total * njobs;
+  if (G >= (1ll << 31)) return (int)hipErrorInvalidValue;
+  if (nwg > G) nwg = (int)G;
+  // the same integer arithmetic as the kernel: share of workgroup w = [G w / nwg, G (w+1) / nwg)
+  int w = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const long long lo = total * i, hi = total * (i + 1);
+    while ((G * (w + 1)) / nwg <= lo) ++w;                    // first workgroup whose share ends beyond lo
+    b.first_wg[i] = (short)w;
+    int last = w;
+    while (last + 1 < nwg && (G * (last + 1)) / nwg < hi) ++last;
+    splits_out[i] = last - w + 1;
+    if (splits_out[i] > larva_wgrad_flat_max_splits(njobs, nwg, (int)total)) return (int)hipErrorInvalidValue;
+  }
+  return (int)launch_wgrad_flat<48, 48>(b, nwg, (hipStream_t)stream);
+}
 
 // Floats of partial-image workspace one job needs for `splits` workgroups.
 long long larva_wgrad_partial_floats(int cout, int cin, int splits) {

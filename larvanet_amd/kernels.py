@@ -390,6 +390,33 @@ def conv3x3_wgrad_partial(jobs, cout, cin, splits):
     return parts, int(used.value)
 
 
+def conv3x3_wgrad_partial_flat(jobs, cout, cin, nwg):
+    """Phase 1 of ALL jobs (<= 64 dicts {dy, x}, 48 -> 48 channels) as one grid of `nwg` workgroups ->
+    (partial tensors, [partial images per job]) or None when the flat launch does not apply."""
+    lib = hip_lib.load()
+    if not 1 <= len(jobs) <= 64 or (cout, cin) != (48, 48):
+        return None
+    N, _, H, W = (int(v) for v in jobs[0]["dy"].shape)
+    if W % 4:
+        return None
+    tiles = N * ((H + 2) // 3) * ((W + 47) // 48)
+    cap = int(lib.larva_wgrad_flat_max_splits(len(jobs), int(nwg), tiles))
+    nfl = wgrad_partial_floats(cout, cin, cap)
+    dys = [_chk(j["dy"], "dy", (N, cout, H, W)) for j in jobs]
+    xs = [_chk(j["x"], "x", (N, cin, H, W)) for j in jobs]
+    parts = [torch.empty(nfl, device=jobs[0]["dy"].device, dtype=torch.float32) for _ in jobs]
+    used = (ctypes.c_int * len(jobs))()
+    code = lib.larva_conv3x3_wgrad_partial_flat(
+        hip_lib.ptr_array(dys), hip_lib.ptr_array(xs), hip_lib.ptr_array([p.data_ptr() for p in parts]),
+        len(jobs), int(nwg), N, cout, cin, H, W, used, _stream())
+    if code == 801:
+        return None
+    hip_lib.check(code, "larva_conv3x3_wgrad_partial_flat")
+    splits = [int(v) for v in used]
+    per = wgrad_partial_floats(cout, cin, 1)
+    return [p[:per * s] for p, s in zip(parts, splits)], splits
+
+
 def wgrad_reduce(jobs, cout=None, cin=None):
     """Phase 2: jobs (<= 64 dicts {partial, splits, dw, db (or None), cin_off, cin_valid[, cout, cin]})
     reduced in ONE launch; dw/db are overwritten.  cout/cin: the kernel shape of every job that does
