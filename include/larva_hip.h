@@ -120,14 +120,16 @@ int larva_conv3x3_exit_l1_batch(int njobs, const float* const* src, int n_src, i
  * five_rows << 31; the two heights alternate along the table, `phase` 0 / 1 = it starts with a
  * 5-row / 4-row tile), returns the tile count (> cap: table truncated) or < 0 when H cannot be cut
  * into 5s and 4s.  larva_conv3x3_fwd_strips: larva_conv3x3_fwd_pitched with `tile_tab` = a DEVICE
- * copy of larva_strip_tile_table(H, pitch); cout 48 and the 16-byte staging path only
+ * copy of larva_strip_tile_table(H, pitch), plain_stores = write the output with plain instead of
+ * non-temporal stores (the forward chain's policy); cout 48 and the 16-byte staging path only
  * (hipErrorNotSupported otherwise).  An image sub-range of a batch is addressed by offsetting the
  * operand pointers and passing its image count as N. */
 int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap);
 int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                              const float* bias, const float* res0, const float* res1, const float* mask,
                              const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                             int relu, int mode, const unsigned* tile_tab, int tiles_per_image, void* stream);
+                             int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
+                             void* stream);
 
 /* Measurement only: the same launch `iters` times with kernel-attached events
  * (hipExtLaunchKernelGGL); mean/min kernel duration in ms.  Synchronises the stream. */

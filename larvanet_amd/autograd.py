@@ -122,6 +122,9 @@ class DualChain:
     hand its memory to a later allocation on the main stream)."""
 
     enabled = False      # set by StepScope
+    # output store policy of the strip launches: "fwd" = plain stores in the forward chain (read at once by
+    # the next launch), non-temporal in the backward chain; "all" / "none" for A/B timing
+    plain_stores = os.environ.get("LARVA_STRIP_PLAIN", "fwd")
     lazy_fwd = False
     lazy_bwd = False
     max_workgroups = 512   # one full-batch launch with more 3 x 48 tiles than this already overlaps by itself
@@ -146,8 +149,9 @@ class DualChain:
         return cls._streams[key]
 
     @classmethod
-    def conv(cls, srcs, wpk, cout, **kw):
-        """kernels.conv3x3 for a link of the chain (same arguments, `out` allocated here)."""
+    def conv(cls, srcs, wpk, cout, forward=False, **kw):
+        """kernels.conv3x3 for a link of the chain (same arguments, `out` allocated here).  forward: a
+        link of the forward chain (its output is read by the next launch at once: plain stores)."""
         first = srcs if isinstance(srcs, torch.Tensor) else srcs[0]
         n, _, h, p = (int(v) for v in first.shape)
         if kw.get("logical_w") is not None or kw.get("shuffle") or not cls.wants(n, h, p):
@@ -166,7 +170,7 @@ class DualChain:
         half = n // 2
         for k, rng in enumerate(((0, half), (half, n))):
             with torch.cuda.stream(cls._stream(k)):
-                K.conv3x3(srcs, wpk, cout, out=out, images=rng, strips=2 if k else True, **kw)
+                K.conv3x3(srcs, wpk, cout, out=out, images=rng, strips=2 if k else True, plain_stores=(cls.plain_stores == "all" or (forward and cls.plain_stores == "fwd")), **kw)
         return out
 
     @classmethod
@@ -638,7 +642,7 @@ class HeadFn(torch.autograd.Function):
             out = K.head_conv3_direct(x, weight.detach(), bias.detach(), pitch=P)
         else:
             (fwd, _), = pc.get()
-            out = DualChain.conv(x16, fwd, cout, bias=bias.detach(), logical_w=_lw())
+            out = DualChain.conv(x16, fwd, cout, forward=True, bias=bias.detach(), logical_w=_lw())
             DualChain.end_of_node(False)
         if x16 is not None:
             ctx.save_for_backward(x16)
@@ -675,11 +679,11 @@ class BodyFn(torch.autograd.Function):
             (f1, _), = pcs[2 * j].get()
             (f2, _), = pcs[2 * j + 1].get()
             c = int(w1.shape[0])
-            h = DualChain.conv(fea, f1, c, bias=b1.detach(), relu=True, logical_w=_lw())
+            h = DualChain.conv(fea, f1, c, forward=True, bias=b1.detach(), relu=True, logical_w=_lw())
             if j == nb - 1:
-                nxt = DualChain.conv(h, f2, c, bias=b2.detach(), res0=fea, res1=x, logical_w=_lw())
+                nxt = DualChain.conv(h, f2, c, forward=True, bias=b2.detach(), res0=fea, res1=x, logical_w=_lw())
             else:
-                nxt = DualChain.conv(h, f2, c, bias=b2.detach(), res0=fea, logical_w=_lw())
+                nxt = DualChain.conv(h, f2, c, forward=True, bias=b2.detach(), res0=fea, logical_w=_lw())
             keep.append(h)
             if j < nb - 1:
                 keep.append(nxt)

@@ -28,6 +28,7 @@
 #include "larva_bicubic.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <type_traits>
 
 // Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
 // bit 0 = skip the MFMA blocks, bit 1 = skip the global->LDS staging, bit 2 = skip the
@@ -44,6 +45,7 @@
 #ifndef LARVA_DIAG
 #define LARVA_DIAG 0
 #endif
+
 // LARVA_DIAG bit 5 (32): in-kernel timeline.  Wave 0 of every workgroup writes 100 MHz wall-clock
 // stamps (s_memrealtime) at kernel entry, after the DMA issue, after the first chunk landed, after
 // the K loop, after the stores were issued and after they drained, to the buffer given to
@@ -115,6 +117,7 @@ struct ConvArgs {
   const float* truth;         // [N][COUT/16][4H][4W], the image the exit is compared with
   float* grad;                // [N][COUT][H][pitch]: sign(out - truth) * gval, pixel-unshuffled
   float* partial;             // [4 * nwg]: sum |out - truth| of every MFMA wave's share of its tile
+  int plain_stores;           // strip kernel, mode-0 output: plain instead of non-temporal stores (see the epilogue)
   float gval;                 // d loss / d out element = seed * (1/M) / numel
                               // (`out` may be null with this epilogue: the exit's image is not wanted)
   // ceil(2^40 / d) for d = tiles_x, tiles_y, cin_per_src / 8: the kernel's wave-uniform divisions
@@ -685,32 +688,48 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         if (y < a.H && x < a.W) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
       }
   } else {
+    // Output store policy.  Non-temporal for the 3 x 48 tiles: the 7 MB store burst of the 256
+    // workgroups drains faster (-0.7 us per launch in a chain of whole-batch launches that writes a
+    // tensor per layer: 15.3 vs 16.1 us).  The strip kernel takes the policy per launch
+    // (a.plain_stores): with two half-batch chains sharing the CUs, plain stores are 0.5 us per
+    // layer faster in the FORWARD chain (the next layer reads the tensor at once: 14.2-14.5 ->
+    // 13.75-14.0 us, forward region of the step 604 -> 581 us) and 0.6 us per layer slower in the
+    // backward chain (same-box A/B of the step: 1.696 ms all-plain vs 1.688 all-non-temporal).
     const size_t plane = (size_t)a.H * a.pitch;
+    auto store_all = [&](auto plain_tag) {
+      constexpr bool kPlain = decltype(plain_tag)::value;
 #pragma unroll
-    for (int c = 0; c < NCT; ++c)
+      for (int c = 0; c < NCT; ++c)
 #pragma unroll
-      for (int p = 0; p < NPG; ++p) {
-        const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
-        const int y = y0 + prow, x = x0 + pcol * 16 + lr;
-        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
-        const f32x4 v = acc[c][p] + bias[c];
-        if (y < a.H && x < a.pitch) {
-          const bool real = x < a.W;  // columns [W, pitch) are kept at zero for the next layer
+        for (int p = 0; p < NPG; ++p) {
+          const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
+          const int y = y0 + prow, x = x0 + pcol * 16 + lr;
+          const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
+          const f32x4 v = acc[c][p] + bias[c];
+          if (y < a.H && x < a.pitch) {
+            const bool real = x < a.W;  // columns [W, pitch) are kept at zero for the next layer
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float o = v[r];
-            if constexpr (EPI == kEpiRelu) o = fmaxf(o, 0.f);
-            if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
-            if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
-            if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
-            o = real ? o : 0.f;
-            // non-temporal: the 7 MB store burst of the 256 workgroups drains faster (-0.7 us per
-            // launch measured); the lines still stay in the XCD's L2 for the next layer
-            if constexpr ((LARVA_DIAG & 16) != 0) a.out[idx0 + r * plane] = o;
-            else __builtin_nontemporal_store(o, &a.out[idx0 + r * plane]);
+            for (int r = 0; r < 4; ++r) {
+              float o = v[r];
+              if constexpr (EPI == kEpiRelu) o = fmaxf(o, 0.f);
+              if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
+              if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
+              if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
+              o = real ? o : 0.f;
+              if constexpr (kPlain) a.out[idx0 + r * plane] = o;
+              else __builtin_nontemporal_store(o, &a.out[idx0 + r * plane]);
+            }
           }
         }
-      }
+    };
+    if constexpr ((LARVA_DIAG & 16) != 0) {
+      store_all(std::true_type{});
+    } else if constexpr (G::COLS == 16) {
+      if (a.plain_stores) store_all(std::true_type{});
+      else store_all(std::false_type{});
+    } else {
+      store_all(std::false_type{});
+    }
   }
 #if LARVA_DIAG & 32
   stamp(4);
@@ -1302,14 +1321,17 @@ int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap) {
 }
 
 // larva_conv3x3_fwd_pitched on strip tiles: `tile_tab` = DEVICE copy of larva_strip_tile_table(H,
-// pitch) with `tiles_per_image` entries.  cout = 48 and the 16-byte staging path only (pitch % 4 == 0,
-// 16-byte aligned tensors), otherwise hipErrorNotSupported.  Results are bit-identical to
+// pitch) with `tiles_per_image` entries.  plain_stores: mode-0 output written with plain instead of
+// non-temporal stores (faster when the next launch reads it at once, see the kernel's epilogue).
+// cout = 48 and the 16-byte staging path only (pitch % 4 == 0, 16-byte aligned tensors), otherwise
+// hipErrorNotSupported.  Results are bit-identical to
 // larva_conv3x3_fwd_pitched: every output's K loop runs in the same order, only the assignment of
 // pixels to workgroups differs.
 int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                              const float* bias, const float* res0, const float* res1, const float* mask,
                              const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                             int relu, int mode, const unsigned* tile_tab, int tiles_per_image, void* stream) {
+                             int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
+                             void* stream) {
   if (cout != 48) return (int)hipErrorNotSupported;
   if (!tile_tab || tiles_per_image < 1) return (int)hipErrorInvalidValue;
   ConvArgs a;
@@ -1321,6 +1343,7 @@ int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src
   if (!aligned) return (int)hipErrorNotSupported;
   if ((long long)N * tiles_per_image >= (1ll << 20)) return (int)hipErrorInvalidValue;  // div_by_magic range
   a.tile_tab = tile_tab;
+  a.plain_stores = plain_stores ? 1 : 0;
   a.tiles_x = tiles_per_image;
   a.tiles_y = 1;
   a.magic_tx = div_magic(tiles_per_image);

@@ -47,7 +47,7 @@ SIGNATURES = {
                                                 _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                ctypes.c_int, ctypes.c_void_p]),
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_conv3x3_fwd_timed": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
                                                _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -141,7 +141,7 @@ def step_prologue(jobs, x, x16, base):
 
 
 def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=None,
-            shuffle=False, base=None, out=None, logical_w=None, images=None, strips=False):
+            shuffle=False, base=None, out=None, logical_w=None, images=None, strips=False, plain_stores=False):
     """Fused 3x3 conv over the channel concatenation of `srcs` (list of [N][c][H][P]).
 
     shuffle=False: returns [N][cout][H][P]; shuffle=True: returns PixelShuffle(4) layout
@@ -151,7 +151,8 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     images=(lo, hi): only images [lo, hi) of the batch are computed (every operand is the full-batch
     tensor; the other images of `out` are left untouched).  strips=True (or 2: the tile table
     starts with the other tile height): 5 x 16 / 4 x 16 tiles instead of 3 x 48 (same results bit for
-    bit; see larva_conv3x3_fwd_strips) where the shape allows, else the regular tiles."""
+    bit; see larva_conv3x3_fwd_strips) where the shape allows, else the regular tiles; plain_stores:
+    the strip launch writes its output with plain instead of non-temporal stores."""
     lib = hip_lib.load()
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
@@ -190,7 +191,7 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     if strips and cout == 48:
         tab = strip_tile_table(H, P, out.device, phase=1 if strips == 2 else 0)
         if tab is not None:
-            code = lib.larva_conv3x3_fwd_strips(*args, tab[0].data_ptr(), tab[1], _stream())
+            code = lib.larva_conv3x3_fwd_strips(*args, tab[0].data_ptr(), tab[1], 1 if plain_stores else 0, _stream())
             if code != 801:   # hipErrorNotSupported: unaligned operands -> the regular tiles below
                 hip_lib.check(code, "larva_conv3x3_fwd_strips")
                 return out

@@ -127,3 +127,11 @@ print("  two chains, ReLU only, a tensor + weights per layer    %.2f" % timed(gr
 print("  two chains, step's epilogue mix, ping-pong             %.2f" % timed(graphed(lambda: step_like(HALVES, True, False))))
 print("  two chains, step's epilogue mix, tensor per layer      %.2f" % timed(graphed(lambda: step_like(HALVES, True, True))))
 print("  two chains, ReLU only, tensor per layer, ONE weight image  %.2f" % timed(graphed(lambda: step_like(HALVES, False, True, False))))
+
+
+def single_distinct(strips=False):
+    for i in range(LAYERS):
+        K.conv3x3(acts[i], wpks[i], C, bias=b, relu=True, out=acts[i + 1], strips=strips)
+
+
+print("  one chain, 3x48 tiles, tensor + weights per layer         %.2f" % timed(graphed(single_distinct)))
