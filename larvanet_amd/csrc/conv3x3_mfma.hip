@@ -45,6 +45,9 @@
 #ifndef LARVA_DIAG
 #define LARVA_DIAG 0
 #endif
+#ifndef LARVA_OPERAND_DEPTH
+#define LARVA_OPERAND_DEPTH 2   // k-steps between an operand's LDS read and the MFMAs that use it (A/B: 1)
+#endif
 
 // LARVA_DIAG bit 5 (32): in-kernel timeline.  Wave 0 of every workgroup writes 100 MHz wall-clock
 // stamps (s_memrealtime) at kernel entry, after the DMA issue, after the first chunk landed, after
@@ -421,24 +424,31 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
   const float* a_base = stage + C::IN_FLOATS + lq * C::CS + lr + ct0 * 16;
   const float* b_base = stage + lq * C::PS + lr + 3;
   constexpr int kEvery = C::STEPS / C::NPW > 0 ? C::STEPS / C::NPW : 1;
-  float av[2][NCT], bv[2][NPG];
-  read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, 0, av[0], bv[0]);
+#if LARVA_SHADOW
+  // Operands are read LARVA_OPERAND_DEPTH k-steps ahead of the MFMAs that use them (ring of DEPTH + 1
+  // register sets).  With depth 1 the wait in front of a k-step's first MFMA was lgkmcnt(0) on reads
+  // issued only 3-4 MFMAs earlier; with depth 2 the compiler's wait is a COUNTED one that leaves the
+  // newest k-step's reads in flight.
+  constexpr int D = LARVA_OPERAND_DEPTH;
+  float av[D + 1][NCT], bv[D + 1][NPG];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < C::STEPS) read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, d, av[d], bv[d]);
 #pragma unroll
   for (int step = 0; step < C::STEPS; ++step) {
-#if LARVA_SHADOW
     // One scheduling region per k-step.  A v_mfma_f32_16x16x4_f32 keeps the matrix pipe busy for
     // 32 cycles but the wave's issue port for only 8 of them: ~24 cycles of other instructions
     // per MFMA are free, everything issued OUTSIDE such a shadow idles the pipe (one wave per
-    // SIMD).  So the operand reads of step s+1 are dealt out one or two per MFMA of step s
+    // SIMD).  So the operand reads of a later step are dealt out one or two per MFMA of step s
     // instead of in a block in front of them, and the LDS-DMA piece follows the first MFMA.
     __builtin_amdgcn_sched_barrier(0);
-    if (step + 1 < C::STEPS)
-      read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+    if (step + D < C::STEPS)
+      read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, step + D, av[(step + D) % (D + 1)], bv[(step + D) % (D + 1)]);
     constexpr int NMF = NCT * NPG;
     constexpr int NRD = NCT + NPG;
 #pragma unroll
     for (int m = 0; m < NMF; ++m) {
-      acc[m / NPG][m % NPG] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][m / NPG], bv[step & 1][m % NPG],
+      acc[m / NPG][m % NPG] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step % (D + 1)][m / NPG], bv[step % (D + 1)][m % NPG],
                                                                   acc[m / NPG][m % NPG], 0, 0, 0);
       if constexpr (PREFETCH) {
         if (m == 0 && step % kEvery == 0 && step / kEvery < C::NPW)
@@ -447,7 +457,12 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
     }
     shadow_groups<NMF, NRD, 0>();
     __builtin_amdgcn_sched_barrier(0);
+  }
 #else
+  float av[2][NCT], bv[2][NPG];
+  read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, 0, av[0], bv[0]);
+#pragma unroll
+  for (int step = 0; step < C::STEPS; ++step) {
     if (step + 1 < C::STEPS)
       read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
     if constexpr (PREFETCH) {
@@ -463,8 +478,8 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
       for (int p = 0; p < NPG; ++p)
         acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][c], bv[step & 1][p], acc[c][p], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-#endif
   }
+#endif
 }
 
 // Wait until all but the `KEEP` youngest vector-memory operations of this wave are done, then
