@@ -49,6 +49,7 @@
 #define LARVA_OPERAND_DEPTH 2   // k-steps between an operand's LDS read and the MFMAs that use it (A/B: 1)
 #endif
 
+
 // LARVA_DIAG bit 5 (32): in-kernel timeline.  Wave 0 of every workgroup writes 100 MHz wall-clock
 // stamps (s_memrealtime) at kernel entry, after the DMA issue, after the first chunk landed, after
 // the K loop, after the stores were issued and after they drained, to the buffer given to
@@ -62,7 +63,10 @@ namespace larva {
 #if defined(LARVA_DIAG) && (LARVA_DIAG & 32)
 __device__ unsigned long long* g_stamps = nullptr;
 __device__ __forceinline__ void stamp(int k) {
-  if (g_stamps && threadIdx.x == 0) g_stamps[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime();
+  // bit 6 (64): stamps in SHADER-CLOCK cycles (s_memtime) instead of the 100 MHz wall clock: the two runs
+  // together give the clock the kernel actually ran at (tools/diag_conv.py --timeline --clock)
+  if (g_stamps && threadIdx.x == 0)
+    g_stamps[blockIdx.x * 16 + k] = (LARVA_DIAG & 64) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
 }
 #else
 __device__ __forceinline__ void stamp(int) {}
@@ -425,6 +429,11 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
   const float* b_base = stage + lq * C::PS + lr + 3;
   constexpr int kEvery = C::STEPS / C::NPW > 0 ? C::STEPS / C::NPW : 1;
 #if LARVA_SHADOW
+  // (Tried and dropped: scheduling regions of TWO k-steps.  tools/probe_mfma_rate.hip shows that a wave
+  // streaming MFMAs beside LDS reads loses a fixed ~28 cycles per region, 36.98 ticks per MFMA with 7
+  // MFMAs per region against 33.44 with 14 -- but in this kernel the longer regions, which must issue a
+  // tap's 16 operand reads within 7 MFMAs, ran the two-chain layer at 15.6 us instead of 13.8 and the
+  // step at 1.726 ms instead of 1.671, same box.)
   // Operands are read LARVA_OPERAND_DEPTH k-steps ahead of the MFMAs that use them (ring of DEPTH + 1
   // register sets).  With depth 1 the wait in front of a k-step's first MFMA was lgkmcnt(0) on reads
   // issued only 3-4 MFMAs earlier; with depth 2 the compiler's wait is a COUNTED one that leaves the

@@ -18,6 +18,8 @@ OUT = os.path.join(ROOT, "tools", "_diag")
 SRC = os.path.join(ROOT, "larvanet_amd", "csrc", "conv3x3_mfma.hip")
 TIMELINE = 32   # full kernel + in-kernel wall-clock stamps (--timeline)
 TIMELINE_MFMA = 38   # the same without staging and epilogue traffic
+TIMELINE_CLK = 96    # full kernel, stamps in shader-clock cycles (s_memtime)
+TIMELINE_MFMA_CLK = 102
 VARIANTS = {0: "full kernel", 1: "no MFMA", 2: "no staging loads", 4: "no epilogue traffic", 3: "no MFMA, no staging",
             6: "MFMA only", 7: "roles + barriers only", 8: "empty launch", 16: "plain output stores"}
 
@@ -25,7 +27,7 @@ VARIANTS = {0: "full kernel", 1: "no MFMA", 2: "no staging loads", 4: "no epilog
 def build():
     os.makedirs(OUT, exist_ok=True)
     procs = []
-    for v in list(VARIANTS) + [TIMELINE, TIMELINE_MFMA]:
+    for v in list(VARIANTS) + [TIMELINE, TIMELINE_MFMA, TIMELINE_CLK, TIMELINE_MFMA_CLK]:
         so = os.path.join(OUT, "libconv_diag%d.so" % v)
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLARVA_DIAG=%d" % v,
                "-DLARVA_DIAG_ONLY48=1", SRC, "-o", so]
@@ -91,6 +93,8 @@ def timeline():
     b = torch.zeros(48, device=dev)
     fwd, _ = K.pack_weights(w)
     which = TIMELINE_MFMA if "--mfma-only" in sys.argv else TIMELINE
+    if "--clock" in sys.argv:
+        return clock(which)
     lib = ctypes.CDLL(os.path.join(OUT, "libconv_diag%d.so" % which))
     fn = lib.larva_conv3x3_fwd
     fn.restype, fn.argtypes = hip_lib.SIGNATURES["larva_conv3x3_fwd"]
@@ -121,6 +125,47 @@ def timeline():
     ends = np.concatenate([t[:, 9:14], t[:, 3:4]], axis=1) - t[:, 8:13 + 1]
     print("chunk durations (barrier exit -> next barrier exit / loop end), medians: " +
           " ".join("%.2f" % np.median(ends[:, c]) for c in range(6)))
+
+
+def clock(which):
+    """K-loop duration in wall-clock microseconds (s_memrealtime build) and in shader-clock cycles
+    (s_memtime build) of the same launch chain -> the clock the loop ran at, and how many of those
+    cycles the 756 MFMAs of a wave (x 32) account for."""
+    import numpy as np
+    import torch
+    import ctypes as ct
+    from larvanet_amd import hip_lib, kernels as K
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    bufs = [(torch.randn(16, 48, 48, 48, generator=g) * 20).to(dev) for _ in range(2)]
+    w = (torch.randn(48, 48, 3, 3, generator=g) * 0.01).to(dev)
+    b = torch.zeros(48, device=dev)
+    fwd, _ = K.pack_weights(w)
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for name, variant in (("us", which), ("cycles", which | 64)):
+        lib = ctypes.CDLL(os.path.join(OUT, "libconv_diag%d.so" % variant))
+        fn = lib.larva_conv3x3_fwd
+        fn.restype, fn.argtypes = hip_lib.SIGNATURES["larva_conv3x3_fwd"]
+        stamps = torch.zeros(256 * 16, device=dev, dtype=torch.int64)
+        lib.larva_diag_set_stamps.argtypes = [ct.c_void_p]
+        assert lib.larva_diag_set_stamps(stamps.data_ptr()) == 0
+        rows = []
+        for rep in range(7):
+            for i in range(40):   # a long chain: the clock has settled by the last launch
+                src, dst = bufs[i & 1], bufs[(i + 1) & 1]
+                assert fn(hip_lib.ptr_array([src.data_ptr()]), 1, 48, fwd.data_ptr(), b.data_ptr(), None, None, None, None,
+                          dst.data_ptr(), 16, 48, 48, 48, 1, 0, stream) == 0
+            torch.cuda.synchronize()
+            t = stamps.cpu().numpy().reshape(256, 16).astype(np.float64)
+            rows.append(np.stack([t[:, 3] - t[:, 2], t[:, 5] - t[:, 0]], 1))   # K loop, workgroup lifetime
+        res[name] = np.median(np.stack(rows), axis=0)
+    k_us, life_us = np.median(res["us"][:, 0]) * 0.01, np.median(res["us"][:, 1]) * 0.01
+    k_cy, life_cy = np.median(res["cycles"][:, 0]), np.median(res["cycles"][:, 1])
+    print("K loop: %.2f us, %.0f s_memtime ticks -> %.3f ticks/us; workgroup lifetime %.2f us, %.0f ticks -> %.3f ticks/us"
+          % (k_us, k_cy, k_cy / k_us, life_us, life_cy, life_cy / life_us))
+    print("a wave's 756 MFMAs x 32 cycles = 24192 cycles = %.2f us at 2.4 GHz, %.2f us at 2.1 GHz, %.2f us at 1.9 GHz"
+          % (24192 / 2400, 24192 / 2100, 24192 / 1900))
 
 
 if __name__ == "__main__":
