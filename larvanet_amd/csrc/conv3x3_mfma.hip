@@ -433,7 +433,9 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
   // streaming MFMAs beside LDS reads loses a fixed ~28 cycles per region -- 36.98 ticks per MFMA with 7
   // MFMAs per region against 33.44 with 14 -- but in this kernel both two-k-step layouts (a tap's 16
   // operand reads within its first 7 MFMAs, or dealt over all 14 with the ring three regions deep) were
-  // slower: the two-chain layer 15.6 / 13.9 us against 13.8, the step 1.726 / 1.712 ms against 1.669.)
+  // slower: the two-chain layer 15.6 / 13.9 us against 13.8, the step 1.726 / 1.712 ms against 1.669; so
+  // was the probe's exact layout with inline-asm MFMAs, accumulators tied in place and one read behind
+  // every MFMA (single chain 16.2 us against 15.5).)
   // Operands are read LARVA_OPERAND_DEPTH k-steps ahead of the MFMAs that use them (ring of DEPTH + 1
   // register sets).  With depth 1 the wait in front of a k-step's first MFMA was lgkmcnt(0) on reads
   // issued only 3-4 MFMAs earlier; with depth 2 the compiler's wait is a COUNTED one that leaves the

@@ -8,7 +8,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NR, int WIDTH, bool SHADOW, int NM = 7>
+template <int NR, int WIDTH, bool SHADOW, int NM = 7, bool USE = true>
 __global__ __launch_bounds__(256) void probe(unsigned long long* out, float* sink, int iters) {
   __shared__ __attribute__((aligned(16))) float lds[12288];
   for (int i = threadIdx.x; i < 12288; i += 256) lds[i] = (float)i * 1e-6f;
@@ -35,7 +35,11 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, float* sin
         if constexpr (WIDTH == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(q); dst[(4 * r) % 8] = v[0]; dst[(4 * r + 1) % 8] = v[1]; dst[(4 * r + 2) % 8] = v[2]; dst[(4 * r + 3) % 8] = v[3]; }
       }
       (void)DW;
-      const float* cur = ring[s];
+      const float* cur = USE ? ring[s] : ring[0];
+      if constexpr (!USE) {   // keep the loaded values alive without feeding the MFMAs
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(ring[(s + 2) % 3][i]));
+      }
 #pragma unroll
       for (int i = 0; i < NM; ++i) acc[i % 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[7], cur[i % 7], acc[i % 7], 0, 0, 0);
       if constexpr (SHADOW && NR > 0 && NM == 14) {
@@ -80,14 +84,14 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, float* sin
   if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
 }
 
-template <int NR, int WIDTH, bool SHADOW, int NM = 7>
+template <int NR, int WIDTH, bool SHADOW, int NM = 7, bool USE = true>
 void run(const char* what, int blocks) {
   unsigned long long* d;
   float* sink;
   (void)hipMalloc(&d, blocks * 8);
   (void)hipMalloc(&sink, blocks * 256 * 4);
   const int iters = 700;
-  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((probe<NR, WIDTH, SHADOW, NM>), dim3(blocks), dim3(256), 0, 0, d, sink, iters);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((probe<NR, WIDTH, SHADOW, NM, USE>), dim3(blocks), dim3(256), 0, 0, d, sink, iters);
   (void)hipDeviceSynchronize();
   unsigned long long h[1024];
   (void)hipMemcpy(h, d, blocks * 8, hipMemcpyDeviceToHost);
@@ -99,7 +103,7 @@ void run(const char* what, int blocks) {
 }
 
 int main() {
-  for (int blocks : {1, 256}) {
+  for (int blocks : {256}) {
     run<0, 1, false>("no LDS reads", blocks);
     run<2, 1, false>("2 x ds_read_b32 per step", blocks);
     run<4, 1, false>("4 x ds_read_b32 per step", blocks);
@@ -110,6 +114,8 @@ int main() {
     run<8, 4, true>("8 x ds_read_b128 per step, dealt out", blocks);
     run<0, 1, false, 14>("14 MFMAs per step, no LDS reads", blocks);
     run<8, 1, true, 14>("14 MFMAs per step, 8 x ds_read_b32 dealt out", blocks);
+    run<16, 1, true, 14>("14 MFMAs per step, 16 x ds_read_b32 dealt out (= two k-steps per region)", blocks);
+    run<8, 2, true, 14>("14 MFMAs per step, 8 x ds_read_b64 dealt out", blocks);
     run<8, 1, false, 14>("14 MFMAs per step, 8 x ds_read_b32 compiler's placement", blocks);
     run<8, 1, false, 21>("21 MFMAs per step, 8 x ds_read_b32 compiler's placement", blocks);
   }
