@@ -27,7 +27,6 @@
 #include "larva_common.h"
 #include "larva_bicubic.h"
 #include <hip/hip_ext.h>
-#include <stdlib.h>
 #include <type_traits>
 
 // Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
@@ -1301,8 +1300,6 @@ int larva_conv3x3_exit_l1_batch(int njobs, const float* const* src, int n_src, i
 // 5-row / 4-row tile.
 int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap) {
   if (H <= 0 || W <= 0 || H >= 4096 || W >= 4096 || !tab || cap < 0) return -1;
-  const char* pref = getenv("LARVA_STRIP_PREFER");   // experiment: "4" = as many 4-row tiles as possible, "5" = 5-row
-  const int prefer = pref ? atoi(pref) : 0;
   // pass 1: how each 16-column strip is cut (5 a + 4 b = H, the running counts of the two heights kept close)
   int n5 = 0, n4 = 0;
   for (int pass = 0; pass < 2; ++pass) {
@@ -1313,9 +1310,7 @@ int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap) {
         if ((H - 5 * a5) % 4) continue;
         const int b4 = (H - 5 * a5) / 4;
         const int gap = (fives + a5) - (fours + b4);
-        int g = gap < 0 ? -gap : gap;
-        if (prefer == 4) g = a5;
-        if (prefer == 5) g = b4;
+        const int g = gap < 0 ? -gap : gap;
         if (g < best_gap) { best_gap = g; best_a = a5; }
       }
       if (best_a < 0) return -2;
