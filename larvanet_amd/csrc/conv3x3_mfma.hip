@@ -44,6 +44,9 @@
 #ifndef LARVA_DIAG
 #define LARVA_DIAG 0
 #endif
+#ifndef LARVA_PIXEL_MAJOR
+#define LARVA_PIXEL_MAJOR 1   // 0: channel-major accumulators in every epilogue (A/B timing)
+#endif
 #ifndef LARVA_OPERAND_DEPTH
 #define LARVA_OPERAND_DEPTH 2   // k-steps between an operand's LDS read and the MFMAs that use it (A/B: 1)
 #endif
@@ -297,6 +300,7 @@ __device__ __forceinline__ void make_loader_plan(const ConvArgs& a, int lane, in
 template <int COUT, typename G>
 __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int lane, int n, int y0, int x0) {
   using C = ConvCfg<COUT, G>;
+  if constexpr ((LARVA_DIAG & 256) != 0) return;   // (no barriers to meet the MFMA waves at)
   LoaderPlan<COUT, G> pl;
   make_loader_plan<COUT, G>(a, lane, y0, x0, pl);
   const int last = a.n_chunks - 1;
@@ -390,6 +394,13 @@ template <int COUT, typename G, int NCT, int PG0, int NPG>
 __device__ __forceinline__ void read_operands(const float* a_base, const float* b_base, int step,
                                               float (&av)[NCT], float (&bv)[NPG]) {
   using C = ConvCfg<COUT, G>;
+  if constexpr ((LARVA_DIAG & 128) != 0) {   // timing ablation: operands from registers, no LDS reads
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) av[c] = (float)step;
+#pragma unroll
+    for (int p = 0; p < NPG; ++p) bv[p] = (float)(step + p);
+    return;
+  }
   const int tap = step / (kCh / 4), kk = step % (kCh / 4);
   const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
@@ -418,7 +429,10 @@ __device__ __forceinline__ void shadow_groups() {
 // (hipcc otherwise sinks every ds_read to just above its first use, lgkmcnt(0) per pair of
 // MFMAs; the sched_barriers pin "reads of s+1, [one LDS-DMA piece], MFMAs of s").
 // PREFETCH: the wave's NPW LDS-DMA pieces of the chunk two ahead are issued between k-steps.
-template <int COUT, typename G, int NCT, int PG0, int NPG, bool PREFETCH>
+// SWAP: the MFMA's A operand = activations (M = 16 pixels), B = weights (N = 16 output channels), so
+// that a lane ends up with 4 CONSECUTIVE PIXELS of one output channel (see run_role's epilogue) instead
+// of 4 consecutive output channels of one pixel.  Same products, same k order: identical results.
+template <int COUT, typename G, int NCT, int PG0, int NPG, bool PREFETCH, bool SWAP>
 __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave, int lane,
                                            f32x4 (&acc)[NCT][NPG], const DmaPlan<COUT, G>& pl, const ChunkSrc& nxt,
                                            unsigned nxt_stage) {
@@ -458,8 +472,8 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
     constexpr int NRD = NCT + NPG;
 #pragma unroll
     for (int m = 0; m < NMF; ++m) {
-      acc[m / NPG][m % NPG] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step % (D + 1)][m / NPG], bv[step % (D + 1)][m % NPG],
-                                                                  acc[m / NPG][m % NPG], 0, 0, 0);
+      const float wv = av[step % (D + 1)][m / NPG], xv = bv[step % (D + 1)][m % NPG];
+      acc[m / NPG][m % NPG] = __builtin_amdgcn_mfma_f32_16x16x4f32(SWAP ? xv : wv, SWAP ? wv : xv, acc[m / NPG][m % NPG], 0, 0, 0);
       if constexpr (PREFETCH) {
         if (m == 0 && step % kEvery == 0 && step / kEvery < C::NPW)
           dma_piece<COUT, G>(pl, step / kEvery, wave, nxt, nxt_stage);
@@ -486,7 +500,8 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
       for (int p = 0; p < NPG; ++p)
-        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][c], bv[step & 1][p], acc[c][p], 0, 0, 0);
+        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(SWAP ? bv[step & 1][p] : av[step & 1][c],
+                                                         SWAP ? av[step & 1][c] : bv[step & 1][p], acc[c][p], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 #endif
@@ -509,6 +524,15 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
 
   // Bias (added in the epilogue) and the epilogue's other operands are fetched inside the DMA
   // prologue, older than chunk 1's pieces, so the first counted wait of the ring covers them.
+  // Orientation of the accumulators.  Channel-major (the MFMA's A operand = weights): lane (lr, lq)
+  // holds output channels 4 lq .. 4 lq + 3 of pixel lr of its group -- what the pixel-shuffle store wants
+  // (4 sub-pixels of one HR row = 16 contiguous bytes).  Pixel-major (A = activations, LARVA_PIXEL_MAJOR):
+  // lane (lr, lq) holds pixels 4 lq .. 4 lq + 3 of output channel lr -- 16 contiguous bytes of an NCHW
+  // row, so the ordinary epilogues store (and fetch their mask / residual operands) with ONE 16-byte
+  // access per (channel group, pixel group) instead of four 4-byte ones: in the batched launch the
+  // store phase was 1.3 us of a conv's 12.7 us (un-instrumented ablation, tools/bench_conv_batch.py).
+  constexpr bool kShuffleEpi = (EPI == kEpiShuffle || EPI == kEpiShuffleBase || EPI == kEpiShuffleL1);
+  constexpr bool kPixMajor = LARVA_PIXEL_MAJOR && VEC && !kShuffleEpi;
   f32x4 bias[NCT];
 #pragma unroll
   for (int c = 0; c < NCT; ++c) bias[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -517,7 +541,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
 #pragma unroll
       for (int c = 0; c < NCT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[c][r] = a.bias[(ct0 + c) * 16 + lq * 4 + r];
+        for (int r = 0; r < 4; ++r) bias[c][r] = a.bias[(ct0 + c) * 16 + (kPixMajor ? lr : lq * 4 + r)];
     }
   };
 
@@ -525,7 +549,6 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   // land under the whole K loop instead of being waited for after it (the mask / residual
   // variants ran 1-1.3 us longer than plain ReLU).  They are older than every LDS-DMA piece, so
   // the first counted wait of the ring covers them too.
-  constexpr bool kShuffleEpi = (EPI == kEpiShuffle || EPI == kEpiShuffleBase || EPI == kEpiShuffleL1);
   constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiShuffleBase)
                            ? 1 : ((EPI == kEpiRes2 || EPI == kEpiShuffleL1) ? 2 : 0);
   f32x4 aux[NAUX > 0 ? NAUX : 1][NCT][NPG];
@@ -541,6 +564,13 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
           const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
           aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.base + idx);
           if constexpr (EPI == kEpiShuffleL1) aux[1][c][p] = *reinterpret_cast<const f32x4*>(a.truth + idx);
+        } else if constexpr (kPixMajor) {
+          const size_t plane = (size_t)a.H * a.pitch;
+          const int xb = min(x0 + pcol * 16 + lq * 4, a.pitch - 4);   // (pitch % 4 == 0 on this path)
+          const size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * a.pitch + xb;
+          if constexpr (EPI == kEpiMask) aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.mask + idx);
+          if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.res0 + idx);
+          if constexpr (EPI == kEpiRes2) aux[1][c][p] = *reinterpret_cast<const f32x4*>(a.res1 + idx);
         } else {
           const size_t plane = (size_t)a.H * a.pitch;
           const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
@@ -604,7 +634,9 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       if constexpr (C::LOADER) {
         // this wave only issued its share of chunks 0 and 1: the first wait leaves chunk 1's
         // pieces in flight, every later one finds nothing outstanding
-        if (chunk == 0) wait_and_barrier<(LARVA_DIAG & 2) ? 0 : C::NPW>();
+        if constexpr ((LARVA_DIAG & 256) != 0) {
+          // timing ablation (with bit 1: nothing is staged): no barrier between the chunks
+        } else if (chunk == 0) wait_and_barrier<(LARVA_DIAG & 2) ? 0 : C::NPW>();
         else wait_and_barrier<0>();
       } else {
         // (the NPW youngest operations belong to chunk+1)
@@ -616,10 +648,10 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       if constexpr (!(LARVA_DIAG & 1)) {
         if constexpr (!(LARVA_DIAG & 2) && !C::LOADER) {
           const ChunkSrc nxt = chunk_src<COUT, G>(a, min(chunk + 2, last), n);
-          mfma_chunk<COUT, G, NCT, PG0, NPG, true>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt,
+          mfma_chunk<COUT, G, NCT, PG0, NPG, true, kPixMajor>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt,
                                                 lds_addr_of(smem + nstage * C::STAGE_FLOATS));
         } else {
-          mfma_chunk<COUT, G, NCT, PG0, NPG, false>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, ChunkSrc{},
+          mfma_chunk<COUT, G, NCT, PG0, NPG, false, kPixMajor>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, ChunkSrc{},
                                                  0u);
         }
       }
@@ -644,7 +676,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         if (more) reg_load<COUT, G>(a, chunk_src<COUT, G>(a, chunk + 1, n), y0, x0, tid, st);
       }
       if constexpr (!(LARVA_DIAG & 1))
-        mfma_chunk<COUT, G, NCT, PG0, NPG, false>(cur, ct0, wave, lane, acc, DmaPlan<COUT, G>{}, ChunkSrc{}, 0u);
+        mfma_chunk<COUT, G, NCT, PG0, NPG, false, kPixMajor>(cur, ct0, wave, lane, acc, DmaPlan<COUT, G>{}, ChunkSrc{}, 0u);
       if constexpr (!(LARVA_DIAG & 2)) {
         if (more) reg_store<COUT, G>(nxt, tid, st);
       }
@@ -712,6 +744,43 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         if constexpr (EPI == kEpiShuffleBase) v += aux[0][c][p];
         if (y < a.H && x < a.W) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
       }
+  } else if constexpr (kPixMajor) {
+    // Pixel-major accumulators: acc[c][p][r] = output channel (ct0+c)*16 + lr of pixel
+    // (y0 + pg / PC, x0 + (pg % PC) * 16 + 4 lq + r): one 16-byte store per (c, p).  Store policy as below.
+    const size_t plane = (size_t)a.H * a.pitch;
+    auto store_all = [&](auto plain_tag) {
+      constexpr bool kPlain = decltype(plain_tag)::value;
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int p = 0; p < NPG; ++p) {
+          const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
+          const int y = y0 + prow, xb = x0 + pcol * 16 + lq * 4;
+          const size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * a.pitch + xb;
+          f32x4 v = acc[c][p] + bias[c];
+          if (y < a.H && xb < a.pitch) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float o = v[r];
+              if constexpr (EPI == kEpiRelu) o = fmaxf(o, 0.f);
+              if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
+              if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
+              if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
+              v[r] = (xb + r < a.W) ? o : 0.f;   // columns [W, pitch) are kept at zero for the next layer
+            }
+            if constexpr (kPlain) *reinterpret_cast<f32x4*>(a.out + idx) = v;
+            else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
+          }
+        }
+    };
+    if constexpr ((LARVA_DIAG & 16) != 0) {
+      store_all(std::true_type{});
+    } else if constexpr (G::COLS == 16) {
+      if (a.plain_stores) store_all(std::true_type{});
+      else store_all(std::false_type{});
+    } else {
+      store_all(std::false_type{});
+    }
   } else {
     // Output store policy.  Non-temporal for the 3 x 48 tiles: the 7 MB store burst of the 256
     // workgroups drains faster (-0.7 us per launch in a chain of whole-batch launches that writes a
@@ -1146,6 +1215,9 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
     a.src[i] = src[i];
     aligned = aligned && ((reinterpret_cast<uintptr_t>(src[i]) & 15) == 0);
   }
+  // (16-byte accesses to the mode-0 output and to the mask / residual operands)
+  aligned = aligned && (((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res0) |
+                          reinterpret_cast<uintptr_t>(res1) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0);
   a.wpk = wpk; a.bias = bias; a.res0 = res0; a.res1 = res1; a.mask = mask; a.base = base;
   a.out = out;
   a.cin_per_src = cin_per_src;

@@ -24,13 +24,20 @@ VARIANTS = {0: "full kernel", 1: "no MFMA", 2: "no staging loads", 4: "no epilog
             6: "MFMA only", 7: "roles + barriers only", 8: "empty launch", 16: "plain output stores"}
 
 
+EXTRA = [a for a in sys.argv[1:] if a.startswith("-D")]      # e.g. -DLARVA_REGION_KSTEPS=2: applied to every variant
+TAG = os.environ.get("DIAG_TAG", "")                          # library name suffix for such builds
+
+
 def build():
     os.makedirs(OUT, exist_ok=True)
     procs = []
-    for v in list(VARIANTS) + [TIMELINE, TIMELINE_MFMA, TIMELINE_CLK, TIMELINE_MFMA_CLK]:
-        so = os.path.join(OUT, "libconv_diag%d.so" % v)
+    only = [TIMELINE, TIMELINE_MFMA, TIMELINE_CLK, TIMELINE_MFMA_CLK, TIMELINE_MFMA | 128, TIMELINE_MFMA_CLK | 128] \
+        if "--clock-only" in sys.argv else \
+        list(VARIANTS) + [TIMELINE, TIMELINE_MFMA, TIMELINE_CLK, TIMELINE_MFMA_CLK]
+    for v in only:
+        so = os.path.join(OUT, "libconv_diag%d%s.so" % (v, TAG))
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLARVA_DIAG=%d" % v,
-               "-DLARVA_DIAG_ONLY48=1", SRC, "-o", so]
+               "-DLARVA_DIAG_ONLY48=1"] + EXTRA + [SRC, "-o", so]
         procs.append(subprocess.Popen(cmd))
     for p in procs:
         assert p.wait() == 0
@@ -93,6 +100,8 @@ def timeline():
     b = torch.zeros(48, device=dev)
     fwd, _ = K.pack_weights(w)
     which = TIMELINE_MFMA if "--mfma-only" in sys.argv else TIMELINE
+    if "--no-operand-reads" in sys.argv:
+        which = TIMELINE_MFMA | 128
     if "--clock" in sys.argv:
         return clock(which)
     lib = ctypes.CDLL(os.path.join(OUT, "libconv_diag%d.so" % which))
@@ -144,7 +153,7 @@ def clock(which):
     stream = torch.cuda.current_stream().cuda_stream
     res = {}
     for name, variant in (("us", which), ("cycles", which | 64)):
-        lib = ctypes.CDLL(os.path.join(OUT, "libconv_diag%d.so" % variant))
+        lib = ctypes.CDLL(os.path.join(OUT, "libconv_diag%d%s.so" % (variant, TAG)))
         fn = lib.larva_conv3x3_fwd
         fn.restype, fn.argtypes = hip_lib.SIGNATURES["larva_conv3x3_fwd"]
         stamps = torch.zeros(256 * 16, device=dev, dtype=torch.int64)
