@@ -172,6 +172,15 @@ int larva_wgrad_reduce(const float* const* partial, float* const* dw, float* con
                        const int* cin_off, const int* cin_valid, const int* w_cin_total,
                        const int* splits, const int* cout, const int* cin, int njobs, void* stream);
 
+/* larva_wgrad_reduce + larva_loss_from_partials in ONE launch (same arguments, same arithmetic as the two):
+ * the loss of a training step (models/LarvaNet.py:104-109) is not needed before the step ends, so its
+ * finishing block rides on the last launch of backward. */
+int larva_wgrad_reduce_with_loss(const float* const* partial, float* const* dw, float* const* db,
+                                 const int* cin_off, const int* cin_valid, const int* w_cin_total,
+                                 const int* splits, const int* cout, const int* cin, int njobs,
+                                 const float* const* terms, const int* count, const float* scale, int nterms,
+                                 float divisor, float* loss_out, void* stream);
+
 /* ---- base image -----------------------------------------------------------------------------
  * F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False), models/LarvaNet.py:283-285.
  * in [N][C][H][W] -> out [N][C][4H][4W]. */
@@ -224,6 +233,11 @@ int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* 
 int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
                           float beta2, float eps, float weight_decay, float grad_scale, long long n,
                           void* stream);
+/* larva_adamw_step_host that also copies one float, copy_dst[0] = copy_src[0] (both may be NULL): the step's
+ * loss out of the captured graph's static buffer into a tensor the caller keeps (models/LarvaNet.py:139). */
+int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, float grad_scale, long long n,
+                               const float* copy_src, float* copy_dst, void* stream);
 
 /* ---- device-resident patch sampler ----------------------------------------------------------
  * Crop + np.rot90(k) + horizontal flip + uint8->float of a training batch from a dataset held

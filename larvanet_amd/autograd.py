@@ -451,6 +451,18 @@ class DeferredWgrad:
         out.sort(key=lambda l: -max(j["dw"].data_ptr() for j in l[2]))
         return out
 
+    # the step's loss (mean of the exits' terms), left to ride on the last reduction launch of backward:
+    # (terms, scales, divisor, out) or None; see MeanTermsFn
+    pending_loss = None
+
+    @classmethod
+    def finish_loss(cls):
+        """The loss nobody has finished yet (no reduction launch took it along): its own launch."""
+        job, cls.pending_loss = cls.pending_loss, None
+        if job is not None:
+            terms, scales, divisor, out = job
+            out.copy_(K.loss_from_partials(terms, scales, divisor))
+
     @staticmethod
     def _issue(launches):
         """The partial-image launches one after the other, then ONE fixed-order reduction over all
@@ -464,7 +476,9 @@ class DeferredWgrad:
             parts, used = K.conv3x3_wgrad_partial(chunk, cout, cin, _splits(len(chunk)))
             reduce_jobs += [dict(j, partial=p, splits=used, cout=cout, cin=cin) for j, p in zip(chunk, parts)]
         for i in range(0, len(reduce_jobs), 64):
-            K.wgrad_reduce(reduce_jobs[i:i + 64])
+            last = i + 64 >= len(reduce_jobs)
+            loss, DeferredWgrad.pending_loss = (DeferredWgrad.pending_loss, None) if last else (None, DeferredWgrad.pending_loss)
+            K.wgrad_reduce(reduce_jobs[i:i + 64], loss=loss)
 
     @classmethod
     def flush(cls, split=False):
@@ -494,6 +508,7 @@ class DeferredWgrad:
     def drop(cls):
         cls._pending = {}
         cls._late = []
+        cls.pending_loss = None
 
 
 class StepScope:
@@ -555,6 +570,7 @@ class StepScope:
                 SideStreams.join()
             if exc_type is None:
                 self.early_targets = DeferredWgrad.flush(split=self.split_flush)
+                DeferredWgrad.finish_loss()
             else:
                 DeferredWgrad.drop()
             if exc_type is None and JointInputGrad._parked:
@@ -971,6 +987,12 @@ class MeanTermsFn(torch.autograd.Function):
         ctx.meta = meta
         ctx.shapes = [tuple(t.shape) for t in tensors]
         ts, scales = [t.contiguous() for t in tensors], [m[0] for m in meta]
+        if len(ts) <= 8 and DeferredWgrad.active and StepScope.depth > 0 and DeferredWgrad.pending_loss is None:
+            # inside the plugin's step nobody reads the value before the step ends (backward is seeded with 1):
+            # the finishing block rides on the weight-gradient reduction launch at the end of backward
+            out = torch.empty((), device=ts[0].device, dtype=torch.float32)
+            DeferredWgrad.pending_loss = (ts, scales, float(len(ts)), out)
+            return out
         if len(ts) <= 8:
             return K.loss_from_partials(ts, scales, float(len(ts)))
         # more terms than one launch takes: sums of groups of 8 first, then their mean

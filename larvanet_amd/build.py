@@ -11,7 +11,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liblarva_hip.so")
 SOURCES = ["conv3x3_mfma.hip", "wgrad3x3_mfma.hip", "larva_pointwise.hip"]
-HEADERS = ["larva_common.h", "larva_bicubic.h"]
+HEADERS = ["larva_common.h", "larva_bicubic.h", "larva_loss.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

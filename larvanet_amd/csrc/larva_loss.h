@@ -1,0 +1,35 @@
+// out[0] = ( sum_i scale_i * (sum of the count_i floats at p_i) ) / divisor: the mean over the exits of their
+// L1 terms straight from partial sums (count_i of them, scale_i = 1 / numel), or of ready scalars (count 1,
+// scale 1).  Every term is reduced in a fixed order by ONE 256-thread block, the terms are added in index
+// order: reproducible.  Shared by larva_pointwise.hip (loss_from_partials_kernel) and wgrad3x3_mfma.hip (the
+// weight-gradient reduction launch can carry it as an extra block: one launch less per training step).
+#pragma once
+#include "larva_common.h"
+
+namespace larva {
+
+struct TermList {
+  const float* p[8];
+  int count[8];
+  float scale[8];
+  int n;
+};
+
+// Call with all 256 threads of a block.
+__device__ __forceinline__ void loss_terms_block(const TermList& l, float divisor, float* __restrict__ out) {
+  __shared__ float ws[4];
+  float total = 0.f;
+  for (int i = 0; i < l.n; ++i) {
+    float s = 0.f;
+    for (int k = threadIdx.x; k < l.count[i]; k += 256) s += l.p[i][k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    total += ((ws[0] + ws[1]) + (ws[2] + ws[3])) * l.scale[i];
+  }
+  if (threadIdx.x == 0) out[0] = total / divisor;
+}
+
+}  // namespace larva

@@ -3,6 +3,7 @@
 // kernels: 16-byte accesses per lane, grid capped at 2048 blocks, no LDS.
 #include "larva_common.h"
 #include "larva_bicubic.h"
+#include "larva_loss.h"
 
 namespace larva {
 
@@ -267,26 +268,8 @@ __global__ __launch_bounds__(256) void l1_partial_grad_batch_kernel(L1Jobs jobs,
 // its block count, scale_i = 1 / numel), or of ready scalars (count 1, scale 1).  Each term is
 // reduced exactly like l1_finish_kernel does, the terms are added in index order: bit-identical
 // to l1_finish + sum_scalars, in one launch instead of n + 1.
-struct TermList {
-  const float* p[8];
-  int count[8];
-  float scale[8];
-  int n;
-};
 __global__ __launch_bounds__(256) void loss_from_partials_kernel(TermList l, float divisor, float* __restrict__ out) {
-  __shared__ float ws[4];
-  float total = 0.f;
-  for (int i = 0; i < l.n; ++i) {
-    float s = 0.f;
-    for (int k = threadIdx.x; k < l.count[i]; k += 256) s += l.p[i][k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-    __syncthreads();
-    total += ((ws[0] + ws[1]) + (ws[2] + ws[3])) * l.scale[i];
-  }
-  if (threadIdx.x == 0) out[0] = total / divisor;
+  loss_terms_block(l, divisor, out);
 }
 
 // out[0] = (t0 + t1 + ... ) / divisor over up to 8 device scalars, added in index order.
@@ -335,7 +318,8 @@ __global__ void pixel_unshuffle4_kernel(const float* __restrict__ in, float* __r
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, const float* __restrict__ step_lr, float step_h,
                              float lr_h, float beta1, float beta2, float eps, float wd, float gscale,
-                             long long n) {
+                             long long n, const float* __restrict__ copy_src, float* __restrict__ copy_dst) {
+  if (copy_dst && blockIdx.x == 0 && threadIdx.x == 0) copy_dst[0] = copy_src[0];   // (the step's loss: see the launcher)
   const float step = step_lr ? step_lr[0] : step_h, lr = step_lr ? step_lr[1] : lr_h;
   const float bc1 = 1.f - powf(beta1, step);
   const float bc2 = 1.f - powf(beta2, step);
@@ -592,7 +576,8 @@ int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* 
                      void* stream) {
   if (!p || !g || !m || !v || !step_lr || n <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     step_lr, 0.f, 0.f, beta1, beta2, eps, weight_decay, grad_scale, n);
+                     step_lr, 0.f, 0.f, beta1, beta2, eps, weight_decay, grad_scale, n, (const float*)nullptr,
+                     (float*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -602,7 +587,21 @@ int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step
                           void* stream) {
   if (!p || !g || !m || !v || n <= 0 || step < 1) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     (const float*)nullptr, (float)step, lr, beta1, beta2, eps, weight_decay, grad_scale, n);
+                     (const float*)nullptr, (float)step, lr, beta1, beta2, eps, weight_decay, grad_scale, n,
+                     (const float*)nullptr, (float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+// larva_adamw_step_host that also copies ONE float (copy_dst[0] = copy_src[0]) -- the step's loss out of the
+// captured graph's static buffer into a tensor of the caller's (models/LarvaNet.py:139 returns the loss):
+// saves the 4-byte device-to-device copy launch.
+int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, float grad_scale, long long n,
+                               const float* copy_src, float* copy_dst, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1 || (copy_dst && !copy_src)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (const float*)nullptr, (float)step, lr, beta1, beta2, eps, weight_decay, grad_scale, n, copy_src,
+                     copy_dst);
   return (int)hipGetLastError();
 }
 

@@ -24,6 +24,7 @@
 //
 // Roofline: fp32 MFMA, 2*9*Cin*Cout FLOP per pixel (same as the forward conv).
 #include "larva_common.h"
+#include "larva_loss.h"
 
 #include <stdlib.h>
 
@@ -737,9 +738,19 @@ constexpr int kMaxReduceJobs = 64;
 
 struct ReduceBatch {
   ReduceJob job[kMaxReduceJobs];
+  // optional extra block (blockIdx.y == njobs): the step's loss from its terms (larva_loss.h) -- the value is not
+  // needed before the step ends, so it rides on this launch instead of having one of its own
+  int njobs;
+  TermList loss_terms;
+  float loss_divisor;
+  float* loss_out;
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceBatch rb) {
+  if ((int)blockIdx.y == rb.njobs) {   // (only launched when there is a loss to finish)
+    if (blockIdx.x == 0) loss_terms_block(rb.loss_terms, rb.loss_divisor, rb.loss_out);
+    return;
+  }
   const ReduceJob& j = rb.job[blockIdx.y];
   const int ct_n = j.cout / 16, nb = (j.cin / 16) * 9;
   const int n_w = nb * ct_n * 256;
@@ -931,9 +942,9 @@ int larva_conv3x3_wgrad_partial(const float* const* dy, const float* const* x, f
 // cin_valid[i] channels are written; the rest of `cin` is zero padding of x), db[i] [cout] (may
 // be null).  Gradients are OVERWRITTEN, not accumulated.  One launch: a training step reduces
 // all of its layers at the end of backward instead of once per module.
-int larva_wgrad_reduce(const float* const* partial, float* const* dw, float* const* db,
-                       const int* cin_off, const int* cin_valid, const int* w_cin_total,
-                       const int* splits, const int* cout, const int* cin, int njobs, void* stream) {
+static int reduce_launch(const float* const* partial, float* const* dw, float* const* db, const int* cin_off,
+                         const int* cin_valid, const int* w_cin_total, const int* splits, const int* cout, const int* cin,
+                         int njobs, const TermList* loss, float divisor, float* loss_out, void* stream) {
   if (njobs < 1 || njobs > kMaxReduceJobs) return (int)hipErrorInvalidValue;
   ReduceBatch rb{};
   int pf_max = 0;
@@ -945,9 +956,43 @@ int larva_wgrad_reduce(const float* const* partial, float* const* dw, float* con
     const int pf = (cin[i] / 16) * 9 * (cout[i] / 16) * 256 + cout[i];
     pf_max = pf > pf_max ? pf : pf_max;
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((pf_max / 4 + 255) / 256, njobs), dim3(256), 0, (hipStream_t)stream,
-                     rb);
+  rb.njobs = njobs;
+  if (loss) {
+    rb.loss_terms = *loss;
+    rb.loss_divisor = divisor;
+    rb.loss_out = loss_out;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((pf_max / 4 + 255) / 256, njobs + (loss ? 1 : 0)), dim3(256), 0,
+                     (hipStream_t)stream, rb);
   return (int)hipGetLastError();
+}
+
+int larva_wgrad_reduce(const float* const* partial, float* const* dw, float* const* db,
+                       const int* cin_off, const int* cin_valid, const int* w_cin_total,
+                       const int* splits, const int* cout, const int* cin, int njobs, void* stream) {
+  return reduce_launch(partial, dw, db, cin_off, cin_valid, w_cin_total, splits, cout, cin, njobs, nullptr, 1.f, nullptr,
+                       stream);
+}
+
+// larva_wgrad_reduce + larva_loss_from_partials (same arguments, same arithmetic) in one launch: the loss of a
+// training step (models/LarvaNet.py:104-109) is not needed before the step ends, so finishing it rides on
+// the last launch of backward.
+int larva_wgrad_reduce_with_loss(const float* const* partial, float* const* dw, float* const* db,
+                                 const int* cin_off, const int* cin_valid, const int* w_cin_total,
+                                 const int* splits, const int* cout, const int* cin, int njobs,
+                                 const float* const* terms, const int* count, const float* scale, int nterms,
+                                 float divisor, float* loss_out, void* stream) {
+  if (!terms || !count || !scale || nterms < 1 || nterms > 8 || !loss_out) return (int)hipErrorInvalidValue;
+  TermList l{};
+  for (int i = 0; i < nterms; ++i) {
+    if (!terms[i] || count[i] < 1) return (int)hipErrorInvalidValue;
+    l.p[i] = terms[i];
+    l.count[i] = count[i];
+    l.scale[i] = scale[i];
+  }
+  l.n = nterms;
+  return reduce_launch(partial, dw, db, cin_off, cin_valid, w_cin_total, splits, cout, cin, njobs, &l, divisor, loss_out,
+                       stream);
 }
 
 // Both phases for njobs (<= 64) layers.

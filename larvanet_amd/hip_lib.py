@@ -66,6 +66,13 @@ SIGNATURES = {
                                                         _c_int_p, ctypes.c_void_p]),
     "larva_wgrad_reduce": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p,
                                           _c_int_p, ctypes.c_int, ctypes.c_void_p]),
+    "larva_wgrad_reduce_with_loss": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p, _c_int_p, _c_int_p,
+                                                    _c_int_p, ctypes.c_int, _c_pp, _c_int_p, _c_float_p, ctypes.c_int,
+                                                    ctypes.c_float, _c_float_p, ctypes.c_void_p]),
+    "larva_adamw_step_host_copy": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
+                                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                  ctypes.c_float, ctypes.c_float, ctypes.c_longlong, _c_float_p, _c_float_p,
+                                                  ctypes.c_void_p]),
     "larva_bicubic4_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_void_p]),
     "larva_l1_workspace_floats": (ctypes.c_int, []),

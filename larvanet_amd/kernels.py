@@ -418,10 +418,23 @@ def conv3x3_wgrad_partial_flat(jobs, cout, cin, nwg):
     return [p[:per * s] for p, s in zip(parts, splits)], splits
 
 
-def wgrad_reduce(jobs, cout=None, cin=None):
+def _loss_terms(terms, scales):
+    ptrs, counts = [], []
+    for t in terms:
+        _chk(t, "term")
+        if t.dim() > 1:
+            raise RuntimeError("larvanet_amd: a loss term is a scalar or a vector of partial sums")
+        ptrs.append(t.data_ptr())
+        counts.append(max(1, int(t.numel())))
+    sc = (ctypes.c_float * len(terms))(*[float(v) for v in scales])
+    return hip_lib.ptr_array(ptrs), hip_lib.int_array(counts), sc
+
+
+def wgrad_reduce(jobs, cout=None, cin=None, loss=None):
     """Phase 2: jobs (<= 64 dicts {partial, splits, dw, db (or None), cin_off, cin_valid[, cout, cin]})
     reduced in ONE launch; dw/db are overwritten.  cout/cin: the kernel shape of every job that does
-    not carry its own."""
+    not carry its own.  loss = (terms, scales, divisor, out): the same launch also finishes
+    loss_from_partials(terms, scales, divisor) into the 0-d tensor `out`."""
     lib = hip_lib.load()
     if not 1 <= len(jobs) <= 64:
         raise RuntimeError("larvanet_amd: 1..64 reduce jobs per call")
@@ -447,10 +460,18 @@ def wgrad_reduce(jobs, cout=None, cin=None):
         splits.append(sp)
         couts.append(co)
         cins.append(ci)
-    code = lib.larva_wgrad_reduce(
-        hip_lib.ptr_array(parts), hip_lib.ptr_array(dws), hip_lib.ptr_array(dbs), hip_lib.int_array(offs),
-        hip_lib.int_array(valids), hip_lib.int_array(totals), hip_lib.int_array(splits), hip_lib.int_array(couts),
-        hip_lib.int_array(cins), len(jobs), _stream())
+    common = (hip_lib.ptr_array(parts), hip_lib.ptr_array(dws), hip_lib.ptr_array(dbs), hip_lib.int_array(offs),
+              hip_lib.int_array(valids), hip_lib.int_array(totals), hip_lib.int_array(splits), hip_lib.int_array(couts),
+              hip_lib.int_array(cins), len(jobs))
+    if loss is None:
+        code = lib.larva_wgrad_reduce(*common, _stream())
+    else:
+        terms, scales, divisor, out = loss
+        if not 1 <= len(terms) <= 8:
+            raise RuntimeError("larvanet_amd: 1..8 loss terms")
+        _chk(out, "loss", ())
+        ptrs, counts, sc = _loss_terms(terms, scales)
+        code = lib.larva_wgrad_reduce_with_loss(*common, ptrs, counts, sc, len(terms), float(divisor), out.data_ptr(), _stream())
     hip_lib.check(code, "larva_wgrad_reduce")
 
 
@@ -640,12 +661,21 @@ def gather_patches(data, offsets, hw, draws, batch, patch, mult, out=None):
     return out
 
 
-def adamw_step_host(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
-    """One AdamW step over flat buffers, step count and learning rate given by the host."""
+def adamw_step_host(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, copy=None):
+    """One AdamW step over flat buffers, step count and learning rate given by the host.  copy = (src, dst):
+    the launch also copies the 0-d tensor src into dst (the step's loss out of a captured graph's buffer)."""
     lib = hip_lib.load()
     n = p.numel()
     for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, name, (n,))
+    if copy is not None:
+        src, dst = copy
+        _chk(src, "copy source", ())
+        _chk(dst, "copy destination", ())
+        hip_lib.check(lib.larva_adamw_step_host_copy(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), int(step),
+                                                     float(lr), beta1, beta2, eps, weight_decay, grad_scale, n,
+                                                     src.data_ptr(), dst.data_ptr(), _stream()), "larva_adamw_step_host_copy")
+        return
     hip_lib.check(lib.larva_adamw_step_host(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), int(step),
                                             float(lr), beta1, beta2, eps, weight_decay, grad_scale, n, _stream()),
                   "larva_adamw_step_host")

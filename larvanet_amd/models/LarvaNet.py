@@ -592,7 +592,16 @@ class LarvaNet(BaseModel):
 
         loss, out = self._forward_backward(input_tensor, truth_tensor)
         self._finish_backward()  # rest of a split backward + mean of the gradients over ranks
+        loss_copy = None
+        if not self.sync_loss and isinstance(self.optim, FlatAdamW) and loss.is_cuda:
+            # the caller gets a tensor of its own (the captured step's loss buffer is overwritten by the next
+            # replay); the optimizer launch makes the 4-byte copy
+            loss_copy = torch.empty_like(loss)
+            self.optim.copy_scalar = (loss.detach(), loss_copy)
         self.optim.step()
+        if loss_copy is not None and self.optim.copy_scalar is not None:   # the step took another path: copy here
+            self.optim.copy_scalar = None
+            loss_copy = None
         self.model.invalidate_packed_weights()  # the kernel-layout weight images are now stale
 
         if self.global_step == 1:
@@ -613,7 +622,9 @@ class LarvaNet(BaseModel):
         # the reference returns loss.item() (a host sync every step, models/LarvaNet.py:139);
         # sync_loss=False hands back a 0-d device tensor instead so the host can run ahead (a copy:
         # the captured step's own loss tensor is overwritten by the next replay)
-        return loss.item() if self.sync_loss else loss.detach().clone()
+        if self.sync_loss:
+            return loss.item()
+        return loss_copy if loss_copy is not None else loss.detach().clone()
 
     def _write_summary(self, summary, loss, input_tensor, out, truth_tensor):
         summary.add_scalar("loss", loss, self.global_step)

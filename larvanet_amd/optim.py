@@ -33,6 +33,8 @@ class FlatAdamW(torch.optim.AdamW):
         self._v = torch.zeros_like(flat_params)
         self._t = 0
         self._plist = params
+        # (src, dst) 0-d tensors: the next flat step() also copies src into dst (the step's loss), then forgets it
+        self.copy_scalar = None
         self.mean_scale = 1.0   # (not "grad_scale": torch.optim reserves that attribute for AMP) gradients are multiplied by this inside the step (1/world_size: mean over ranks)
 
     def _flat_ok(self):
@@ -55,8 +57,9 @@ class FlatAdamW(torch.optim.AdamW):
             return self._fallback_step(closure)
         self._t += 1
         b1, b2 = g["betas"]
+        copy, self.copy_scalar = self.copy_scalar, None
         K.adamw_step_host(self._flat_p, self._bucket.flat, self._m, self._v, self._t, float(g["lr"]), b1, b2,
-                          g["eps"], g["weight_decay"], self.mean_scale)
+                          g["eps"], g["weight_decay"], self.mean_scale, copy=copy)
         return None
 
     def training_state(self):

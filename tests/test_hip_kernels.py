@@ -769,3 +769,38 @@ def test_flat_wgrad_grid_over_all_layers(hip_device, njobs, nwg, N, H, W):
     K.wgrad_reduce([dict(j, partial=p, splits=s, cout=48, cin=48) for j, p, s in zip(jobs, *res2)])
     torch.cuda.synchronize()
     assert all(torch.equal(a, j["dw"]) for a, j in zip(first, jobs))
+
+
+def test_reduce_launch_carries_the_loss_and_adamw_launch_the_copy(hip_device):
+    """larva_wgrad_reduce_with_loss == larva_wgrad_reduce + larva_loss_from_partials (same bits), and
+    larva_adamw_step_host_copy == larva_adamw_step_host + a 4-byte copy."""
+    from larvanet_amd import kernels as K
+    gen = torch.Generator().manual_seed(77)
+    jobs = []
+    for _ in range(3):
+        jobs.append({"dy": (torch.randn(2, 48, 9, 48, generator=gen) * 1e-3).to(hip_device),
+                     "x": (torch.randn(2, 48, 9, 48, generator=gen) * 20).to(hip_device),
+                     "dw": torch.empty((48, 48, 3, 3), device=hip_device), "db": torch.empty(48, device=hip_device)})
+    parts, used = K.conv3x3_wgrad_partial(jobs, 48, 48, 4)
+    rjobs = [dict(j, partial=p, splits=used, cout=48, cin=48) for j, p in zip(jobs, parts)]
+    terms = [(torch.rand(1024, generator=gen) * 1e4).to(hip_device), (torch.rand(37, generator=gen) * 1e4).to(hip_device),
+             torch.tensor(3.5, device=hip_device)]
+    scales = [1.0 / 7.0e6, 1.0 / 7.0e6, 1.0]
+    K.wgrad_reduce(rjobs)
+    ref_dw = [j["dw"].clone() for j in jobs]
+    ref_loss = K.loss_from_partials(terms, scales, 3.0)
+    for j in jobs:
+        j["dw"].fill_(float("nan"))
+    out = torch.full((), float("nan"), device=hip_device)
+    K.wgrad_reduce(rjobs, loss=(terms, scales, 3.0, out))
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, j["dw"]) for a, j in zip(ref_dw, jobs)) and torch.equal(out, ref_loss)
+    n = 1000
+    p0, g = torch.randn(n, generator=gen).to(hip_device), torch.randn(n, generator=gen).to(hip_device)
+    res = []
+    for copy in (None, (ref_loss, torch.zeros((), device=hip_device))):
+        p, m, v = p0.clone(), torch.zeros(n, device=hip_device), torch.zeros(n, device=hip_device)
+        K.adamw_step_host(p, g, m, v, 1, 4e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, copy=copy)
+        res.append(p)
+    torch.cuda.synchronize()
+    assert torch.equal(res[0], res[1]) and torch.equal(copy[1], ref_loss)
