@@ -804,3 +804,42 @@ def test_reduce_launch_carries_the_loss_and_adamw_launch_the_copy(hip_device):
         res.append(p)
     torch.cuda.synchronize()
     assert torch.equal(res[0], res[1]) and torch.equal(copy[1], ref_loss)
+
+
+def test_strip_tiles_seeded_shape_fuzz(hip_device):
+    """24 seeded random problems (batch, height, width % 4 == 0, 1-2 sources, every mode-0 epilogue and the
+    pixel-shuffle ones, image sub-ranges, both table phases and store policies): strip tiles == 3 x 48 tiles
+    bit for bit wherever a height can be cut into 5s and 4s."""
+    from larvanet_amd import kernels as K
+    rng = np.random.default_rng(2025)
+    done = 0
+    while done < 24:
+        N, H, W = int(rng.integers(1, 5)), int(rng.integers(4, 40)), 4 * int(rng.integers(1, 17))
+        if K.strip_tile_table(H, W, hip_device) is None:
+            continue
+        done += 1
+        n_src = int(rng.integers(1, 3))
+        kind = ["plain", "relu", "mask", "res1", "res2", "shuffle", "shuffle_base"][int(rng.integers(0, 7))]
+        xs = [_dev(_rand(rng, (N, 48, H, W), 20.0), hip_device) for _ in range(n_src)]
+        fwd, _ = K.pack_weights(_dev(_rand(rng, (48, 48 * n_src, 3, 3), 0.05), hip_device), want_bwd=False)
+        kw = {"bias": _dev(_rand(rng, (48,), 1.0), hip_device)}
+        if kind == "relu":
+            kw["relu"] = True
+        if kind == "mask":
+            kw["mask"] = _dev(_rand(rng, (N, 48, H, W), 1.0), hip_device)
+        if kind in ("res1", "res2"):
+            kw["res0"] = _dev(_rand(rng, (N, 48, H, W), 5.0), hip_device)
+        if kind == "res2":
+            kw["res1"] = _dev(_rand(rng, (N, 48, H, W), 5.0), hip_device)
+        if kind.startswith("shuffle"):
+            kw["shuffle"] = True
+        if kind == "shuffle_base":
+            kw["base"] = _dev(_rand(rng, (N, 3, 4 * H, 4 * W), 50.0), hip_device)
+        lo = int(rng.integers(0, N))
+        hi = int(rng.integers(lo + 1, N + 1))
+        ref = K.conv3x3(xs, fwd, 48, **kw)
+        out = torch.full(ref.shape, 3.0, device=hip_device)
+        K.conv3x3(xs, fwd, 48, out=out, images=(lo, hi), strips=1 + done % 2, plain_stores=bool(done % 3), **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out[lo:hi], ref[lo:hi]), (N, H, W, n_src, kind, lo, hi)
+        assert bool((out[:lo] == 3.0).all()) and bool((out[hi:] == 3.0).all()), (N, H, W, kind, lo, hi)
