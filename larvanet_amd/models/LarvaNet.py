@@ -684,6 +684,8 @@ class LarvaNet(BaseModel):
         key = tuple(x.shape)
         ent = cache.get(key)
         if ent is None:
+            if len(seen) > 512:   # (a long run over images of ever new sizes: forget the counts)
+                seen.clear()
             seen[key] = seen.get(key, 0) + 1
             if seen[key] < 2 or len(cache) >= 4:
                 return self.model(x)
