@@ -281,7 +281,7 @@ def roofline_block(dev, c=CH, full=True, dual=False):
         blk["traffic_source"] = HBM_TRAFFIC_SOURCE
     if dual:
         blk.update({
-            "kernel": "conv3x3_mfma_strip_kernel<1> (fused conv3x3+bias+ReLU, 5x16 / 4x16 pixel tiles), two concurrent "
+            "kernel": "conv3x3_mfma_strip_kernel<%d, 1> (fused conv3x3+bias+ReLU, 5x16 / 4x16 pixel tiles), two concurrent " % c +
                       "half-batch launches (8x%dx48x48 each) = one 16x%dx48x48 fp32 layer" % (c, c),
             "launches_per_layer": 2, "flop_per_launch": flop // 2, "flop_per_layer": flop,
             "traffic_is": "HBM-side bytes per LAYER (two launches)",
@@ -662,7 +662,9 @@ def main():
     line["infer"] = {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
                      "unit": "HR Mpixels/s"}
     if extras:
-        line["roofline_c32"] = roofline_block(dev, 32, full=False)
+        c32 = roofline_block(dev, 32, full=False, dual=True)     # two half-batch strip chains, like the 48-channel layer
+        line["roofline_c32"] = c32 if c32 is not None else roofline_block(dev, 32, full=False)
+        line["roofline_c32_single_chain"] = roofline_block(dev, 32, full=False)
         line["roofline_c64"] = roofline_block(dev, 64, full=False)
         del model
         line["infer_full_image"] = full_image_block(dev)

@@ -121,7 +121,7 @@ int larva_conv3x3_exit_l1_batch(int njobs, const float* const* src, int n_src, i
  * 5-row / 4-row tile), returns the tile count (> cap: table truncated) or < 0 when H cannot be cut
  * into 5s and 4s.  larva_conv3x3_fwd_strips: larva_conv3x3_fwd_pitched with `tile_tab` = a DEVICE
  * copy of larva_strip_tile_table(H, pitch), plain_stores = write the output with plain instead of
- * non-temporal stores (the forward chain's policy); cout 48 and the 16-byte staging path only
+ * non-temporal stores (the forward chain's policy); cout 48 or 32 and the 16-byte staging path only
  * (hipErrorNotSupported otherwise).  An image sub-range of a batch is addressed by offsetting the
  * operand pointers and passing its image count as N. */
 int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap);

@@ -890,18 +890,32 @@ __global__ __launch_bounds__(VEC ? ConvCfg<COUT>::THREADS_DMA : 256, VEC ? 2 : 1
 // ONE image's tiles -- 5 x 16 or 4 x 16 pixels -- and runs the matching instantiation.  ROWS pixel
 // groups x 3 cout groups: waves 0..2 own one cout group x the first ROWS-1 pixel groups, wave 3 all
 // three cout groups of the last pixel group (15 units -> 4,4,4,3; 12 -> 3,3,3,3).
-template <int EPI, typename G>
+template <int COUT, int EPI, typename G>
 __device__ __forceinline__ void strip_roles(const ConvArgs& a, float* smem, int wave, int n, int y0, int x0, int tid) {
-  static_assert(ConvCfg<48, G>::LOADER, "the strip kernel is launched with a loader wave");
+  static_assert(ConvCfg<COUT, G>::LOADER, "the strip kernel is launched with a loader wave");
+  static_assert(COUT == 48 || COUT == 32, "strip tiles: 48 or 32 output channels");
   if (wave == 4) {
-    run_loader<48, G>(a, smem, tid & 63, n, y0, x0);
+    run_loader<COUT, G>(a, smem, tid & 63, n, y0, x0);
     return;
   }
-  if (wave < 3) run_role<48, G, true, EPI, 1, 0, G::ROWS - 1>(a, smem, wave, wave, n, y0, x0, tid);
-  else run_role<48, G, true, EPI, 3, G::ROWS - 1, 1>(a, smem, 0, wave, n, y0, x0, tid);
+  if constexpr (COUT == 48) {
+    // ROWS pixel groups x 3 cout groups: waves 0..2 own one cout group x the first ROWS-1 pixel groups, wave 3
+    // all three cout groups of the last pixel group (15 units -> 4,4,4,3; 12 -> 3,3,3,3)
+    if (wave < 3) run_role<COUT, G, true, EPI, 1, 0, G::ROWS - 1>(a, smem, wave, wave, n, y0, x0, tid);
+    else run_role<COUT, G, true, EPI, 3, G::ROWS - 1, 1>(a, smem, 0, wave, n, y0, x0, tid);
+  } else if constexpr (G::ROWS == 5) {
+    // 32 channels, 5 pixel groups x 2 cout groups = 10 units -> 3,3,2,2
+    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 3>(a, smem, wave, wave, n, y0, x0, tid);
+    else if (wave == 2) run_role<COUT, G, true, EPI, 2, 3, 1>(a, smem, 0, wave, n, y0, x0, tid);
+    else run_role<COUT, G, true, EPI, 2, 4, 1>(a, smem, 0, wave, n, y0, x0, tid);
+  } else {
+    // 32 channels, 4 pixel groups x 2 cout groups = 8 units -> 2,2,2,2
+    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 2>(a, smem, wave, wave, n, y0, x0, tid);
+    else run_role<COUT, G, true, EPI, 1, 2, 2>(a, smem, wave - 2, wave, n, y0, x0, tid);
+  }
 }
 
-template <int EPI>
+template <int COUT, int EPI>
 __global__ __launch_bounds__(320, 2) void conv3x3_mfma_strip_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   fetch_args(a);
@@ -912,12 +926,13 @@ __global__ __launch_bounds__(320, 2) void conv3x3_mfma_strip_kernel(ConvArgs a) 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_amdgcn_s_setprio(1);
-  if (e >> 31) strip_roles<EPI, GeoS5>(a, smem, wave, n, y0, x0, tid);
-  else strip_roles<EPI, GeoS4>(a, smem, wave, n, y0, x0, tid);
+  if (e >> 31) strip_roles<COUT, EPI, GeoS5>(a, smem, wave, n, y0, x0, tid);
+  else strip_roles<COUT, EPI, GeoS4>(a, smem, wave, n, y0, x0, tid);
 }
+template <int COUT>
 constexpr size_t kStripLdsBytes =
-    ConvCfg<48, GeoS5>::LDS_BYTES_DMA > ConvCfg<48, GeoS4>::LDS_BYTES_DMA ? ConvCfg<48, GeoS5>::LDS_BYTES_DMA
-                                                                          : ConvCfg<48, GeoS4>::LDS_BYTES_DMA;
+    ConvCfg<COUT, GeoS5>::LDS_BYTES_DMA > ConvCfg<COUT, GeoS4>::LDS_BYTES_DMA ? ConvCfg<COUT, GeoS5>::LDS_BYTES_DMA
+                                                                              : ConvCfg<COUT, GeoS4>::LDS_BYTES_DMA;
 
 // Several INDEPENDENT convolutions of one shape and one epilogue in one launch (blockIdx.y = job).
 // A single conv launch at the training shape is one workgroup per CU and spends half of its time
@@ -1109,28 +1124,29 @@ static hipError_t launch_batch(const ConvBatch& b, int njobs, int epi, hipStream
   }
 }
 
-template <int EPI>
+template <int COUT, int EPI>
 static hipError_t launch_strip_e(const ConvArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_strip_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStripLdsBytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_strip_kernel<COUT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStripLdsBytes<COUT>);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_mfma_strip_kernel<EPI>), dim3(a.nwg), dim3(320), kStripLdsBytes, stream, a);
+  hipLaunchKernelGGL((conv3x3_mfma_strip_kernel<COUT, EPI>), dim3(a.nwg), dim3(320), kStripLdsBytes<COUT>, stream, a);
   return hipGetLastError();
 }
 
+template <int COUT>
 static hipError_t launch_strip(const ConvArgs& a, int epi, hipStream_t stream) {
   switch (epi) {
-    case kEpiPlain: return launch_strip_e<kEpiPlain>(a, stream);
-    case kEpiRelu: return launch_strip_e<kEpiRelu>(a, stream);
-    case kEpiMask: return launch_strip_e<kEpiMask>(a, stream);
-    case kEpiRes1: return launch_strip_e<kEpiRes1>(a, stream);
-    case kEpiRes2: return launch_strip_e<kEpiRes2>(a, stream);
-    case kEpiShuffle: return launch_strip_e<kEpiShuffle>(a, stream);
-    case kEpiShuffleBase: return launch_strip_e<kEpiShuffleBase>(a, stream);
+    case kEpiPlain: return launch_strip_e<COUT, kEpiPlain>(a, stream);
+    case kEpiRelu: return launch_strip_e<COUT, kEpiRelu>(a, stream);
+    case kEpiMask: return launch_strip_e<COUT, kEpiMask>(a, stream);
+    case kEpiRes1: return launch_strip_e<COUT, kEpiRes1>(a, stream);
+    case kEpiRes2: return launch_strip_e<COUT, kEpiRes2>(a, stream);
+    case kEpiShuffle: return launch_strip_e<COUT, kEpiShuffle>(a, stream);
+    case kEpiShuffleBase: return launch_strip_e<COUT, kEpiShuffleBase>(a, stream);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1416,7 +1432,7 @@ int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap) {
 // larva_conv3x3_fwd_pitched on strip tiles: `tile_tab` = DEVICE copy of larva_strip_tile_table(H,
 // pitch) with `tiles_per_image` entries.  plain_stores: mode-0 output written with plain instead of
 // non-temporal stores (faster when the next launch reads it at once, see the kernel's epilogue).
-// cout = 48 and the 16-byte staging path only (pitch % 4 == 0, 16-byte aligned tensors), otherwise
+// cout = 48 or 32 and the 16-byte staging path only (pitch % 4 == 0, 16-byte aligned tensors), otherwise
 // hipErrorNotSupported.  Results are bit-identical to
 // larva_conv3x3_fwd_pitched: every output's K loop runs in the same order, only the assignment of
 // pixels to workgroups differs.
@@ -1425,7 +1441,7 @@ int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src
                              const float* base, float* out, int N, int cout, int H, int W, int pitch,
                              int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
                              void* stream) {
-  if (cout != 48) return (int)hipErrorNotSupported;
+  if (cout != 48 && cout != 32) return (int)hipErrorNotSupported;
   if (!tile_tab || tiles_per_image < 1) return (int)hipErrorInvalidValue;
   ConvArgs a;
   bool aligned;
@@ -1442,7 +1458,10 @@ int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src
   a.magic_tx = div_magic(tiles_per_image);
   a.magic_ty = div_magic(1);
   a.nwg = N * tiles_per_image;
-  return (int)launch_strip(a, epi, (hipStream_t)stream);
+#if !LARVA_DIAG_ONLY48
+  if (cout == 32) return (int)launch_strip<32>(a, epi, (hipStream_t)stream);
+#endif
+  return (int)launch_strip<48>(a, epi, (hipStream_t)stream);
 }
 
 #if LARVA_DIAG & 32

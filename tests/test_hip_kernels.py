@@ -843,3 +843,35 @@ def test_strip_tiles_seeded_shape_fuzz(hip_device):
         torch.cuda.synchronize()
         assert torch.equal(out[lo:hi], ref[lo:hi]), (N, H, W, n_src, kind, lo, hi)
         assert bool((out[:lo] == 3.0).all()) and bool((out[hi:] == 3.0).all()), (N, H, W, kind, lo, hi)
+
+
+@pytest.mark.parametrize("kind", ["relu", "res2", "mask", "plain"])
+def test_strip_tiles_at_32_channels(hip_device, kind):
+    """Strip tiles at 32 output channels (waves 3/3/2/2 and 2/2/2/2) == the 3 x 48 tiles bit for bit, and the
+    C oracle (BASELINE's "32ch" configuration has no reference counterpart: SURVEY 8a N1)."""
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    rng = np.random.default_rng(32)
+    N, C, H, W = 3, 32, 13, 20
+    x = _rand(rng, (N, C, H, W), 20.0)
+    w = _rand(rng, (C, C, 3, 3), 0.05)
+    b = _rand(rng, (C,), 1.0)
+    fwd, _ = K.pack_weights(_dev(w, hip_device), want_bwd=False)
+    kw = {"bias": _dev(b, hip_device)}
+    aux = [_rand(rng, (N, C, H, W), 5.0) for _ in range(2)]
+    ref = R.conv3x3(x, w, b)
+    if kind == "relu":
+        kw["relu"] = True
+        ref = np.maximum(ref, 0)
+    elif kind == "mask":
+        kw["mask"] = _dev(aux[0], hip_device)
+        ref = np.where(aux[0] > 0, ref, 0).astype(np.float32)
+    elif kind == "res2":
+        kw["res0"], kw["res1"] = _dev(aux[0], hip_device), _dev(aux[1], hip_device)
+        ref = (ref + aux[0]) + aux[1]
+    wide = K.conv3x3(_dev(x, hip_device), fwd, C, **kw)
+    out = torch.full(wide.shape, -1.0, device=hip_device)
+    K.conv3x3(_dev(x, hip_device), fwd, C, out=out, images=(1, 3), strips=2, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out[1:], wide[1:]) and bool((out[0] == -1.0).all())
+    _report("c32 strips[%s]" % kind, wide.cpu().numpy(), ref, 2e-5)
