@@ -135,3 +135,6 @@ def single_distinct(strips=False):
 
 
 print("  one chain, 3x48 tiles, tensor + weights per layer         %.2f" % timed(graphed(single_distinct)))
+print("  three chains 6 + 5 + 5 images                             %.2f" % timed(graphed(lambda: multi([(0, 6), (6, 11), (11, 16)]))))
+print("  three chains 6 + 5 + 5 images, alternating tables          %.2f" % timed(graphed(lambda: multi([(0, 6), (6, 11), (11, 16)], 0, True))))
+print("  four quarter-batch chains, alternating tables              %.2f" % timed(graphed(lambda: multi([(0, 4), (4, 8), (8, 12), (12, 16)], 0, True))))
