@@ -36,6 +36,11 @@ def build_parser():
     p.add_argument("--save_path", type=str)
     p.add_argument("--chop_forward", action="store_true")
     p.add_argument("--chop_overlap_size", type=int, default=20)
+    p.add_argument("--host_psnr", action="store_true",
+                   help="score on the host like the reference (the HR image travels over PCIe) even when no image "
+                        "is saved; default without --save_path / --chop_forward: round, clip and squared error in one "
+                        "kernel on the device, 8 bytes come back (same protocol; equal to ~1e-7 dB: exact integer sum "
+                        "instead of a float32 mean)")
     p.add_argument("--band_gpus", action="store_true",
                    help="latency mode under torchrun: every image is cut into one row band per rank "
                         "(exact: halo = the network's receptive field) instead of image i -> rank i mod world")
@@ -73,10 +78,31 @@ def main(argv=None):
             for index in (range(num_images) if args.band_gpus else range(rank, num_images, world)):
                 lr, hr, name = loader.get_image_pair(image_index=index, scale=scale)
                 t0 = time.perf_counter()
+                on_device = (not args.host_psnr and args.save_path is None and not args.chop_forward
+                             and getattr(model, "device", None) is not None and model.device.type == "cuda"
+                             and hasattr(model, "upscale_tensor"))
+                if on_device and not args.band_gpus:
+                    # nothing to save: score where the image is (validate.py:17-27 in one kernel)
+                    from . import kernels as K
+                    out_dev = model.upscale_tensor(input_list=[lr])[0].contiguous()
+                    truth8 = torch.from_numpy(np.ascontiguousarray(image_to_uint8(hr))).to(model.device)
+                    psnr = K.psnr_u8(out_dev, truth8)   # (reads 8 bytes back: the launch has finished)
+                    duration = time.perf_counter() - t0
+                    mine.append((index, psnr, duration))
+                    print("x%d, %d/%d, psnr=%.2f, duration=%.4f" % (scale, index + 1, num_images, psnr, duration))
+                    continue
                 if args.band_gpus:
                     # one row band per rank, moved by ONE device all-gather (RCCL over xGMI)
                     out_dev = image_utils.upscale_banded_device(model, lr, scale, rank, world, ldist.all_gather_tensor)
                     if rank != 0:  # every rank holds the image now; rank 0 scores and saves it
+                        continue
+                    if on_device:
+                        from . import kernels as K
+                        truth8 = torch.from_numpy(np.ascontiguousarray(image_to_uint8(hr))).to(model.device)
+                        psnr = K.psnr_u8(out_dev.contiguous(), truth8)
+                        duration = time.perf_counter() - t0
+                        mine.append((index, psnr, duration))
+                        print("x%d, %d/%d, psnr=%.2f, duration=%.4f" % (scale, index + 1, num_images, psnr, duration))
                         continue
                     out = out_dev.cpu().numpy()
                 elif args.chop_forward:

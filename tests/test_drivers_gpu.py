@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -29,3 +30,19 @@ def test_train_then_validate(hip_device, tmp_path, capsys):
     assert len(glob.glob(os.path.join(str(tmp_path), "sr", "x4", "*.png"))) == 3
     chop = validate.main(common + ["--chop_forward", "--chop_overlap_size=8"])
     assert np.isfinite(chop[4]["psnr"]) and abs(chop[4]["psnr"] - plain[4]["psnr"]) < 1.0
+
+
+def test_validate_scores_on_the_device_like_on_the_host(hip_device):
+    """validate.py without --save_path scores every image with one kernel on the device (8 bytes back
+    instead of the HR image); --host_psnr is the reference's numpy protocol: same PSNR to 1e-4 dB."""
+    from larvanet_amd import validate
+    common = ["--model=LarvaNet", "--dataloader=synthetic_loader", "--num_modules=2", "--num_blocks=1,1",
+              "--synthetic_images=3", "--synthetic_lr_size=21", "--synthetic_uint8"]
+    torch.manual_seed(0)
+    dev = validate.main(list(common))
+    torch.manual_seed(0)
+    host = validate.main(common + ["--host_psnr"])
+    a, b = dev[4]["per_image"], host[4]["per_image"]
+    assert [r[0] for r in a] == [r[0] for r in b] == [0, 1, 2]
+    # (exact integer sum on the device, float32 mean on the host)
+    assert all(abs(x[1] - y[1]) < 1e-4 for x, y in zip(a, b))
