@@ -571,9 +571,11 @@ def main():
     for _ in range(max(a.warmup, 1)):
         model.train_step_larva(args, val, x_fresh, truth_fresh)
     if model.hip_graph_fell_back:
-        # a 2.4x slower step must not pass for the captured one
-        sys.stderr.write("bench.py: hipGraph capture failed (%s)\n" % model.hip_graph_fell_back)
-        sys.exit(3)
+        # a 2.4x slower step must not pass for the captured one: single GPU = an error; under data
+        # parallelism the run goes on (a flagged slow point of the scaling curve says more than no curve)
+        sys.stderr.write("bench.py: hipGraph capture FAILED, the step runs as eager launches (%s)\n" % model.hip_graph_fell_back)
+        if world == 1 or os.environ.get("LARVA_BENCH_STRICT_GRAPH", "0") != "0":
+            sys.exit(3)
     # the batch sits where a device-side producer (dataloaders/device_patch_loader, `out=`) puts it:
     # in the input buffers of the captured step, so the step does not copy it again
     x, truth = x_fresh, truth_fresh
@@ -617,7 +619,7 @@ def main():
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                    "inputs": "resident in the captured step's input buffers" if bufs is not None else "resident in HBM",
                    "loss_sync_per_step": bool(a.sync_loss), "hip_graph": bool(model.use_hip_graph),
-                   "dual_chain": bool(model.dual_chain),
+                   "dual_chain": bool(model.dual_chain), "hip_graph_fell_back": model.hip_graph_fell_back,
                    "final_loss": final_loss},
         "rounds": {"n": rounds, "steps_each": a.steps, "ms_per_step_median": ms_per_step,
                    "ms_per_step_min": per_step[0], "ms_per_step_max": per_step[-1],
