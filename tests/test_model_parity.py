@@ -443,3 +443,23 @@ def test_repeated_inference_shape_replays_a_graph_with_the_eager_result(hip_devi
     fresh = _model(name, flags, seed=99)
     fresh.restore(path)
     assert np.array_equal(replayed, fresh.upscale(batch, 4)) and not np.array_equal(replayed, eager)
+
+
+def test_reference_checkpoint_file_restores_and_reproduces_its_outputs(hip_device, golden, tmp_path):
+    """A checkpoint as the reference writes it (torch.save of the bare state_dict, models/LarvaNet.py:183-185;
+    here rebuilt from the weights captured in fixture F1) loads through restore() into a differently
+    initialised plugin, which then reproduces the reference's own staged outputs."""
+    g = golden("f1_m2b2_forward.npz")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    path = str(tmp_path / "model_step7_vol0G.pth")
+    torch.save(sd, path)
+    m = _model("LarvaNet", ["--num_modules=2", "--num_blocks=2,2"], seed=1234)     # other weights than the file's
+    assert not np.array_equal(m.model.state_dict()["head.feature_extraction.weight"].cpu().numpy(),
+                              g["sd.head.feature_extraction.weight"])
+    m.restore(path)
+    up = m.upscale([g["x"][0], g["x"][1]], 4)
+    np.testing.assert_allclose(up, g["final"], rtol=0, atol=2e-3)
+    # and the other way round: what save() writes is that same wire format
+    out = m.save(str(tmp_path))
+    back = torch.load(out, map_location="cpu")
+    assert sorted(back) == sorted(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
