@@ -225,11 +225,14 @@ int larva_pixel_unshuffle4(const float* in, float* out, int N, int C, int H, int
 
 /* ---- AdamW over a flat buffer (optim.AdamW, models/LarvaNet.py:86-88,114) ------------------
  * step_lr: device floats {step (1-based), lr}.  g is multiplied by grad_scale first
- * (1/world_size after a sum all-reduce). */
+ * (1/world_size after a sum all-reduce).  Buffers that are all 16-byte aligned are walked 16 bytes per lane
+ * (any n; the tail is element-wise), others element-wise; the values are the same either way. */
 int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* step_lr,
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                      long long n, void* stream);
 
+/* The same update with step (1-based) and lr from the host; 1 - beta^step is then computed on the host in
+ * double, as torch.optim.AdamW does. */
 int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
                           float beta2, float eps, float weight_decay, float grad_scale, long long n,
                           void* stream);

@@ -315,29 +315,61 @@ __global__ void pixel_unshuffle4_kernel(const float* __restrict__ in, float* __r
 // decoupled weight decay, bias-corrected moments, eps added after the sqrt).  `step_lr` holds
 // {step count as float, lr} on the device so that a captured graph can be replayed.
 // ---------------------------------------------------------------------------------------------
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                             float* __restrict__ v, const float* __restrict__ step_lr, float step_h,
-                             float lr_h, float beta1, float beta2, float eps, float wd, float gscale,
-                             long long n, const float* __restrict__ copy_src, float* __restrict__ copy_dst) {
-  if (copy_dst && blockIdx.x == 0 && threadIdx.x == 0) copy_dst[0] = copy_src[0];   // (the step's loss: see the launcher)
-  const float step = step_lr ? step_lr[0] : step_h, lr = step_lr ? step_lr[1] : lr_h;
+struct AdamwCoef {   // per-step scalars of torch.optim.AdamW: step_size = lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), 1 - lr * wd
+  float step_size, inv_bc2_sqrt, decay;
+};
+
+__device__ __forceinline__ AdamwCoef adamw_coef_device(float step, float lr, float beta1, float beta2, float wd) {
   const float bc1 = 1.f - powf(beta1, step);
   const float bc2 = 1.f - powf(beta2, step);
-  const float step_size = lr / bc1;
-  const float bc2_sqrt = sqrtf(bc2);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    const float grad = g[i] * gscale;
-    float param = p[i];
-    param *= 1.f - lr * wd;
-    const float mi = m[i] + (grad - m[i]) * (1.f - beta1);  // lerp, as torch does
-    const float vi = v[i] * beta2 + (1.f - beta2) * grad * grad;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    param -= step_size * (mi / denom);
-    p[i] = param;
-    m[i] = mi;
-    v[i] = vi;
+  return AdamwCoef{lr / bc1, 1.f / sqrtf(bc2), 1.f - lr * wd};
+}
+
+// (Explicit roundings: the 16-byte walk and the element-wise walk must give the same bits whatever the compiler
+// would contract in each.)
+__device__ __forceinline__ void adamw_update(float& param, float& mi, float& vi, float grad, const AdamwCoef& c,
+                                             float beta1, float beta2, float eps) {
+  mi = __fmaf_rn(__fsub_rn(grad, mi), 1.f - beta1, mi);  // lerp, as torch does
+  vi = __fmaf_rn(__fmul_rn(1.f - beta2, grad), grad, __fmul_rn(vi, beta2));
+  const float denom = __fmaf_rn(__fsqrt_rn(vi), c.inv_bc2_sqrt, eps);
+  param = __fmaf_rn(-c.step_size, __fdiv_rn(mi, denom), __fmul_rn(param, c.decay));
+}
+
+// step_lr != null: {step count as float, lr} live on the device (a captured graph can be replayed) and the
+// bias corrections are computed per thread; else `coef` comes ready from the host (computed in double like
+// torch does) and the flat buffers are walked 16 bytes per lane.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ step_lr, AdamwCoef coef, float beta1,
+                                                    float beta2, float eps, float wd, float gscale, long long n, int vec,
+                                                    const float* __restrict__ copy_src, float* __restrict__ copy_dst) {
+  if (copy_dst && blockIdx.x == 0 && threadIdx.x == 0) copy_dst[0] = copy_src[0];   // (the step's loss: see the launcher)
+  if (step_lr) coef = adamw_coef_device(step_lr[0], step_lr[1], beta1, beta2, wd);
+  const long long n4 = vec ? n >> 2 : 0;   // (vec: all four buffers are 16-byte aligned)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = pp[e], me = mm[e], ve = vv[e];
+      adamw_update(pe, me, ve, __fmul_rn(gg[e], gscale), coef, beta1, beta2, eps);
+      pp[e] = pe; mm[e] = me; vv[e] = ve;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
   }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float pp = p[i], mm = m[i], vv = v[i];
+    adamw_update(pp, mm, vv, __fmul_rn(g[i], gscale), coef, beta1, beta2, eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+
+static int adamw_vec_ok(const void* p, const void* g, const void* m, const void* v) {
+  return ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+           reinterpret_cast<uintptr_t>(v)) & 15) == 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -575,21 +607,23 @@ int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* 
                      float beta2, float eps, float weight_decay, float grad_scale, long long n,
                      void* stream) {
   if (!p || !g || !m || !v || !step_lr || n <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     step_lr, 0.f, 0.f, beta1, beta2, eps, weight_decay, grad_scale, n, (const float*)nullptr,
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     step_lr, AdamwCoef{}, beta1, beta2, eps, weight_decay, grad_scale, n, adamw_vec_ok(p, g, m, v),
+                     (const float*)nullptr,
                      (float*)nullptr);
   return (int)hipGetLastError();
 }
+
+int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, float grad_scale, long long n,
+                               const float* copy_src, float* copy_dst, void* stream);
 
 // Same update with the step count (1-based) and learning rate passed from the host.
 int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
                           float beta2, float eps, float weight_decay, float grad_scale, long long n,
                           void* stream) {
-  if (!p || !g || !m || !v || n <= 0 || step < 1) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     (const float*)nullptr, (float)step, lr, beta1, beta2, eps, weight_decay, grad_scale, n,
-                     (const float*)nullptr, (float*)nullptr);
-  return (int)hipGetLastError();
+  return larva_adamw_step_host_copy(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale, n, nullptr, nullptr,
+                                    stream);
 }
 
 // larva_adamw_step_host that also copies ONE float (copy_dst[0] = copy_src[0]) -- the step's loss out of the
@@ -599,9 +633,12 @@ int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int
                                float beta2, float eps, float weight_decay, float grad_scale, long long n,
                                const float* copy_src, float* copy_dst, void* stream) {
   if (!p || !g || !m || !v || n <= 0 || step < 1 || (copy_dst && !copy_src)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     (const float*)nullptr, (float)step, lr, beta1, beta2, eps, weight_decay, grad_scale, n, copy_src,
-                     copy_dst);
+  // the per-step scalars in double, like torch.optim.AdamW computes them on the host
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const AdamwCoef coef{(float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), (float)(1.0 - (double)lr * (double)weight_decay)};
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (const float*)nullptr, coef, beta1, beta2, eps, weight_decay, grad_scale, n, adamw_vec_ok(p, g, m, v),
+                     copy_src, copy_dst);
   return (int)hipGetLastError();
 }
 

@@ -806,6 +806,33 @@ def test_reduce_launch_carries_the_loss_and_adamw_launch_the_copy(hip_device):
     assert torch.equal(res[0], res[1]) and torch.equal(copy[1], ref_loss)
 
 
+def test_adamw_host_scalars_match_torch_and_unaligned_views(hip_device):
+    """larva_adamw_step_host: 16-byte-per-lane walk + a tail (n % 4 != 0), against torch.optim.AdamW on the CPU over 5
+    steps; buffers that start 4 bytes off a 16-byte boundary take the element-wise walk and give the same bits."""
+    from larvanet_amd import kernels as K
+    gen = torch.Generator().manual_seed(5)
+    n = 40007
+    p0 = torch.randn(n, generator=gen) * 0.05
+    grads = [torch.randn(n, generator=gen) * 1e-3 for _ in range(5)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    outs = []
+    for off in (0, 1):
+        buf = [torch.zeros(n + 4, device=hip_device) for _ in range(4)]
+        p, g, m, v = (b[off:off + n] for b in buf)
+        p.copy_(p0)
+        for t, gr in enumerate(grads, 1):
+            g.copy_(gr)
+            K.adamw_step_host(p, g, m, v, t, 4e-4, 0.9, 0.999, 1e-8, 0.01)
+        outs.append((p.clone(), m.clone(), v.clone()))
+    for gr in grads:
+        ref.grad = gr.clone()
+        opt.step()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-8)
+
+
 def test_strip_tiles_seeded_shape_fuzz(hip_device):
     """24 seeded random problems (batch, height, width % 4 == 0, 1-2 sources, every mode-0 epilogue and the
     pixel-shuffle ones, image sub-ranges, both table phases and store policies): strip tiles == 3 x 48 tiles
