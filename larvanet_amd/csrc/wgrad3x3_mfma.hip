@@ -746,29 +746,45 @@ struct ReduceBatch {
   float* loss_out;
 };
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceBatch rb) {
-  if ((int)blockIdx.y == rb.njobs) {   // (only launched when there is a loss to finish)
-    if (blockIdx.x == 0) loss_terms_block(rb.loss_terms, rb.loss_divisor, rb.loss_out);
-    return;
-  }
-  const ReduceJob& j = rb.job[blockIdx.y];
+// One block per (layer, 16 output channels, 16 input channels): threads 0..191 each sum three 16-byte columns of
+// the [splits][pf] partial matrix (tap = 3 u + tid / 64; up to 24 independent loads in flight), the sums cross an LDS
+// transpose from accumulator layout to [co][ci][tap], and all 256 threads write the block's 16 runs of 144
+// contiguous floats of dw.  (Until round 2 every thread stored its 4 sums straight from accumulator layout:
+// 4-byte stores 36 bytes apart, 16.7 MB of HBM writes for 2.65 MB of gradients.)
+// A layer with MANY partial images (the 3 -> 48 head: one image per tile, 256 of them, for 1296 gradients) keeps the
+// older form instead -- 16-byte columns stored straight from accumulator layout, 64 columns per block with the
+// images dealt to the block's four waves: its (cout / 16) x (cin / 16) blocks would each pull megabytes through
+// one CU (and did so in the column-per-thread form too: 7 blocks, 1 MB each, were the launch's long pole).
+constexpr int kReduceRow = 16 * 9 + 1;   // LDS row of one output channel: [ci 16][tap 9] + 1 float of bank skew
+constexpr int kReduceColumnwiseAbove = 16;   // partial images per layer above which the column-per-thread form runs
+
+__device__ __forceinline__ void reduce_columnwise(const ReduceJob& j) {
+  // 64 columns per block; wave w sums the images k = w, w + 4, ... (8 loads in flight), the four sums meet in LDS
+  // in a fixed order
+  __shared__ f32x4 meet[3][64];
   const int ct_n = j.cout / 16, nb = (j.cin / 16) * 9;
   const int n_w = nb * ct_n * 256;
   const int pf = n_w + j.cout;  // multiple of 4
-  const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= pf) return;
-  // one 16-byte column of the [splits][pf] partial matrix per thread; 8 independent loads in flight
+  const int col = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = (blockIdx.x * 64 + col) * 4;
+  if (blockIdx.x * 256 >= pf) return;   // (whole block)
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  const float* p = j.partial + i;
-  int k = 0;
-  for (; k + 8 <= j.splits; k += 8) {
-    f32x4 v[8];
+  if (i < pf) {
+    const float* p = j.partial + i;
+    int k = wave;
+    for (; k + 28 < j.splits; k += 32) {
+      f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + u) * pf);
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 4 * u) * pf);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < j.splits; k += 4) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * pf);
   }
-  for (; k < j.splits; ++k) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * pf);
+  if (wave) meet[wave - 1][col] = s;
+  __syncthreads();
+  if (wave || i >= pf) return;
+  s = (s + meet[0][col]) + (meet[1][col] + meet[2][col]);
   if (i < n_w) {
     const int lane = (i >> 2) & 63;
     const int t = i >> 8;
@@ -783,6 +799,65 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceBatch rb) {
   } else if (j.db) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) j.db[i - n_w + r] = s[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceBatch rb) {
+  if ((int)blockIdx.y == rb.njobs) {   // (only launched when there is a loss to finish)
+    if (blockIdx.x == 0) loss_terms_block(rb.loss_terms, rb.loss_divisor, rb.loss_out);
+    return;
+  }
+  __shared__ float tile[16 * kReduceRow];
+  const ReduceJob& j = rb.job[blockIdx.y];
+  if (j.splits > kReduceColumnwiseAbove) return reduce_columnwise(j);
+  const int ct_n = j.cout / 16;
+  const int c = blockIdx.x % ct_n, cit = blockIdx.x / ct_n;
+  if (cit >= j.cin / 16) return;
+  const int n_w = (j.cin / 16) * 9 * ct_n * 256;
+  const int pf = n_w + j.cout;  // multiple of 4
+  const int tid = threadIdx.x;
+  if (tid < 192) {
+    const int lane = tid & 63, tap0 = tid >> 6;
+    f32x4 s[3];
+    const float* p[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      p[u] = j.partial + ((size_t)((cit * 9 + tap0 + 3 * u) * ct_n + c) * 256 + lane * 4);
+    }
+    int k = 0;
+    for (; k + 8 <= j.splits; k += 8) {   // the images are added in index order, whatever is in flight
+      f32x4 v[3][8];
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[u][q] = *reinterpret_cast<const f32x4*>(p[u] + (size_t)(k + q) * pf);
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s[u] += v[u][q];
+    }
+    for (; k < j.splits; ++k)
+#pragma unroll
+      for (int u = 0; u < 3; ++u) s[u] += *reinterpret_cast<const f32x4*>(p[u] + (size_t)k * pf);
+    const int co = (lane >> 4) * 4, ci = lane & 15;   // accumulator layout: lane -> (4 output channels, input channel)
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(co + r) * kReduceRow + ci * 9 + tap0 + 3 * u] = s[u][r];
+  } else if (cit == 0 && j.db && tid < 192 + 16) {   // the bias gradient: the last `cout` floats of every image
+    const float* p = j.partial + n_w + c * 16 + (tid - 192);
+    float sb = 0.f;
+    for (int k = 0; k < j.splits; ++k) sb += p[(size_t)k * pf];
+    j.db[c * 16 + (tid - 192)] = sb;
+  }
+  __syncthreads();
+  const int ci_n = min(16, j.cin_valid - cit * 16);   // (the head: 3 of its 16 padded input channels exist)
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const int idx = e * 256 + tid, co = idx / 144, rem = idx - co * 144;
+    if (rem < ci_n * 9)
+      j.dw[((size_t)(c * 16 + co) * j.w_cin_total + j.cin_off + cit * 16) * 9 + rem] = tile[co * kReduceRow + rem];
   }
 }
 
@@ -953,7 +1028,9 @@ static int reduce_launch(const float* const* partial, float* const* dw, float* c
       return (int)hipErrorInvalidValue;
     rb.job[i] = ReduceJob{partial[i], dw[i], db ? db[i] : nullptr, cin_off[i], cin_valid[i], w_cin_total[i],
                           splits[i], cout[i], cin[i]};
-    const int pf = (cin[i] / 16) * 9 * (cout[i] / 16) * 256 + cout[i];
+    const int pf = splits[i] > kReduceColumnwiseAbove
+                       ? (((cin[i] / 16) * 9 * (cout[i] / 16) * 256 + cout[i]) / 4 + 63) / 64
+                       : (cout[i] / 16) * (cin[i] / 16);   // blocks of this layer
     pf_max = pf > pf_max ? pf : pf_max;
   }
   rb.njobs = njobs;
@@ -962,7 +1039,7 @@ static int reduce_launch(const float* const* partial, float* const* dw, float* c
     rb.loss_divisor = divisor;
     rb.loss_out = loss_out;
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((pf_max / 4 + 255) / 256, njobs + (loss ? 1 : 0)), dim3(256), 0,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(pf_max, njobs + (loss ? 1 : 0)), dim3(256), 0,
                      (hipStream_t)stream, rb);
   return (int)hipGetLastError();
 }
