@@ -975,42 +975,59 @@ __host__ __device__ constexpr int packed_floats(int cout, int cin) {
   return (cin / kCh) * 9 * kCh * cout_stride(cout);
 }
 
-// All layers of a network in one launch (blockIdx.y = layer): 41 packs per training step would
-// otherwise be 41 launch boundaries for 3 us of work each.
-__device__ __forceinline__ void pack_job(const PackJob& j, int first, int stride) {
-  const int csf = cout_stride(j.cout), csb = cout_stride(j.cin);
-  const int nf = packed_floats(j.cout, j.cin);
-  const int nb = packed_floats(j.cin, j.cout);
-  for (int i = first; i < nf + nb; i += stride) {
-    if (i < nf) {
-      if (!j.fwd) continue;
-      const int co = i % csf;
-      int t = i / csf;
-      const int k = t % kCh; t /= kCh;
-      const int tap = t % 9;
-      const int chunk = t / 9;
-      const int cin_abs = j.w_cin_off + chunk * kCh + k;
-      float v = 0.f;
-      if (co < j.cout && cin_abs < j.w_cin_total) v = j.w[((size_t)co * j.w_cin_total + cin_abs) * 9 + tap];
-      j.fwd[i] = v;
+// All layers of a network in one launch: 41 packs per training step would otherwise be 41 launch boundaries for
+// 3 us of work each.  One block per (layer, direction, chunk of 8 channels): it reads the chunk's source rows
+// (fwd: 72 contiguous floats per output channel; bwd: cin x 9 contiguous floats per output channel of the chunk)
+// with consecutive lanes on consecutive floats, transposes them in LDS and writes the chunk's 72 x CS packed rows
+// (64 columns per pass: one contiguous run when CS <= 64).  (Until round 2 every thread gathered ONE packed float: three integer divisions and a
+// 36- or 1728-byte-strided load each, 7872 blocks per step.)
+constexpr int kPackTileCols = 64;                       // columns of a packed row one pass of the LDS tile holds
+constexpr int kPackLd = kPackTileCols + 1;
+constexpr int kPackTileFloats = 9 * kCh * kPackLd;
+
+__host__ __device__ constexpr int pack_slots(int cout, int cin) { return cin / kCh + cout / kCh; }
+
+__device__ __forceinline__ void pack_block(const PackJob& j, int slot, float* __restrict__ tile) {
+  const int nfc = j.cin / kCh;
+  const bool fwd = slot < nfc;
+  const int chunk = fwd ? slot : slot - nfc;
+  float* __restrict__ out = fwd ? j.fwd : j.bwd;
+  if ((!fwd && chunk >= j.cout / kCh) || !out) return;   // (whole block)
+  const int cols = fwd ? j.cout : j.cin;                 // fastest index of a packed row
+  const int cs = cout_stride(cols);
+  const int tid = threadIdx.x;
+  out += (size_t)chunk * 72 * cs;
+  for (int c0 = 0; c0 < cs; c0 += kPackTileCols) {       // 64 columns of the chunk's 72 rows per pass
+    const int ncol = min(kPackTileCols, cols - c0);      // source columns of this pass (<= 0: padding only)
+    if (fwd) {
+      for (int idx = tid; idx < ncol * 72; idx += 256) {
+        const int c = idx / 72, r = idx - c * 72, k = r / 9, tap = r - k * 9;
+        const int cin_abs = j.w_cin_off + chunk * kCh + k;
+        tile[(tap * kCh + k) * kPackLd + c] =
+            cin_abs < j.w_cin_total ? j.w[((size_t)(c0 + c) * j.w_cin_total + cin_abs) * 9 + tap] : 0.f;
+      }
     } else {
-      if (!j.bwd) continue;
-      const int q = i - nf;
-      const int ci = q % csb;
-      int t = q / csb;
-      const int k = t % kCh; t /= kCh;
-      const int tap = t % 9;
-      const int chunk = t / 9;
-      float v = 0.f;
-      if (ci < j.cin && j.w_cin_off + ci < j.w_cin_total)
-        v = j.w[((size_t)(chunk * kCh + k) * j.w_cin_total + j.w_cin_off + ci) * 9 + (8 - tap)];
-      j.bwd[q] = v;
+      const int row = ncol * 9;
+      for (int idx = tid; idx < kCh * row; idx += 256) {
+        const int k = idx / row, rem = idx - k * row, c = rem / 9, tap = rem - c * 9;
+        tile[((8 - tap) * kCh + k) * kPackLd + c] =
+            j.w_cin_off + c0 + c < j.w_cin_total
+                ? j.w[((size_t)(chunk * kCh + k) * j.w_cin_total + j.w_cin_off + c0) * 9 + rem] : 0.f;
+      }
     }
+    __syncthreads();
+    const int wcols = min(kPackTileCols, cs - c0);
+    for (int idx = tid; idx < 72 * wcols; idx += 256) {
+      const int r = idx / wcols, c = idx - r * wcols;
+      out[r * cs + c0 + c] = c < ncol ? tile[r * kPackLd + c] : 0.f;
+    }
+    __syncthreads();
   }
 }
 
-__global__ void pack_weights_batch_kernel(PackBatch b) {
-  pack_job(b.job[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(PackBatch b) {
+  __shared__ float tile[kPackTileFloats];
+  pack_block(b.job[blockIdx.y], blockIdx.x, tile);
 }
 
 // Everything a training step does before its first convolution, in ONE launch (blockIdx.y = role):
@@ -1018,10 +1035,11 @@ __global__ void pack_weights_batch_kernel(PackBatch b) {
 // head's input zero-padded to 16 channels (HeadFn) and the bicubic x4 base image
 // (models/LarvaNet.py:283-285).  As three launches these were 8 + 4 + 7 us of launch-latency-bound
 // work in front of the layer chain.
+constexpr int kPrologueBlocks = 192;   // blocks per pad / bicubic slice
 constexpr int kProloguePadSlices = 2, kPrologueBicSlices = 8;
 struct PrologueArgs {
   PackBatch packs;
-  int npack;
+  int npack, slots;   // pack blocks: npack x slots (slots = the largest pack_slots() of the jobs), the first in the grid
   const float* x;     // [N][C][H][W], C <= 16
   float* x16;         // [N][16][H][W]: channels [0, C) copied (the rest stay zero: written once by the host)
   float* base;        // [N][C][4H][4W]
@@ -1029,19 +1047,25 @@ struct PrologueArgs {
 };
 
 __global__ __launch_bounds__(256) void step_prologue_kernel(PrologueArgs a) {
-  const int y = blockIdx.y;
-  const int tid = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
-  if (y < a.npack) {
-    pack_job(a.packs.job[y], tid, nthr);
-  } else if (y < a.npack + kProloguePadSlices) {
+  __shared__ float tile[kPackTileFloats];
+  int blk = blockIdx.x;
+  if (blk < a.npack * a.slots) {
+    const int job = blk / a.slots;
+    pack_block(a.packs.job[job], blk - job * a.slots, tile);
+    return;
+  }
+  blk -= a.npack * a.slots;
+  constexpr int nthr = kPrologueBlocks * 256;
+  const int slice = blk / kPrologueBlocks, tid = (blk - slice * kPrologueBlocks) * 256 + threadIdx.x;
+  const int nbic = a.base ? kPrologueBicSlices : 0;
+  if (slice < nbic) {
+    bicubic4_body(a.x, a.base, a.N * a.C, a.H, a.W, (long long)slice * nthr + tid, (long long)nthr * kPrologueBicSlices);
+  } else {
     const int plane = a.H * a.W, per_img = a.C * plane, total = a.N * per_img;
-    for (int i = (y - a.npack) * nthr + tid; i < total; i += nthr * kProloguePadSlices) {
+    for (int i = (slice - nbic) * nthr + tid; i < total; i += nthr * kProloguePadSlices) {
       const int n = i / per_img, r = i - n * per_img;
       a.x16[(size_t)n * 16 * plane + r] = a.x[i];
     }
-  } else {
-    const int slice = y - a.npack - kProloguePadSlices;
-    bicubic4_body(a.x, a.base, a.N * a.C, a.H, a.W, (long long)slice * nthr + tid, (long long)nthr * kPrologueBicSlices);
   }
 }
 
@@ -1162,20 +1186,26 @@ extern "C" {
 long long larva_packed_weight_floats(int cout, int cin) { return (long long)packed_floats(cout, cin); }
 
 // njobs (<= 64) packs in one launch; arrays are host arrays of length njobs.
+static int fill_pack_jobs(PackBatch& b, const float* const* w, float* const* wpk_fwd, float* const* wpk_bwd,
+                          const int* cout, const int* cin, const int* w_cin_total, const int* w_cin_off, int njobs) {
+  int slots = 0;   // -> blocks per job; < 0: invalid
+  for (int i = 0; i < njobs; ++i) {
+    if (!w[i] || cout[i] % kCh || cin[i] % kCh || cout[i] <= 0 || cin[i] <= 0) return -1;
+    b.job[i] = PackJob{w[i], wpk_fwd[i], wpk_bwd[i], cout[i], cin[i], w_cin_total[i], w_cin_off[i]};
+    const int n = pack_slots(cout[i], cin[i]);
+    slots = n > slots ? n : slots;
+  }
+  return slots;
+}
+
 int larva_pack_weights_batch(const float* const* w, float* const* wpk_fwd, float* const* wpk_bwd,
                              const int* cout, const int* cin, const int* w_cin_total,
                              const int* w_cin_off, int njobs, void* stream) {
   if (njobs < 1 || njobs > kMaxPackJobs) return (int)hipErrorInvalidValue;
   PackBatch b{};
-  int max_total = 0;
-  for (int i = 0; i < njobs; ++i) {
-    if (!w[i] || cout[i] % kCh || cin[i] % kCh || cout[i] <= 0 || cin[i] <= 0) return (int)hipErrorInvalidValue;
-    b.job[i] = PackJob{w[i], wpk_fwd[i], wpk_bwd[i], cout[i], cin[i], w_cin_total[i], w_cin_off[i]};
-    const int total = packed_floats(cout[i], cin[i]) + packed_floats(cin[i], cout[i]);
-    max_total = total > max_total ? total : max_total;
-  }
-  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((max_total + 255) / 256, njobs), dim3(256), 0,
-                     (hipStream_t)stream, b);
+  const int slots = fill_pack_jobs(b, w, wpk_fwd, wpk_bwd, cout, cin, w_cin_total, w_cin_off, njobs);
+  if (slots < 1) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(slots, njobs), dim3(256), 0, (hipStream_t)stream, b);
   return (int)hipGetLastError();
 }
 
@@ -1190,17 +1220,15 @@ int larva_step_prologue(const float* const* w, float* const* wpk_fwd, float* con
   if ((long long)N * 16 * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
   if (base && (reinterpret_cast<uintptr_t>(base) & 15)) return (int)hipErrorInvalidValue;
   PrologueArgs a{};
-  for (int i = 0; i < njobs; ++i) {
-    if (!w[i] || cout[i] % kCh || cin[i] % kCh || cout[i] <= 0 || cin[i] <= 0) return (int)hipErrorInvalidValue;
-    a.packs.job[i] = PackJob{w[i], wpk_fwd[i], wpk_bwd[i], cout[i], cin[i], w_cin_total[i], w_cin_off[i]};
-  }
+  a.slots = njobs ? fill_pack_jobs(a.packs, w, wpk_fwd, wpk_bwd, cout, cin, w_cin_total, w_cin_off, njobs) : 0;
+  if (a.slots < 0) return (int)hipErrorInvalidValue;
   a.npack = njobs;
   a.x = x; a.x16 = x16; a.base = base;
   a.N = N; a.C = C; a.H = H; a.W = W;
-  const int roles = njobs + (x16 ? kProloguePadSlices : 0) + (base ? kPrologueBicSlices : 0);
-  if (!x16 && base) return (int)hipErrorInvalidValue;   // (roles are positional: pad slices precede the bicubic ones)
-  if (roles == 0) return 0;
-  hipLaunchKernelGGL(step_prologue_kernel, dim3(192, roles), dim3(256), 0, (hipStream_t)stream, a);
+  if (!x16 && base) return (int)hipErrorInvalidValue;   // (slices are positional: the bicubic ones precede the pad ones)
+  const int blocks = njobs * a.slots + kPrologueBlocks * ((base ? kPrologueBicSlices : 0) + (x16 ? kProloguePadSlices : 0));
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
