@@ -185,6 +185,9 @@ int larva_wgrad_reduce_with_loss(const float* const* partial, float* const* dw, 
  * F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False), models/LarvaNet.py:283-285.
  * in [N][C][H][W] -> out [N][C][4H][4W]. */
 int larva_bicubic4_fwd(const float* in, float* out, int N, int C, int H, int W, void* stream);
+/* F.interpolate(x, scale_factor=4, mode, align_corners=False) for the modes with which the reference's call
+ * (models/LarvaNet.py:57,283-285) does not raise: mode 0 bicubic (as above), 1 bilinear.  out 16-byte aligned. */
+int larva_upsample4_fwd(const float* in, float* out, int N, int C, int H, int W, int mode, void* stream);
 
 /* ---- L1 loss ---------------------------------------------------------------------------------
  * nn.L1Loss() forward/backward, models/LarvaNet.py:85,108,113.  Pointers 16-byte aligned. */

@@ -19,6 +19,47 @@ __global__ void bicubic4_kernel(const float* __restrict__ in, float* __restrict_
                 (long long)gridDim.x * blockDim.x);
 }
 
+// The other F.interpolate mode the reference's --interpolate flag can reach (models/LarvaNet.py:57,283-285 always
+// passes align_corners=False, which F.interpolate refuses for nearest / area with a ValueError; 'linear' and
+// 'trilinear' do not take 4-D input): BILINEAR x4.  src = max(0.25 (dst + 0.5) - 0.5, 0), i0 = floor(src),
+// i1 = min(i0 + 1, size - 1), w1 = src - i0; out = w0y (w0x v00 + w1x v01) + w1y (w0x v10 + w1x v11) (ATen
+// upsample_bilinear2d: rows of x-interpolations).  One thread produces the 4 horizontally adjacent outputs of one
+// LR pixel in one HR row, like bicubic4_body.
+__global__ void bilinear4_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int H, int W) {
+  const int HH = 4 * H;
+  const long long total = (long long)planes * HH * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const long long t2 = i / W;
+    const int Y = (int)(t2 % HH);
+    const int p = (int)(t2 / HH);
+    const float* src = in + (size_t)p * H * W;
+    const float sy = fmaxf(0.25f * ((float)Y + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, y1 = min(y0 + 1, H - 1);
+    const float wy1 = sy - (float)y0, wy0 = 1.f - wy1;
+    // columns x-1, x, x+1 of the two source rows
+    float v[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int xx = min(max(x - 1 + c, 0), W - 1);
+      v[0][c] = src[(size_t)y0 * W + xx];
+      v[1][c] = src[(size_t)y1 * W + xx];
+    }
+    f32x4 o;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const float sx = fmaxf(0.25f * ((float)(4 * x + jj) + 0.5f) - 0.5f, 0.f);
+      const int x0 = (int)sx;                       // x - 1 for jj < 2 (x itself at the left border), else x
+      const float wx1 = sx - (float)x0, wx0 = 1.f - wx1;
+      const int c0 = x0 - (x - 1), c1 = min(x0 + 1, W - 1) - (x - 1);
+      const float a0 = c0 == 0 ? v[0][0] : v[0][1], a1 = c1 == 0 ? v[0][0] : c1 == 1 ? v[0][1] : v[0][2];
+      const float b0 = c0 == 0 ? v[1][0] : v[1][1], b1 = c1 == 0 ? v[1][0] : c1 == 1 ? v[1][1] : v[1][2];
+      o[jj] = wy0 * (wx0 * a0 + wx1 * a1) + wy1 * (wx0 * b0 + wx1 * b1);
+    }
+    *reinterpret_cast<f32x4*>(out + ((size_t)p * HH + Y) * (4 * W) + 4 * x) = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LarvaHead (models/LarvaNet.py:223-233): conv3x3 3 -> COUT, bias, no activation, as a DIRECT
 // convolution.  K = 27: on the MFMA kernel the image is zero-padded to 16 channels (two 8-channel
@@ -452,6 +493,18 @@ int larva_bicubic4_fwd(const float* in, float* out, int N, int C, int H, int W, 
   const long long work = (long long)N * C * 4 * H * W;
   hipLaunchKernelGGL(bicubic4_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
                      N * C, H, W);
+  return (int)hipGetLastError();
+}
+
+// F.interpolate(x, scale_factor=4, mode, align_corners=False) for mode 0 = bicubic (larva_bicubic4_fwd) and
+// 1 = bilinear -- the two modes for which the reference's call (models/LarvaNet.py:283-285) does not raise.
+// out must be 16-byte aligned.
+int larva_upsample4_fwd(const float* in, float* out, int N, int C, int H, int W, int mode, void* stream) {
+  if (mode == 0) return larva_bicubic4_fwd(in, out, N, C, H, W, stream);
+  if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || mode != 1 || (reinterpret_cast<uintptr_t>(out) & 15))
+    return (int)hipErrorInvalidValue;
+  const long long work = (long long)N * C * 4 * H * W;
+  hipLaunchKernelGGL(bilinear4_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N * C, H, W);
   return (int)hipGetLastError();
 }
 

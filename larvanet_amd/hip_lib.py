@@ -73,6 +73,8 @@ SIGNATURES = {
                                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                                   ctypes.c_float, ctypes.c_float, ctypes.c_longlong, _c_float_p, _c_float_p,
                                                   ctypes.c_void_p]),
+    "larva_upsample4_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_bicubic4_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_void_p]),
     "larva_l1_workspace_floats": (ctypes.c_int, []),

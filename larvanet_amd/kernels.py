@@ -475,6 +475,23 @@ def wgrad_reduce(jobs, cout=None, cin=None, loss=None):
     hip_lib.check(code, "larva_wgrad_reduce")
 
 
+UPSAMPLE_MODES = {"bicubic": 0, "bilinear": 1}
+
+
+def upsample4(x, mode="bicubic"):
+    """F.interpolate(x, scale_factor=4, mode=mode, align_corners=False) (models/LarvaNet.py:283-285) for the two
+    modes that call accepts for a 4-D input (nearest / area refuse align_corners, linear / trilinear the rank)."""
+    lib = hip_lib.load()
+    if mode not in UPSAMPLE_MODES:
+        raise RuntimeError("larvanet_amd: no x4 kernel for interpolate mode %r" % (mode,))
+    N, C, H, W = (int(v) for v in x.shape)
+    _chk(x, "x")
+    out = torch.empty((N, C, 4 * H, 4 * W), device=x.device, dtype=torch.float32)
+    hip_lib.check(lib.larva_upsample4_fwd(x.data_ptr(), out.data_ptr(), N, C, H, W, UPSAMPLE_MODES[mode], _stream()),
+                  "larva_upsample4_fwd")
+    return out
+
+
 def bicubic4(x):
     lib = hip_lib.load()
     N, C, H, W = (int(v) for v in x.shape)

@@ -26,10 +26,12 @@ from ..optim import FlatAdamW, flatten_parameters
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
 from .base import BaseModel
 
-# F.interpolate modes of the base image (models/LarvaNet.py:283-285) that have a HIP kernel.  The
-# reference hands any mode string to F.interpolate; here an unsupported one is refused when the
-# flags are parsed, not at the first forward.
-SUPPORTED_INTERPOLATE = ("bicubic",)
+# F.interpolate modes of the base image (models/LarvaNet.py:283-285).  The reference hands the string to
+# F.interpolate(x, scale_factor=4, mode=..., align_corners=False) at the first forward; of the modes torch knows
+# only these two survive that call (nearest / nearest-exact / area raise ValueError because of align_corners,
+# linear / trilinear NotImplementedError for a 4-D input).  Both have a HIP kernel; anything else is refused
+# with the same ValueError when the flags are parsed instead of at the first forward.
+SUPPORTED_INTERPOLATE = ("bicubic", "bilinear")
 
 NUM_FILTERS = 48  # = 3 * 4**2: PixelShuffle(4) of the leg output must give RGB (models/LarvaNet.py:226,261)
 
@@ -205,13 +207,13 @@ class LarvaNetModule(nn.Module):
         return res[1], res[0]
 
     def base(self, x):
-        """F.interpolate(x, scale_factor=4, mode='bicubic', align_corners=False) (models/LarvaNet.py:283-285)."""
+        """F.interpolate(x, scale_factor=4, mode=args.interpolate, align_corners=False) (models/LarvaNet.py:283-285)."""
         _require_hip(x)
         if self.interpolate not in SUPPORTED_INTERPOLATE:   # (parse_args already refuses it)
             raise ValueError("larvanet_amd: --interpolate=%s has no HIP kernel; supported: %s"
                              % (self.interpolate, ", ".join(SUPPORTED_INTERPOLATE)))
         with torch.no_grad():
-            return K.bicubic4(x.detach().contiguous())
+            return K.upsample4(x.detach().contiguous(), self.interpolate)
 
     def width_scope(self, x):
         """Row-padded activations for inference on widths that are not a multiple of 4."""

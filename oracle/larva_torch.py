@@ -43,10 +43,10 @@ def leg(sd, prefix, fea, base):
     return out + base
 
 
-def forward_exits(sd, x, blocks):
-    """models/LarvaNet.py:102-108"""
+def forward_exits(sd, x, blocks, mode="bicubic"):
+    """models/LarvaNet.py:102-108 (mode = --interpolate, models/LarvaNet.py:57)"""
     fea = head(sd, x)
-    base = base_image(x)
+    base = base_image(x, mode)
     outs, feats = [], []
     for i, nb in enumerate(blocks):
         fea = body(sd, i, fea, nb)
@@ -55,12 +55,12 @@ def forward_exits(sd, x, blocks):
     return outs, feats, base
 
 
-def forward(sd, x, blocks):
+def forward(sd, x, blocks, mode="bicubic"):
     """models/LarvaNet.py:287-293"""
     fea = head(sd, x)
     for i, nb in enumerate(blocks):
         fea = body(sd, i, fea, nb)
-    return leg(sd, "body_%d.leg" % (len(blocks) - 1), fea, base_image(x))
+    return leg(sd, "body_%d.leg" % (len(blocks) - 1), fea, base_image(x, mode))
 
 
 def tail(sd, feats, base):
@@ -69,15 +69,15 @@ def tail(sd, feats, base):
     return leg(sd, "tail", fea, base)
 
 
-def forward_v2(sd, x, blocks):
+def forward_v2(sd, x, blocks, mode="bicubic"):
     """models/LarvaNetV2.py:355-365"""
-    _, feats, base = forward_exits(sd, x, blocks)
+    _, feats, base = forward_exits(sd, x, blocks, mode)
     return tail(sd, feats, base)
 
 
-def multi_exit_loss(sd, x, truth, blocks, v2=False):
+def multi_exit_loss(sd, x, truth, blocks, v2=False, mode="bicubic"):
     """models/LarvaNet.py:104-109 / models/LarvaNetV2.py:108-123"""
-    outs, feats, base = forward_exits(sd, x, blocks)
+    outs, feats, base = forward_exits(sd, x, blocks, mode)
     loss = 0
     for o in outs:
         loss = loss + F.l1_loss(o, truth)

@@ -277,6 +277,23 @@ def test_bicubic4(hip_device, golden):
     np.testing.assert_allclose(out.cpu().numpy(), R.bicubic_up(x, 4), rtol=1e-5, atol=3e-4)
 
 
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+def test_upsample4_modes_match_f_interpolate(hip_device, mode):
+    """The two modes with which the reference's F.interpolate(..., align_corners=False) call works
+    (models/LarvaNet.py:57,283-285) against F.interpolate itself on the CPU, within fp32 rounding on the 0-255
+    scale; borders, a 1-pixel-wide and a 1-pixel-high image included."""
+    import torch.nn.functional as F
+    from larvanet_amd import kernels as K
+    rng = np.random.default_rng(31)
+    for shape in ((2, 3, 17, 23), (1, 3, 1, 9), (1, 2, 6, 1), (16, 3, 48, 48)):
+        x = torch.from_numpy((rng.random(shape) * 255).astype(np.float32))
+        ref = F.interpolate(x, scale_factor=4, mode=mode, align_corners=False)
+        out = K.upsample4(x.to(hip_device), mode).cpu()
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=3e-4, err_msg="%s %s" % (mode, shape))
+    with pytest.raises(RuntimeError):
+        K.upsample4(x.to(hip_device), "nearest")
+
+
 @pytest.mark.parametrize("numel_shape", [(2, 3, 16, 20), (1, 3, 7, 9), (16, 3, 192, 192)])
 def test_l1_forward_backward(hip_device, numel_shape):
     from larvanet_amd import kernels as K

@@ -26,13 +26,21 @@ def test_parse_args_chaining_returns_copy_and_leftovers():
 
 
 def test_unsupported_interpolate_mode_is_refused_when_the_flags_are_parsed():
-    """The reference hands any --interpolate string to F.interpolate (models/LarvaNet.py:283-285);
-    only bicubic has a HIP kernel, and the refusal names what is supported."""
+    """The reference hands any --interpolate string to F.interpolate(..., align_corners=False)
+    (models/LarvaNet.py:283-285): bicubic and bilinear work there and have HIP kernels; every other mode raises
+    in that call (checked here against F.interpolate itself) and is refused when the flags are parsed."""
     import importlib
+    import torch
+    import torch.nn.functional as F
     m = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
-    with pytest.raises(ValueError, match="bicubic"):
-        m.parse_args(["--num_modules=1", "--num_blocks=1", "--interpolate=bilinear"])
-    m.parse_args(["--num_modules=1", "--num_blocks=1", "--interpolate=bicubic"])
+    for bad in ("nearest", "nearest-exact", "area", "trilinear", "linear", "lanczos"):
+        with pytest.raises(ValueError, match="bicubic"):
+            m.parse_args(["--num_modules=1", "--num_blocks=1", "--interpolate=" + bad])
+        with pytest.raises((NotImplementedError, ValueError)):
+            F.interpolate(torch.zeros(1, 3, 4, 4), scale_factor=4, mode=bad, align_corners=False)
+    for ok in ("bicubic", "bilinear"):
+        m.parse_args(["--num_modules=1", "--num_blocks=1", "--interpolate=" + ok])
+        F.interpolate(torch.zeros(1, 3, 4, 4), scale_factor=4, mode=ok, align_corners=False)
 
 
 def test_prepare_validates_scales_and_block_list():

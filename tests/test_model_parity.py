@@ -392,6 +392,39 @@ def test_forward_and_train_step_shape_fuzz_against_the_cpu_restatement(hip_devic
             assert np.abs(ga - gb).max() <= 2e-4 * max(np.abs(gb).max(), 1e-30), (case, name, blocks, k)
 
 
+@pytest.mark.parametrize("name", ["LarvaNet", "LarvaNetV2"])
+@pytest.mark.parametrize("mode", ["bilinear"])
+def test_other_interpolate_modes_against_the_cpu_restatement(hip_device, name, mode):
+    """--interpolate=<mode> (models/LarvaNet.py:57,283-285): inference forward and one training step (loss and
+    every gradient: the base image carries no gradient but shifts every exit's L1 sign) against
+    oracle/larva_torch.py, which hands the same string to F.interpolate."""
+    from oracle import larva_torch as T
+    blocks, v2 = [2, 1], name == "LarvaNetV2"
+    m = _model(name, ["--num_modules=2", "--num_blocks=2,1", "--interpolate=" + mode], training=True, seed=7)
+    sd = {k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()}
+    rng = np.random.RandomState(77)
+    img = rng.randint(0, 256, size=(3, 13, 18)).astype(np.float32)
+    got = m.upscale([img], 4)[0]
+    with torch.no_grad():
+        xt = torch.from_numpy(img)[None]
+        ref = (T.forward_v2(sd, xt, blocks, mode) if v2 else T.forward(sd, xt, blocks, mode))[0].numpy()
+    assert np.abs(got - ref).max() <= 2e-3, (name, mode, float(np.abs(got - ref).max()))
+    x = torch.from_numpy(rng.randint(0, 256, size=(2, 3, 12, 12)).astype(np.float32))
+    t = torch.from_numpy(rng.randint(0, 256, size=(2, 3, 48, 48)).astype(np.float32))
+    for use_graph in (False, True):
+        m.use_hip_graph = use_graph
+        m._graph_shape = None
+        loss, _ = m._forward_backward(x.to(hip_device), t.to(hip_device))
+        torch.cuda.synchronize()
+        sd_req = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref_loss = T.multi_exit_loss(sd_req, x, t, blocks, v2=v2, mode=mode)
+        ref_loss.backward()
+        assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-5 * abs(float(ref_loss.detach())), (name, mode, use_graph)
+        for k, prm in m.model.named_parameters():
+            ga, gb = prm.grad.cpu().numpy(), sd_req[k].grad.numpy()
+            assert np.abs(ga - gb).max() <= 2e-4 * max(np.abs(gb).max(), 1e-30), (name, mode, use_graph, k)
+
+
 @pytest.mark.parametrize("name,flags,use_graph", [("LarvaNet", ["--num_modules=3", "--num_blocks=2,1,2"], False),
                                                   ("LarvaNet", ["--num_modules=2", "--num_blocks=2,2"], True),
                                                   ("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,2"], False),

@@ -138,3 +138,25 @@ print("  one chain, 3x48 tiles, tensor + weights per layer         %.2f" % timed
 print("  three chains 6 + 5 + 5 images                             %.2f" % timed(graphed(lambda: multi([(0, 6), (6, 11), (11, 16)]))))
 print("  three chains 6 + 5 + 5 images, alternating tables          %.2f" % timed(graphed(lambda: multi([(0, 6), (6, 11), (11, 16)], 0, True))))
 print("  four quarter-batch chains, alternating tables              %.2f" % timed(graphed(lambda: multi([(0, 4), (4, 8), (8, 12), (12, 16)], 0, True))))
+
+
+def epilogue_chain(parts, kind):
+    """Two chains whose every link has the same epilogue: 'relu', 'mask', 'res0' or 'res2' (+res0 +res1); a tensor
+    and a weight image per layer as in a training step."""
+    cur = torch.cuda.current_stream()
+    for k, rng in enumerate(parts):
+        st = streams[k]
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            for i in range(LAYERS):
+                kw = {"relu": True} if kind == "relu" else {"mask": acts[(i + 3) % LAYERS]} if kind == "mask" else \
+                     {"res0": acts[(i + 3) % LAYERS]} if kind == "res0" else \
+                     {"res0": acts[(i + 3) % LAYERS], "res1": acts[(i + 7) % LAYERS]}
+                K.conv3x3(acts[i], wpks[i], C, bias=b, out=acts[i + 1], images=rng, strips=2 if k else True,
+                          plain_stores=kind != "relu", **kw)
+    for k in range(len(parts)):
+        cur.wait_stream(streams[k])
+
+
+for kind in ("relu", "mask", "res0", "res2"):
+    print("  two chains, every link with epilogue %-5s                 %.2f" % (kind, timed(graphed(lambda: epilogue_chain(HALVES, kind)))))
