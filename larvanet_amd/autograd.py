@@ -523,6 +523,9 @@ class StepScope:
     # the exits then write their L1 gradient during the FORWARD pass, in the same sweep over
     # (output, truth) that computes the loss.  None = unknown, the exits do it in backward.
     seed_grad = None
+    # The caller reads the loss before backward has run (the plugin's early-loss capture): MeanTermsFn then finishes
+    # it at once instead of leaving it to the last reduction launch of backward.
+    early_loss = False
 
     @classmethod
     def padded_input(cls, shape, device):
@@ -539,8 +542,9 @@ class StepScope:
         return buf
 
     def __init__(self, side_streams=False, defer_wgrad=True, split_flush=False, joint_input_grads=True,
-                 seed_grad=None, dual_chain=False, lazy_chain_joins=(False, False)):
+                 seed_grad=None, dual_chain=False, lazy_chain_joins=(False, False), early_loss=False):
         self.seed_grad_value = seed_grad
+        self.early_loss_value = bool(early_loss)
         self.dual_chain = dual_chain
         self.lazy_chain_joins = lazy_chain_joins
         self.side_streams = side_streams
@@ -561,6 +565,7 @@ class StepScope:
         DualChain.lazy_fwd, DualChain.lazy_bwd = (bool(v) and DualChain.enabled for v in self.lazy_chain_joins)
         StepScope.depth += 1
         StepScope.seed_grad = self.seed_grad_value
+        StepScope.early_loss = self.early_loss_value
         return self
 
     def __exit__(self, exc_type, *exc):
@@ -578,6 +583,7 @@ class StepScope:
         finally:
             StepScope.depth -= 1
             StepScope.seed_grad = None
+            StepScope.early_loss = False
             DeferredWgrad._pending = {}
             SideStreams.active = False
             DualChain.enabled = DualChain.lazy_fwd = DualChain.lazy_bwd = False
@@ -987,7 +993,8 @@ class MeanTermsFn(torch.autograd.Function):
         ctx.meta = meta
         ctx.shapes = [tuple(t.shape) for t in tensors]
         ts, scales = [t.contiguous() for t in tensors], [m[0] for m in meta]
-        if len(ts) <= 8 and DeferredWgrad.active and StepScope.depth > 0 and DeferredWgrad.pending_loss is None:
+        if (len(ts) <= 8 and DeferredWgrad.active and StepScope.depth > 0 and not StepScope.early_loss
+                and DeferredWgrad.pending_loss is None):
             # inside the plugin's step nobody reads the value before the step ends (backward is seeded with 1):
             # the finishing block rides on the weight-gradient reduction launch at the end of backward
             out = torch.empty((), device=ts[0].device, dtype=torch.float32)

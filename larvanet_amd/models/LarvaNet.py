@@ -241,6 +241,9 @@ class LarvaNet(BaseModel):
         super().__init__()
         self.volume_per_step = 0
         self.sync_loss = True
+        # sync_loss with a captured step: forward and backward are two graphs and the loss leaves for the host
+        # between them, so `return loss.item()` (models/LarvaNet.py:139) waits for the forward only
+        self.early_loss = os.environ.get("LARVA_EARLY_LOSS", "1") != "0"
         self.use_hip_graph = os.environ.get("LARVA_HIP_GRAPH", "1") != "0"
         self.hip_graph_fell_back = None   # reason, if a capture failed and the step went eager
         # Exits on a side stream: measured neutral-to-negative on MI355X at batch 16 (same-box A/B:
@@ -415,9 +418,12 @@ class LarvaNet(BaseModel):
     # hipGraph path: one step issues ~330 short kernels; launched one by one from Python the GPU
     # idles between them, so forward + backward are captured once per batch shape and replayed.
     def _graph_key(self, input_tensor, truth_tensor):
-        return (tuple(input_tensor.shape), tuple(truth_tensor.shape), str(input_tensor.device))
+        return (tuple(input_tensor.shape), tuple(truth_tensor.shape), str(input_tensor.device), self._early_loss_capture())
 
-    def _scope(self):
+    def _early_loss_capture(self):
+        return bool(self.sync_loss and self.early_loss)
+
+    def _scope(self, early_loss=False):
         # seed_grad: _forward_backward seeds loss.backward() with _grad_one and nothing scales the loss
         # chains are joined only after the body loop (forward) / at the end of backward when nothing
         # else reads a chain tensor in between: batched exits after the bodies; and in backward one
@@ -428,7 +434,8 @@ class LarvaNet(BaseModel):
         return StepScope(side_streams=self.use_side_streams, defer_wgrad=self.defer_wgrad,
                          split_flush=self._split_backward(), joint_input_grads=self.joint_input_grads,
                          seed_grad=1.0 if self.l1_grad_in_forward else None,
-                         dual_chain=self.dual_chain and not self.use_side_streams, lazy_chain_joins=(lazy_fwd, lazy_bwd))
+                         dual_chain=self.dual_chain and not self.use_side_streams, lazy_chain_joins=(lazy_fwd, lazy_bwd),
+                         early_loss=early_loss)
 
     def _single_consumer_features(self):
         """Is every body output read by its exit and the next body only (V2's tail reads them too)?"""
@@ -471,11 +478,36 @@ class LarvaNet(BaseModel):
         torch.cuda.current_stream().wait_stream(side)
         self._zero_grad()
         graph = torch.cuda.CUDAGraph()
+        self._graph_back = None
         # thread_local: a process-group watchdog thread must not abort the capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            with self._scope() as scope:
-                loss, out = self._exit_losses(self._static_in, self._static_truth)
-                loss.backward(self._grad_one(loss))
+        if not self._early_loss_capture():
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                with self._scope() as scope:
+                    loss, out = self._exit_losses(self._static_in, self._static_truth)
+                    loss.backward(self._grad_one(loss))
+        else:
+            # forward | backward as two graphs over one memory pool: the loss is complete when the first one ends
+            scope = self._scope(early_loss=True)
+            back = torch.cuda.CUDAGraph()
+            scope.__enter__()
+            left = False
+            try:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    loss, out = self._exit_losses(self._static_in, self._static_truth)
+                    DualChain.join()
+                with torch.cuda.graph(back, pool=graph.pool(), capture_error_mode="thread_local"):
+                    loss.backward(self._grad_one(loss))
+                    left = True
+                    scope.__exit__(None, None, None)   # joins the chains, issues the queued weight gradients
+            finally:
+                if not left:
+                    scope.__exit__(RuntimeError, None, None)
+            self._graph_back = back
+            if getattr(self, "_loss_host", None) is None:
+                self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
+                self._loss_stream = torch.cuda.Stream()
+                self._loss_done = torch.cuda.Event()
+                self._fwd_done = torch.cuda.Event()
         self._note_early(scope)
         self._graph_late = None
         if DeferredWgrad._late:  # second half of a split backward: its own graph, same memory pool
@@ -531,6 +563,15 @@ class LarvaNet(BaseModel):
             if truth_tensor.data_ptr() != self._static_truth.data_ptr():
                 self._static_truth.copy_(truth_tensor)
             self._graph.replay()  # gradients are overwritten in place: no zero_grad needed
+            if self._graph_back is not None:
+                # the loss goes to pinned host memory on a stream of its own while backward runs
+                self._fwd_done.record()
+                with torch.cuda.stream(self._loss_stream):
+                    self._loss_stream.wait_event(self._fwd_done)
+                    self._loss_host.copy_(self._graph_loss, non_blocking=True)
+                    self._loss_done.record()
+                self._loss_in_flight = True
+                self._graph_back.replay()
             self._late = self._graph_late.replay if self._graph_late is not None else None
             return self._graph_loss, self._graph_out
         from ..autograd import DeferredWgrad
@@ -625,7 +666,12 @@ class LarvaNet(BaseModel):
         # sync_loss=False hands back a 0-d device tensor instead so the host can run ahead (a copy:
         # the captured step's own loss tensor is overwritten by the next replay)
         if self.sync_loss:
+            if getattr(self, "_loss_in_flight", False):   # (early-loss capture: see _forward_backward)
+                self._loss_in_flight = False
+                self._loss_done.synchronize()
+                return self._loss_host.item()
             return loss.item()
+        self._loss_in_flight = False
         return loss_copy if loss_copy is not None else loss.detach().clone()
 
     def _write_summary(self, summary, loss, input_tensor, out, truth_tensor):
