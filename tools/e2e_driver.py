@@ -18,9 +18,13 @@ for flags, label in ((["--async_loss"], "async loss"), ([], "loss.item() every s
                 "--num_modules=4", "--num_blocks=4,4,4,4", "--synthetic_images=32", "--synthetic_lr_size=96",
                 "--data_seed=1", "--log_freq=100000"] + flags
         train_larva.main(argv + ["--max_steps=60"])       # warm-up: capture, allocator
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        train_larva.main(argv + ["--max_steps=%d" % steps])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    print("DRIVER LOOP, %s: %.3f ms per step incl. model construction (%d steps)" % (label, dt / steps * 1e3, steps))
+        times = []
+        for n in (steps // 4, steps):                       # two run lengths: the slope is the loop itself
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            train_larva.main(argv + ["--max_steps=%d" % n])
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    per_step = (times[1] - times[0]) / (steps - steps // 4)
+    print("DRIVER LOOP, %s: %.3f ms per step (slope between %d and %d steps; %.3f ms incl. model construction and capture)"
+          % (label, per_step * 1e3, steps // 4, steps, times[1] / steps * 1e3), flush=True)
