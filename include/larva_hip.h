@@ -213,6 +213,14 @@ int larva_l1_partial(const float* a, const float* b, long long numel, float* par
                      void* stream);
 int larva_loss_from_partials(const float* const* terms, const int* count, const float* scale, int n,
                              float divisor, float* out, void* stream);
+/* `return loss.item()` (models/LarvaNet.py:139) without waiting for the rest of the step: larva_host_cell_alloc
+ * hands out one float of coherent, device-mapped pinned host memory (NaN on return); the _to_host variant stores the
+ * loss there as well (system-scope release store) and the host polls the cell instead of synchronising.
+ * host_cell may be NULL (= larva_loss_from_partials). */
+int larva_loss_from_partials_to_host(const float* const* terms, const int* count, const float* scale, int n,
+                                     float divisor, float* out, float* host_cell, void* stream);
+int larva_host_cell_alloc(float** cell);
+int larva_host_cell_free(float* cell);
 /* larva_l1_partial and larva_l1_bwd_unshuffle4 in one pass over (a, b), for a gradient value known
  * on the host (training seeds loss.backward() with 1): grad [N][16C][H][W] = sign(a - b) * gvalue *
  * gscale / numel, a, b [N][C][4H][4W]; same partial sums and gradient values as the two calls. */

@@ -523,8 +523,9 @@ class StepScope:
     # the exits then write their L1 gradient during the FORWARD pass, in the same sweep over
     # (output, truth) that computes the loss.  None = unknown, the exits do it in backward.
     seed_grad = None
-    # The caller reads the loss before backward has run (the plugin's early-loss capture): MeanTermsFn then finishes
-    # it at once instead of leaving it to the last reduction launch of backward.
+    # The caller reads the loss before backward has run (the plugin's early-loss captures): MeanTermsFn then finishes
+    # it at once instead of leaving it to the last reduction launch of backward -- True, or the kernels.HostCell
+    # the finishing launch stores the value into as well.
     early_loss = False
 
     @classmethod
@@ -544,7 +545,7 @@ class StepScope:
     def __init__(self, side_streams=False, defer_wgrad=True, split_flush=False, joint_input_grads=True,
                  seed_grad=None, dual_chain=False, lazy_chain_joins=(False, False), early_loss=False):
         self.seed_grad_value = seed_grad
-        self.early_loss_value = bool(early_loss)
+        self.early_loss_value = early_loss or False
         self.dual_chain = dual_chain
         self.lazy_chain_joins = lazy_chain_joins
         self.side_streams = side_streams
@@ -1000,11 +1001,12 @@ class MeanTermsFn(torch.autograd.Function):
             out = torch.empty((), device=ts[0].device, dtype=torch.float32)
             DeferredWgrad.pending_loss = (ts, scales, float(len(ts)), out)
             return out
+        cell = StepScope.early_loss if isinstance(StepScope.early_loss, K.HostCell) else None
         if len(ts) <= 8:
-            return K.loss_from_partials(ts, scales, float(len(ts)))
+            return K.loss_from_partials(ts, scales, float(len(ts)), host_cell=cell)
         # more terms than one launch takes: sums of groups of 8 first, then their mean
         groups = [K.loss_from_partials(ts[i:i + 8], scales[i:i + 8], 1.0) for i in range(0, len(ts), 8)]
-        return K.loss_from_partials(groups, [1.0] * len(groups), float(len(ts)))
+        return K.loss_from_partials(groups, [1.0] * len(groups), float(len(ts)), host_cell=cell)
 
     @staticmethod
     def backward(ctx, g):

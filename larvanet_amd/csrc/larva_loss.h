@@ -15,8 +15,10 @@ struct TermList {
   int n;
 };
 
-// Call with all 256 threads of a block.
-__device__ __forceinline__ void loss_terms_block(const TermList& l, float divisor, float* __restrict__ out) {
+// Call with all 256 threads of a block.  host_cell (may be null): a float in coherent pinned host memory that
+// receives the value too -- the host polls it instead of synchronising with the stream (larva_host_cell_alloc).
+__device__ __forceinline__ void loss_terms_block(const TermList& l, float divisor, float* __restrict__ out,
+                                                 float* __restrict__ host_cell = nullptr) {
   __shared__ float ws[4];
   float total = 0.f;
   for (int i = 0; i < l.n; ++i) {
@@ -29,7 +31,13 @@ __device__ __forceinline__ void loss_terms_block(const TermList& l, float diviso
     __syncthreads();
     total += ((ws[0] + ws[1]) + (ws[2] + ws[3])) * l.scale[i];
   }
-  if (threadIdx.x == 0) out[0] = total / divisor;
+  if (threadIdx.x == 0) {
+    const float v = total / divisor;
+    out[0] = v;
+    if (host_cell) {
+      __hip_atomic_store(host_cell, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 }  // namespace larva

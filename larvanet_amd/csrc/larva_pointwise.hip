@@ -309,8 +309,9 @@ __global__ __launch_bounds__(256) void l1_partial_grad_batch_kernel(L1Jobs jobs,
 // its block count, scale_i = 1 / numel), or of ready scalars (count 1, scale 1).  Each term is
 // reduced exactly like l1_finish_kernel does, the terms are added in index order: bit-identical
 // to l1_finish + sum_scalars, in one launch instead of n + 1.
-__global__ __launch_bounds__(256) void loss_from_partials_kernel(TermList l, float divisor, float* __restrict__ out) {
-  loss_terms_block(l, divisor, out);
+__global__ __launch_bounds__(256) void loss_from_partials_kernel(TermList l, float divisor, float* __restrict__ out,
+                                                                 float* __restrict__ host_cell) {
+  loss_terms_block(l, divisor, out, host_cell);
 }
 
 // out[0] = (t0 + t1 + ... ) / divisor over up to 8 device scalars, added in index order.
@@ -594,9 +595,10 @@ int larva_l1_partial_grad_batch(const float* const* a, const float* b, int n, fl
   return (int)hipGetLastError();
 }
 
-// out[0] = ( sum_i scale[i] * (sum of count[i] floats at terms[i]) ) / divisor, n <= 8 terms.
-int larva_loss_from_partials(const float* const* terms, const int* count, const float* scale, int n,
-                             float divisor, float* out, void* stream) {
+// out[0] = ( sum_i scale[i] * (sum of count[i] floats at terms[i]) ) / divisor, n <= 8 terms; host_cell (may be
+// NULL, else from larva_host_cell_alloc) receives the same float with a system-scope release store.
+int larva_loss_from_partials_to_host(const float* const* terms, const int* count, const float* scale, int n,
+                                     float divisor, float* out, float* host_cell, void* stream) {
   if (!terms || !count || !scale || n < 1 || n > 8 || !out) return (int)hipErrorInvalidValue;
   TermList l{};
   for (int i = 0; i < n; ++i) {
@@ -606,9 +608,29 @@ int larva_loss_from_partials(const float* const* terms, const int* count, const 
     l.scale[i] = scale[i];
   }
   l.n = n;
-  hipLaunchKernelGGL(loss_from_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, l, divisor, out);
+  hipLaunchKernelGGL(loss_from_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, l, divisor, out, host_cell);
   return (int)hipGetLastError();
 }
+
+int larva_loss_from_partials(const float* const* terms, const int* count, const float* scale, int n,
+                             float divisor, float* out, void* stream) {
+  return larva_loss_from_partials_to_host(terms, count, scale, n, divisor, out, nullptr, stream);
+}
+
+// One float (in a 64-byte line of its own) of coherent, device-mapped pinned host memory: a kernel stores into it
+// with system scope, the host reads it without synchronising with any stream (`return loss.item()`,
+// models/LarvaNet.py:139, while the rest of the step still runs).  *cell holds NaN on return.
+int larva_host_cell_alloc(float** cell) {
+  if (!cell) return (int)hipErrorInvalidValue;
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, 64, hipHostMallocCoherent | hipHostMallocMapped);
+  if (e != hipSuccess) return (int)e;
+  *cell = static_cast<float*>(p);
+  (*cell)[0] = __builtin_nanf("");
+  return 0;
+}
+
+int larva_host_cell_free(float* cell) { return cell ? (int)hipHostFree(cell) : 0; }
 
 // L1 backward written in the pixel-unshuffled layout: a, b [N][C][4H][4W] -> ga [N][16C][H][W],
 // ga = sign(a - b) * (gout[0] * gscale) / numel (gscale: e.g. the 1/M of the mean over exits).

@@ -92,6 +92,10 @@ SIGNATURES = {
     "larva_l1_partial_grad_batch": (ctypes.c_int, [_c_pp, _c_float_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, _c_pp,
                                                    _c_int_p, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_void_p]),
+    "larva_loss_from_partials_to_host": (ctypes.c_int, [_c_pp, _c_int_p, _c_float_p, ctypes.c_int, ctypes.c_float,
+                                                        _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "larva_host_cell_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "larva_host_cell_free": (ctypes.c_int, [_c_float_p]),
     "larva_loss_from_partials": (ctypes.c_int, [_c_pp, _c_int_p, _c_float_p, ctypes.c_int, ctypes.c_float,
                                                 _c_float_p, ctypes.c_void_p]),
     "larva_sum_scalars": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_void_p]),

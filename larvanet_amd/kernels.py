@@ -581,8 +581,35 @@ def l1_partial_grad_batch(outs, truth, gvalue, gscale):
     return [p[:nb] for p in parts], 1.0 / float(truth.numel()), grads
 
 
-def loss_from_partials(terms, scales, divisor):
-    """( sum_i scales[i] * terms[i].sum() ) / divisor as a 0-d tensor, one launch, fixed order."""
+class HostCell:
+    """One float of coherent pinned host memory a kernel can store into (larva_host_cell_alloc): the host reads it
+    without synchronising with a stream.  NaN means "nothing stored since reset()"."""
+
+    def __init__(self):
+        p = ctypes.c_void_p()
+        hip_lib.check(hip_lib.load().larva_host_cell_alloc(ctypes.byref(p)), "larva_host_cell_alloc")
+        self.ptr = int(p.value)
+        self._cell = ctypes.c_float.from_address(self.ptr)
+
+    def reset(self):
+        self._cell.value = float("nan")
+
+    @property
+    def value(self):
+        return self._cell.value
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", 0), 0
+        if ptr:
+            try:
+                hip_lib.load().larva_host_cell_free(ptr)
+            except Exception:   # interpreter shutdown
+                pass
+
+
+def loss_from_partials(terms, scales, divisor, host_cell=None):
+    """( sum_i scales[i] * terms[i].sum() ) / divisor as a 0-d tensor, one launch, fixed order; host_cell
+    (HostCell) receives the value too."""
     lib = hip_lib.load()
     if not 1 <= len(terms) <= 8:
         raise RuntimeError("larvanet_amd: 1..8 loss terms")
@@ -595,8 +622,10 @@ def loss_from_partials(terms, scales, divisor):
         counts.append(max(1, int(t.numel())))
     out = torch.empty((), device=terms[0].device, dtype=torch.float32)
     sc = (ctypes.c_float * len(terms))(*[float(v) for v in scales])
-    hip_lib.check(lib.larva_loss_from_partials(hip_lib.ptr_array(ptrs), hip_lib.int_array(counts), sc, len(terms),
-                                               float(divisor), out.data_ptr(), _stream()), "larva_loss_from_partials")
+    hip_lib.check(lib.larva_loss_from_partials_to_host(hip_lib.ptr_array(ptrs), hip_lib.int_array(counts), sc, len(terms),
+                                                       float(divisor), out.data_ptr(),
+                                                       host_cell.ptr if host_cell is not None else None, _stream()),
+                  "larva_loss_from_partials_to_host")
     return out
 
 

@@ -12,6 +12,7 @@ Reference call sites are cited as models/LarvaNet.py:<line> (reference tree).
 import argparse
 import copy
 import os
+import time
 
 import numpy as np
 import torch
@@ -241,9 +242,11 @@ class LarvaNet(BaseModel):
         super().__init__()
         self.volume_per_step = 0
         self.sync_loss = True
-        # sync_loss with a captured step: forward and backward are two graphs and the loss leaves for the host
-        # between them, so `return loss.item()` (models/LarvaNet.py:139) waits for the forward only
-        self.early_loss = os.environ.get("LARVA_EARLY_LOSS", "1") != "0"
+        # sync_loss with a captured step: `return loss.item()` (models/LarvaNet.py:139) waits for the forward only.
+        # "poll": one graph; the launch that finishes the loss right after the exits also stores it into a float of
+        # coherent pinned host memory (kernels.HostCell), which the host polls.  "split": forward | backward as two graphs, the copy goes out
+        # between them on a side stream and the host waits for its event.  False: the host waits for the whole step.
+        self.early_loss = {"0": False, "split": "split"}.get(os.environ.get("LARVA_EARLY_LOSS", "poll"), "poll")
         self.use_hip_graph = os.environ.get("LARVA_HIP_GRAPH", "1") != "0"
         self.hip_graph_fell_back = None   # reason, if a capture failed and the step went eager
         # Exits on a side stream: measured neutral-to-negative on MI355X at batch 16 (same-box A/B:
@@ -421,7 +424,9 @@ class LarvaNet(BaseModel):
         return (tuple(input_tensor.shape), tuple(truth_tensor.shape), str(input_tensor.device), self._early_loss_capture())
 
     def _early_loss_capture(self):
-        return bool(self.sync_loss and self.early_loss)
+        if not (self.sync_loss and self.early_loss):
+            return False
+        return "split" if self.early_loss == "split" else "poll"
 
     def _scope(self, early_loss=False):
         # seed_grad: _forward_backward seeds loss.backward() with _grad_one and nothing scales the loss
@@ -480,9 +485,17 @@ class LarvaNet(BaseModel):
         graph = torch.cuda.CUDAGraph()
         self._graph_back = None
         # thread_local: a process-group watchdog thread must not abort the capture
-        if not self._early_loss_capture():
+        mode = self._early_loss_capture()
+        if mode == "split" and getattr(self, "_loss_host", None) is None:
+            self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
+            self._loss_stream = torch.cuda.Stream()
+            self._loss_done = torch.cuda.Event()
+            self._fwd_done = torch.cuda.Event()
+        if mode == "poll" and getattr(self, "_loss_cell", None) is None:
+            self._loss_cell = K.HostCell()
+        if mode != "split":
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                with self._scope() as scope:
+                with self._scope(early_loss=self._loss_cell if mode else False) as scope:
                     loss, out = self._exit_losses(self._static_in, self._static_truth)
                     loss.backward(self._grad_one(loss))
         else:
@@ -503,11 +516,7 @@ class LarvaNet(BaseModel):
                 if not left:
                     scope.__exit__(RuntimeError, None, None)
             self._graph_back = back
-            if getattr(self, "_loss_host", None) is None:
-                self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
-                self._loss_stream = torch.cuda.Stream()
-                self._loss_done = torch.cuda.Event()
-                self._fwd_done = torch.cuda.Event()
+        self._graph_polls = mode == "poll"
         self._note_early(scope)
         self._graph_late = None
         if DeferredWgrad._late:  # second half of a split backward: its own graph, same memory pool
@@ -562,6 +571,9 @@ class LarvaNet(BaseModel):
                 self._static_in.copy_(input_tensor)
             if truth_tensor.data_ptr() != self._static_truth.data_ptr():
                 self._static_truth.copy_(truth_tensor)
+            if self._graph_polls:
+                self._loss_cell.reset()   # NaN = "not there yet"
+                self._loss_in_flight = "poll"
             self._graph.replay()  # gradients are overwritten in place: no zero_grad needed
             if self._graph_back is not None:
                 # the loss goes to pinned host memory on a stream of its own while backward runs
@@ -570,7 +582,7 @@ class LarvaNet(BaseModel):
                     self._loss_stream.wait_event(self._fwd_done)
                     self._loss_host.copy_(self._graph_loss, non_blocking=True)
                     self._loss_done.record()
-                self._loss_in_flight = True
+                self._loss_in_flight = "event"
                 self._graph_back.replay()
             self._late = self._graph_late.replay if self._graph_late is not None else None
             return self._graph_loss, self._graph_out
@@ -666,13 +678,30 @@ class LarvaNet(BaseModel):
         # sync_loss=False hands back a 0-d device tensor instead so the host can run ahead (a copy:
         # the captured step's own loss tensor is overwritten by the next replay)
         if self.sync_loss:
-            if getattr(self, "_loss_in_flight", False):   # (early-loss capture: see _forward_backward)
-                self._loss_in_flight = False
+            how, self._loss_in_flight = getattr(self, "_loss_in_flight", False), False
+            if how == "event":   # (early-loss captures: see _forward_backward)
                 self._loss_done.synchronize()
                 return self._loss_host.item()
+            if how == "poll":
+                return self._poll_loss()
             return loss.item()
         self._loss_in_flight = False
         return loss_copy if loss_copy is not None else loss.detach().clone()
+
+    def _poll_loss(self):
+        """The step's loss as soon as the launch that finishes it has stored it into the host cell (NaN = not yet).
+        A loss that IS NaN shows after one full synchronisation; from then on every step waits that way."""
+        cell = self._loss_cell
+        if not getattr(self, "_loss_is_nan", False):
+            deadline = time.perf_counter() + 5.0
+            while time.perf_counter() < deadline:
+                v = cell.value
+                if v == v:
+                    return v
+        torch.cuda.current_stream().synchronize()
+        v = cell.value
+        self._loss_is_nan = v != v
+        return v
 
     def _write_summary(self, summary, loss, input_tensor, out, truth_tensor):
         summary.add_scalar("loss", loss, self.global_step)

@@ -395,19 +395,20 @@ def test_forward_and_train_step_shape_fuzz_against_the_cpu_restatement(hip_devic
 @pytest.mark.parametrize("name,flags", [("LarvaNet", ["--num_modules=3", "--num_blocks=2,1,2"]),
                                         ("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,2"])])
 def test_early_loss_capture_trains_exactly_like_the_single_graph(hip_device, name, flags):
-    """`return loss.item()` (models/LarvaNet.py:139) with a captured step: forward | backward as two graphs with the
-    loss handed to pinned host memory in between (the host waits for the forward only) must return the same floats
-    and leave the same weights as one graph with the loss read at the end, and as the device-tensor return."""
+    """`return loss.item()` (models/LarvaNet.py:139) with a captured step, the host waiting for the forward only --
+    "poll": the launch that finishes the loss stores it into coherent pinned host memory, which the host polls;
+    "split": forward | backward as two graphs, the loss copied out between them -- must return the same floats and
+    leave the same weights as one graph with the loss read at the end, and as the device-tensor return."""
     g = torch.Generator().manual_seed(19)
     xs = [(torch.rand(4, 3, 12, 16, generator=g) * 255).to(hip_device) for _ in range(5)]
     ts = [(torch.rand(4, 3, 48, 64, generator=g) * 255).to(hip_device) for _ in range(5)]
     args = types.SimpleNamespace(train_path="/tmp")
     results = []
-    for early, sync in ((True, True), (False, True), (True, False)):
+    for early, sync in (("poll", True), ("split", True), (False, True), ("poll", False)):
         m = _model(name, flags, training=True, seed=5)
         m.early_loss, m.sync_loss = early, sync
         losses = [m.train_step_larva(args, FakeValLoader(7), x, t) for x, t in zip(xs, ts)]
-        assert (m._graph_back is not None) == (early and sync)
+        assert (m._graph_back is not None) == (early == "split" and sync) and m._graph_polls == (early == "poll" and sync)
         if sync:
             assert all(isinstance(v, float) for v in losses)
         else:
