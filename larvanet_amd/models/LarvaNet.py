@@ -243,9 +243,10 @@ class LarvaNet(BaseModel):
         self.volume_per_step = 0
         self.sync_loss = True
         # sync_loss with a captured step: `return loss.item()` (models/LarvaNet.py:139) waits for the forward only.
-        # "poll": one graph; the launch that finishes the loss right after the exits also stores it into a float of
-        # coherent pinned host memory (kernels.HostCell), which the host polls.  "split": forward | backward as two graphs, the copy goes out
-        # between them on a side stream and the host waits for its event.  False: the host waits for the whole step.
+        # "poll": one graph; the launch that finishes the loss right after the exits also stores it into a float
+        # of coherent pinned host memory (kernels.HostCell), which the host polls.  "split": forward | backward
+        # as two graphs, the loss is copied out between them on a side stream and the host waits for that event.
+        # False: the host waits for the whole step.
         self.early_loss = {"0": False, "split": "split"}.get(os.environ.get("LARVA_EARLY_LOSS", "poll"), "poll")
         self.use_hip_graph = os.environ.get("LARVA_HIP_GRAPH", "1") != "0"
         self.hip_graph_fell_back = None   # reason, if a capture failed and the step went eager
