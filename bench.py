@@ -260,6 +260,23 @@ def time_dominant_kernel(dev, iters=50):
     return k_mean, k_min, float(np.mean(pair))
 
 
+def strip_launch_alone_ms(dev, c, iters=50):
+    """(mean, min) ms of one half-batch strip-tile conv+ReLU launch running alone (kernel-attached events)."""
+    import torch
+    from larvanet_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(BATCH, c, PATCH, PATCH, generator=g) * 20).to(dev)
+    w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.zeros(c, device=dev)
+    fwd, _ = K.pack_weights(w)
+    out = torch.empty_like(x)
+    try:
+        K.conv3x3_relu_strips_timed(x, fwd, c, b, out, 5, images=(0, BATCH // 2))
+        return K.conv3x3_relu_strips_timed(x, fwd, c, b, out, iters, images=(0, BATCH // 2))
+    except RuntimeError:
+        return None
+
+
 def roofline_block(dev, c=CH, full=True, dual=False):
     """fp32-MFMA roofline of the fused conv3x3+ReLU layer at 16 x c x 48 x 48.  dual=False: one
     chain of whole-batch launches (3 x 48 tiles, conv3x3_mfma_kernel).  dual=True: the layer as the
@@ -280,6 +297,13 @@ def roofline_block(dev, c=CH, full=True, dual=False):
     if c == CH:
         blk["traffic_source"] = HBM_TRAFFIC_SOURCE
     if dual:
+        alone = strip_launch_alone_ms(dev, c)
+        if alone is not None:
+            blk["launch_alone_ms"] = alone[0]
+            blk["launch_alone_is"] = ("mean duration of ONE half-batch strip launch running alone, kernel-attached HIP events over "
+                                      "50 launches (min %.5f): the figure rocprofv3 --stats reports per dispatch of this kernel "
+                                      "(profiles/r02_c_bench_final_kernel_stats.csv), NOT half of avg_ms -- two such launches "
+                                      "overlap in the step" % alone[1])
         blk.update({
             "kernel": "conv3x3_mfma_strip_kernel<%d, 1> (fused conv3x3+bias+ReLU, 5x16 / 4x16 pixel tiles), two concurrent " % c +
                       "half-batch launches (8x%dx48x48 each) = one 16x%dx48x48 fp32 layer" % (c, c),

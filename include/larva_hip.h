@@ -137,6 +137,13 @@ int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src,
                             const float* bias, const float* res0, const float* res1, const float* mask,
                             const float* base, float* out, int N, int cout, int H, int W, int relu,
                             int mode, void* stream, int iters, float* mean_ms, float* min_ms);
+/* The same for a strip-tile launch (larva_conv3x3_fwd_strips below; same arguments): what a profiler reports for
+ * one half-batch launch running alone, beside bench.py's time per layer with two of them running concurrently. */
+int larva_conv3x3_fwd_strips_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                                   const float* bias, const float* res0, const float* res1, const float* mask,
+                                   const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                                   int relu, int mode, const unsigned* tile_tab, int tiles_per_image,
+                                   int plain_stores, void* stream, int iters, float* mean_ms, float* min_ms);
 
 /* ---- weight / bias gradient ---------------------------------------------------------------
  * Replaces autograd's conv weight/bias gradient for the call sites above (loss.backward(),

@@ -1149,7 +1149,7 @@ static hipError_t launch_batch(const ConvBatch& b, int njobs, int epi, hipStream
 }
 
 template <int COUT, int EPI>
-static hipError_t launch_strip_e(const ConvArgs& a, hipStream_t stream) {
+static hipError_t launch_strip_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_strip_kernel<COUT, EPI>),
@@ -1157,20 +1157,24 @@ static hipError_t launch_strip_e(const ConvArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_mfma_strip_kernel<COUT, EPI>), dim3(a.nwg), dim3(320), kStripLdsBytes<COUT>, stream, a);
+  if (tm)
+    hipExtLaunchKernelGGL((conv3x3_mfma_strip_kernel<COUT, EPI>), dim3(a.nwg), dim3(320), kStripLdsBytes<COUT>, stream,
+                          tm->start, tm->stop, 0, a);
+  else
+    hipLaunchKernelGGL((conv3x3_mfma_strip_kernel<COUT, EPI>), dim3(a.nwg), dim3(320), kStripLdsBytes<COUT>, stream, a);
   return hipGetLastError();
 }
 
 template <int COUT>
-static hipError_t launch_strip(const ConvArgs& a, int epi, hipStream_t stream) {
+static hipError_t launch_strip(const ConvArgs& a, int epi, hipStream_t stream, const LaunchTiming* tm = nullptr) {
   switch (epi) {
-    case kEpiPlain: return launch_strip_e<COUT, kEpiPlain>(a, stream);
-    case kEpiRelu: return launch_strip_e<COUT, kEpiRelu>(a, stream);
-    case kEpiMask: return launch_strip_e<COUT, kEpiMask>(a, stream);
-    case kEpiRes1: return launch_strip_e<COUT, kEpiRes1>(a, stream);
-    case kEpiRes2: return launch_strip_e<COUT, kEpiRes2>(a, stream);
-    case kEpiShuffle: return launch_strip_e<COUT, kEpiShuffle>(a, stream);
-    case kEpiShuffleBase: return launch_strip_e<COUT, kEpiShuffleBase>(a, stream);
+    case kEpiPlain: return launch_strip_e<COUT, kEpiPlain>(a, stream, tm);
+    case kEpiRelu: return launch_strip_e<COUT, kEpiRelu>(a, stream, tm);
+    case kEpiMask: return launch_strip_e<COUT, kEpiMask>(a, stream, tm);
+    case kEpiRes1: return launch_strip_e<COUT, kEpiRes1>(a, stream, tm);
+    case kEpiRes2: return launch_strip_e<COUT, kEpiRes2>(a, stream, tm);
+    case kEpiShuffle: return launch_strip_e<COUT, kEpiShuffle>(a, stream, tm);
+    case kEpiShuffleBase: return launch_strip_e<COUT, kEpiShuffleBase>(a, stream, tm);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1464,11 +1468,11 @@ int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap) {
 // hipErrorNotSupported.  Results are bit-identical to
 // larva_conv3x3_fwd_pitched: every output's K loop runs in the same order, only the assignment of
 // pixels to workgroups differs.
-int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                             const float* bias, const float* res0, const float* res1, const float* mask,
-                             const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                             int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
-                             void* stream) {
+static int strips_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                           const float* bias, const float* res0, const float* res1, const float* mask,
+                           const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                           int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
+                           void* stream, const LaunchTiming* tm) {
   if (cout != 48 && cout != 32) return (int)hipErrorNotSupported;
   if (!tile_tab || tiles_per_image < 1) return (int)hipErrorInvalidValue;
   ConvArgs a;
@@ -1487,9 +1491,18 @@ int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src
   a.magic_ty = div_magic(1);
   a.nwg = N * tiles_per_image;
 #if !LARVA_DIAG_ONLY48
-  if (cout == 32) return (int)launch_strip<32>(a, epi, (hipStream_t)stream);
+  if (cout == 32) return (int)launch_strip<32>(a, epi, (hipStream_t)stream, tm);
 #endif
-  return (int)launch_strip<48>(a, epi, (hipStream_t)stream);
+  return (int)launch_strip<48>(a, epi, (hipStream_t)stream, tm);
+}
+
+int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                             const float* bias, const float* res0, const float* res1, const float* mask,
+                             const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                             int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
+                             void* stream) {
+  return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu, mode,
+                         tile_tab, tiles_per_image, plain_stores, stream, nullptr);
 }
 
 #if LARVA_DIAG & 32
@@ -1500,10 +1513,9 @@ int larva_diag_set_stamps(unsigned long long* buf) {
 
 // Measurement only (synchronises; not capturable): runs the same launch `iters` times with
 // kernel-attached events and returns the mean and minimum kernel duration in milliseconds.
-int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                            const float* bias, const float* res0, const float* res1, const float* mask,
-                            const float* base, float* out, int N, int cout, int H, int W, int relu,
-                            int mode, void* stream, int iters, float* mean_ms, float* min_ms) {
+extern "C++" {
+template <typename Launch>
+static int timed_launches(int iters, float* mean_ms, float* min_ms, Launch launch) {
   if (iters < 1 || !mean_ms || !min_ms) return (int)hipErrorInvalidValue;
   LaunchTiming tm{};
   hipError_t e = hipEventCreate(&tm.start);
@@ -1514,8 +1526,7 @@ int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src,
   float best = 1e30f;
   int rc = 0;
   for (int i = 0; i < iters && rc == 0; ++i) {
-    rc = conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, 0, relu,
-                       mode, stream, &tm);
+    rc = launch(&tm);
     if (rc) break;
     e = hipEventSynchronize(tm.stop);
     float ms = 0.f;
@@ -1529,6 +1540,30 @@ int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src,
   *mean_ms = (float)(sum / iters);
   *min_ms = best;
   return rc;
+}
+}  // extern "C++"
+
+int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                            const float* bias, const float* res0, const float* res1, const float* mask,
+                            const float* base, float* out, int N, int cout, int H, int W, int relu,
+                            int mode, void* stream, int iters, float* mean_ms, float* min_ms) {
+  return timed_launches(iters, mean_ms, min_ms, [&](const LaunchTiming* tm) {
+    return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, 0, relu, mode,
+                         stream, tm);
+  });
+}
+
+// The same for a strip-tile launch (larva_conv3x3_fwd_strips): what a profiler reports for ONE half-batch launch
+// running alone, beside bench.py's time per layer with two such launches running concurrently.
+int larva_conv3x3_fwd_strips_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                                   const float* bias, const float* res0, const float* res1, const float* mask,
+                                   const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                                   int relu, int mode, const unsigned* tile_tab, int tiles_per_image,
+                                   int plain_stores, void* stream, int iters, float* mean_ms, float* min_ms) {
+  return timed_launches(iters, mean_ms, min_ms, [&](const LaunchTiming* tm) {
+    return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu,
+                           mode, tile_tab, tiles_per_image, plain_stores, stream, tm);
+  });
 }
 
 }  // extern "C"

@@ -48,6 +48,12 @@ SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_conv3x3_fwd_strips_timed": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
+                                                      _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                      ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "larva_conv3x3_fwd_timed": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
                                                _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
