@@ -850,6 +850,26 @@ def test_adamw_host_scalars_match_torch_and_unaligned_views(hip_device):
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-8)
 
 
+def test_timed_launches_compute_what_the_plain_launches_compute(hip_device):
+    """larva_conv3x3_fwd_timed / larva_conv3x3_fwd_strips_timed (bench.py's kernel-attached event timings): the
+    same output as the untimed launch, and durations that are positive and ordered (min <= mean)."""
+    from larvanet_amd import kernels as K
+    gen = torch.Generator().manual_seed(8)
+    x = (torch.randn(4, 48, 48, 48, generator=gen) * 20).to(hip_device)
+    w = (torch.randn(48, 48, 3, 3, generator=gen) * 0.05).to(hip_device)
+    b = torch.randn(48, generator=gen).to(hip_device)
+    fwd, _ = K.pack_weights(w)
+    ref = K.conv3x3(x, fwd, 48, bias=b, relu=True)
+    out = torch.full_like(ref, float("nan"))
+    mean, best = K.conv3x3_relu_timed(x, fwd, 48, b, out, 3)
+    assert torch.equal(out, ref) and 0 < best <= mean < 1.0
+    out = torch.full_like(ref, float("nan"))
+    mean, best = K.conv3x3_relu_strips_timed(x, fwd, 48, b, out, 3, images=(1, 3))
+    torch.cuda.synchronize()
+    assert torch.equal(out[1:3], ref[1:3]) and bool(torch.isnan(out[0]).all()) and bool(torch.isnan(out[3]).all())
+    assert 0 < best <= mean < 1.0
+
+
 def test_strip_tiles_seeded_shape_fuzz(hip_device):
     """24 seeded random problems (batch, height, width % 4 == 0, 1-2 sources, every mode-0 epilogue and the
     pixel-shuffle ones, image sub-ranges, both table phases and store policies): strip tiles == 3 x 48 tiles
