@@ -168,6 +168,16 @@ int larva_wgrad_flat_max_splits(int njobs, int nwg, int tiles_per_layer);
 int larva_conv3x3_wgrad_partial_flat(const float* const* dy, const float* const* x, float* const* partial,
                                      int njobs, int nwg, int N, int cout, int cin, int H, int W,
                                      int* splits_out, void* stream);
+/* The same grid with LarvaHead's weight gradient (models/LarvaNet.py:227-233; a (48, 16) layer: head_x16 = the
+ * head's input zero-padded to 16 channels, [N][16][H][W]) as the tail of the sequence: the last workgroups take
+ * its tiles (priced at 0.7 of a 48 -> 48 tile) instead of a launch of its own behind this one.  head_partial holds
+ * larva_wgrad_flat_head_splits(njobs, nwg, tiles per layer) images of larva_wgrad_partial_floats(48, 16, 1)
+ * floats; *head_splits_out = the images written (what larva_wgrad_reduce needs for that layer). */
+int larva_wgrad_flat_head_splits(int njobs, int nwg, int tiles_per_layer);
+int larva_conv3x3_wgrad_partial_flat_head(const float* const* dy, const float* const* x, float* const* partial,
+                                          int njobs, const float* head_dy, const float* head_x16, float* head_partial,
+                                          int nwg, int N, int H, int W, int* splits_out, int* head_splits_out,
+                                          void* stream);
 
 /* The two phases separately: partial images for njobs (<= 64) layers, and the fixed-order
  * reduction of up to 64 layers' partial images (each with its own split count and kernel shape)

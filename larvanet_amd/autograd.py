@@ -433,6 +433,7 @@ class DeferredWgrad:
 
     # one grid over all layers of a launch (kernels.conv3x3_wgrad_partial_flat) where the shape allows
     flat = os.environ.get("LARVA_WGRAD_FLAT", "1") != "0"
+    head_in_flat = os.environ.get("LARVA_WGRAD_HEAD_IN_FLAT", "1") != "0"
 
     @classmethod
     def _launches(cls, split=False):
@@ -468,10 +469,26 @@ class DeferredWgrad:
         """The partial-image launches one after the other, then ONE fixed-order reduction over all
         of them (each layer with its own split count and kernel shape)."""
         reduce_jobs = []
-        for cout, cin, chunk in launches:
-            res = K.conv3x3_wgrad_partial_flat(chunk, cout, cin, _WGRAD_WORKGROUPS) if DeferredWgrad.flat else None
+        # the 3 -> 48 head (one (48, 16) layer on its padded input) rides at the end of the last flat (48, 48) grid
+        # of the same image geometry instead of having a launch of its own
+        head = host = None
+        if DeferredWgrad.flat and DeferredWgrad.head_in_flat:
+            heads = [l for l in launches if (l[0], l[1]) == (48, 16) and len(l[2]) == 1]
+            hosts = [l for l in launches if (l[0], l[1]) == (48, 48)]
+            if len(heads) == 1 and hosts and hosts[-1][2][0]["dy"].shape == heads[0][2][0]["dy"].shape:
+                head, host = heads[0], hosts[-1]
+        todo = [l for l in launches if l is not head]
+        for launch in todo:   # (may grow: a head whose host grid did not apply goes its own way at the end)
+            cout, cin, chunk = launch
+            extra = head[2][0] if launch is host else None
+            res = K.conv3x3_wgrad_partial_flat(chunk, cout, cin, _WGRAD_WORKGROUPS, head=extra) if DeferredWgrad.flat else None
+            if res is None and extra is not None:
+                todo.append(head)
+                extra = None
             if res is not None:
                 reduce_jobs += [dict(j, partial=p, splits=s, cout=cout, cin=cin) for j, p, s in zip(chunk, *res)]
+                if extra is not None:
+                    reduce_jobs.append(dict(extra, partial=res[0][-1], splits=res[1][-1], cout=48, cin=16))
                 continue
             parts, used = K.conv3x3_wgrad_partial(chunk, cout, cin, _splits(len(chunk)))
             reduce_jobs += [dict(j, partial=p, splits=used, cout=cout, cin=cin) for j, p in zip(chunk, parts)]

@@ -62,7 +62,23 @@ struct WgradBatch {
   // (its partial image for that layer is image 0, the next workgroup's image 1, ...)
   int njobs;
   short first_wg[kMaxJobs];
+  // optional tail of the flat sequence: ONE (COUT, 16) layer -- the 3 -> 48 head on its zero-padded input --
+  // on the register-staged role.  It enters the sequence as head_units pseudo-tiles (its tiles priced in units of
+  // a 48 -> 48 tile, see flat_head_units); pseudo-tile p covers its tiles [p T / head_units, (p + 1) T / head_units).
+  WgradJob head;
+  int head_units;       // 0: no head job
+  int head_first_wg;    // the first workgroup whose share reaches into the head
 };
+
+// A (48, 16) tile on the register-staged role against a (48, 48) tile on the pipelined one: a third of the MFMAs,
+// but two workgroup barriers and an exposed LDS write per tile -- measured 0.58 of the time (same-box builds with
+// the price at 0.4 / 0.5 / 0.6 / 0.7: step 1.835 / 1.709 / 1.636 / 1.634 ms: under-priced, the workgroups whose whole
+// share is head tiles finish last and set the launch's duration).  Priced at 0.7: finishing early costs a fraction
+// of one CU.
+#ifndef LARVA_HEAD_COST10
+#define LARVA_HEAD_COST10 7
+#endif
+__host__ __device__ constexpr int flat_head_units(int tiles) { return (tiles * LARVA_HEAD_COST10 + 9) / 10; }
 
 template <int COUT, int CIN>
 struct WgCfg {
@@ -209,8 +225,8 @@ __device__ __forceinline__ void wg_read(const float* a_base, const float* b_base
 }
 
 template <int COUT, int CIN, bool VEC, int B0, int NBW>
-__device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, float* smem,
-                                        int split, int splits, int tid, bool bias_wave) {
+__device__ __forceinline__ void wg_role_range(const WgradBatch& b, const WgradJob& j, float* smem,
+                                              int t_begin, int t_end, float* part, int tid, bool bias_wave) {
   using C = WgCfg<COUT, CIN>;
   const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   float* s_dy = smem;
@@ -226,10 +242,6 @@ __device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, 
   float bsum[C::CT];
 #pragma unroll
   for (int c = 0; c < C::CT; ++c) bsum[c] = 0.f;
-
-  const int total = b.N * b.tiles_x * b.tiles_y;
-  const int t_begin = (int)(((long long)total * split) / splits);
-  const int t_end = (int)(((long long)total * (split + 1)) / splits);
 
   // The next tile's global loads ride in registers under the MFMA block of the current one;
   // at 64x64 channels accumulators + staging exceed the register file, so that shape loads
@@ -265,7 +277,6 @@ __device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, 
 
   // Partial image: [b][ct][lane][4] = the accumulator registers as they stand (1 KiB per tile
   // per store instruction, fully coalesced).  acc[c][k][r] = dW[co = 16c + 4lq + r][ci = 16*cit + lr][tap].
-  float* part = j.partial + (size_t)split * C::PARTIAL_FLOATS;
 #pragma unroll
   for (int c = 0; c < C::CT; ++c)
 #pragma unroll
@@ -280,6 +291,16 @@ __device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, 
       if (lane < 16) part[C::NB * C::CT * 256 + c * 16 + lane] = v;
     }
   }
+}
+
+template <int COUT, int CIN, bool VEC, int B0, int NBW>
+__device__ __forceinline__ void wg_role(const WgradBatch& b, const WgradJob& j, float* smem,
+                                        int split, int splits, int tid, bool bias_wave) {
+  const int total = b.N * b.tiles_x * b.tiles_y;
+  const int t_begin = (int)(((long long)total * split) / splits);
+  const int t_end = (int)(((long long)total * (split + 1)) / splits);
+  wg_role_range<COUT, CIN, VEC, B0, NBW>(b, j, smem, t_begin, t_end,
+                                         j.partial + (size_t)split * WgCfg<COUT, CIN>::PARTIAL_FLOATS, tid, bias_wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -686,9 +707,12 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_flat_kernel(WgradBatch b
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w = blockIdx.x, nwg = gridDim.x;
   const int total = b.N * b.tiles_x * b.tiles_y;
-  const long long G = (long long)total * b.njobs;
-  int g = __builtin_amdgcn_readfirstlane((int)((G * w) / nwg));
-  const int g_end = __builtin_amdgcn_readfirstlane((int)((G * (w + 1)) / nwg));
+  const long long T = (long long)total * b.njobs;       // tiles of the njobs layers; the head's pseudo-tiles follow
+  const long long G = T + b.head_units;
+  const int g0 = __builtin_amdgcn_readfirstlane((int)((G * w) / nwg));
+  const int g1 = __builtin_amdgcn_readfirstlane((int)((G * (w + 1)) / nwg));
+  int g = g0;
+  const int g_end = min(g1, (int)T);
   int jb = __builtin_amdgcn_readfirstlane(g / total);
   while (g < g_end) {   // one pass per layer this workgroup touches (bounded: at most njobs)
     const int base = jb * total;
@@ -699,6 +723,20 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_flat_kernel(WgradBatch b
     __syncthreads();    // every wave is done with the tile buffers before the next layer restages them
     g = seg_end;
     ++jb;
+  }
+  if (b.head_units > 0 && g1 > (int)T) {   // (wave-uniform: whole workgroup)
+    using H = WgCfg<COUT, 16>;
+    const long long p0 = max(g0, (int)T) - T, p1 = g1 - T;
+    const int h_begin = __builtin_amdgcn_readfirstlane((int)(p0 * total / b.head_units));
+    const int h_end = __builtin_amdgcn_readfirstlane((int)(p1 * total / b.head_units));
+    float* part = b.head.partial + (size_t)(w - b.head_first_wg) * H::PARTIAL_FLOATS;
+    // (ci group, tap) operands of the 16-channel job dealt to the 4 waves: NB = 9 -> 3, 2, 2, 2
+    constexpr int NB = H::NB;
+    constexpr int W0 = (NB + 3) / 4, W1 = (NB + 2) / 4, W2 = (NB + 1) / 4, W3 = NB / 4;
+    if (wave == 0) wg_role_range<COUT, 16, true, 0, W0>(b, b.head, smem, h_begin, h_end, part, tid, true);
+    else if (wave == 1) wg_role_range<COUT, 16, true, W0, W1>(b, b.head, smem, h_begin, h_end, part, tid, false);
+    else if (wave == 2) wg_role_range<COUT, 16, true, W0 + W1, W2>(b, b.head, smem, h_begin, h_end, part, tid, false);
+    else wg_role_range<COUT, 16, true, W0 + W1 + W2, W3>(b, b.head, smem, h_begin, h_end, part, tid, false);
   }
 }
 
@@ -936,26 +974,37 @@ int larva_wgrad_flat_max_splits(int njobs, int nwg, int tiles_per_layer) {
   return (int)((tiles_per_layer + smallest - 1) / smallest + 1);        // shares that can touch one layer
 }
 
-int larva_conv3x3_wgrad_partial_flat(const float* const* dy, const float* const* x, float* const* partial,
-                                     int njobs, int nwg, int N, int cout, int cin, int H, int W,
-                                     int* splits_out, void* stream) {
+int larva_wgrad_flat_head_splits(int njobs, int nwg, int tiles_per_layer);
+
+static int wgrad_flat_impl(const float* const* dy, const float* const* x, float* const* partial, int njobs,
+                           const float* head_dy, const float* head_x16, float* head_partial, int nwg, int N, int cout,
+                           int cin, int H, int W, int* splits_out, int* head_splits_out, void* stream) {
   if (njobs < 1 || njobs > kMaxJobs || nwg < 1 || nwg > 32767 || N <= 0 || H <= 0 || W <= 0 || !splits_out)
     return (int)hipErrorInvalidValue;
   if (cout != 48 || cin != 48 || W % 4 || !wgrad_use_pipe()) return (int)hipErrorNotSupported;
+  const bool head = head_dy || head_x16 || head_partial;
+  if (head && (!head_dy || !head_x16 || !head_partial || !head_splits_out)) return (int)hipErrorInvalidValue;
   WgradBatch b{};
   for (int i = 0; i < njobs; ++i) {
     if (!dy[i] || !x[i] || !partial[i]) return (int)hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(dy[i]) | reinterpret_cast<uintptr_t>(x[i])) & 15) return (int)hipErrorNotSupported;
     b.job[i] = WgradJob{dy[i], x[i], partial[i]};
   }
+  if (head && ((reinterpret_cast<uintptr_t>(head_dy) | reinterpret_cast<uintptr_t>(head_x16)) & 15))
+    return (int)hipErrorNotSupported;
   b.N = N; b.H = H; b.W = W;
   b.tiles_x = (W + kTileCols - 1) / kTileCols;
   b.tiles_y = (H + kTileRows - 1) / kTileRows;
   b.vec_ok = 1;
   b.njobs = njobs;
   const long long total = (long long)N * b.tiles_x * b.tiles_y;
-  const long long G = total * njobs;
-  if (G >= (1ll << 31)) return (int)hipErrorInvalidValue;
+  const long long T = total * njobs;
+  if (T >= (1ll << 30)) return (int)hipErrorInvalidValue;
+  if (head) {
+    b.head = WgradJob{head_dy, head_x16, head_partial};
+    b.head_units = flat_head_units((int)total);
+  }
+  const long long G = T + b.head_units;
   if (nwg > G) nwg = (int)G;
   // the same integer arithmetic as the kernel: share of workgroup w = [G w / nwg, G (w+1) / nwg)
   int w = 0;
@@ -968,7 +1017,44 @@ int larva_conv3x3_wgrad_partial_flat(const float* const* dy, const float* const*
     splits_out[i] = last - w + 1;
     if (splits_out[i] > larva_wgrad_flat_max_splits(njobs, nwg, (int)total)) return (int)hipErrorInvalidValue;
   }
+  if (head) {
+    while ((G * (w + 1)) / nwg <= T) ++w;                     // first workgroup whose share reaches beyond T
+    b.head_first_wg = w;
+    *head_splits_out = nwg - w;
+    if (*head_splits_out > larva_wgrad_flat_head_splits(njobs, nwg, (int)total)) return (int)hipErrorInvalidValue;
+  }
   return (int)launch_wgrad_flat<48, 48>(b, nwg, (hipStream_t)stream);
+}
+
+int larva_conv3x3_wgrad_partial_flat(const float* const* dy, const float* const* x, float* const* partial,
+                                     int njobs, int nwg, int N, int cout, int cin, int H, int W,
+                                     int* splits_out, void* stream) {
+  return wgrad_flat_impl(dy, x, partial, njobs, nullptr, nullptr, nullptr, nwg, N, cout, cin, H, W, splits_out, nullptr,
+                         stream);
+}
+
+// The same grid with ONE (48, 16) layer behind the njobs (48, 48) layers -- LarvaHead's weight gradient
+// (models/LarvaNet.py:227-233; head_x16 = its input zero-padded to 16 channels, [N][16][H][W]) -- on the
+// register-staged role: the workgroups at the end of the sequence take its tiles instead of a launch of its own
+// (256 workgroups x 1 tile, 256 partial images) running after this one.  head_partial must hold
+// larva_wgrad_flat_head_splits(njobs, nwg, tiles) images of larva_wgrad_partial_floats(48, 16, 1) floats;
+// *head_splits_out = the images written.
+int larva_wgrad_flat_head_splits(int njobs, int nwg, int tiles_per_layer) {
+  if (njobs < 1 || nwg < 1 || tiles_per_layer < 1) return 0;
+  const long long T = (long long)njobs * tiles_per_layer, G = T + flat_head_units(tiles_per_layer);
+  if (nwg > G) nwg = (int)G;
+  int w = 0;
+  while ((G * (w + 1)) / nwg <= T) ++w;
+  return nwg - w;
+}
+
+int larva_conv3x3_wgrad_partial_flat_head(const float* const* dy, const float* const* x, float* const* partial,
+                                          int njobs, const float* head_dy, const float* head_x16, float* head_partial,
+                                          int nwg, int N, int H, int W, int* splits_out, int* head_splits_out,
+                                          void* stream) {
+  if (!head_dy || !head_x16 || !head_partial || !head_splits_out) return (int)hipErrorInvalidValue;
+  return wgrad_flat_impl(dy, x, partial, njobs, head_dy, head_x16, head_partial, nwg, N, 48, 48, H, W, splits_out,
+                         head_splits_out, stream);
 }
 
 // Floats of partial-image workspace one job needs for `splits` workgroups.

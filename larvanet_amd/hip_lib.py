@@ -66,6 +66,10 @@ SIGNATURES = {
     "larva_conv3x3_wgrad_partial": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    _c_int_p, ctypes.c_void_p]),
+    "larva_wgrad_flat_head_splits": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "larva_conv3x3_wgrad_partial_flat_head": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, ctypes.c_int, _c_float_p, _c_float_p,
+                                                             _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                             ctypes.c_int, _c_int_p, _c_int_p, ctypes.c_void_p]),
     "larva_wgrad_flat_max_splits": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "larva_conv3x3_wgrad_partial_flat": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

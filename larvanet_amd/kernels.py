@@ -413,9 +413,11 @@ def conv3x3_wgrad_partial(jobs, cout, cin, splits):
     return parts, int(used.value)
 
 
-def conv3x3_wgrad_partial_flat(jobs, cout, cin, nwg):
+def conv3x3_wgrad_partial_flat(jobs, cout, cin, nwg, head=None):
     """Phase 1 of ALL jobs (<= 64 dicts {dy, x}, 48 -> 48 channels) as one grid of `nwg` workgroups ->
-    (partial tensors, [partial images per job]) or None when the flat launch does not apply."""
+    (partial tensors, [partial images per job]) or None when the flat launch does not apply.  head: one more dict
+    {dy [N][48][H][W], x [N][16][H][W]} -- the 3 -> 48 head on its padded input -- whose tiles the last workgroups of
+    the same grid take; the result then ends with that job's partial tensor / image count."""
     lib = hip_lib.load()
     if not 1 <= len(jobs) <= 64 or (cout, cin) != (48, 48):
         return None
@@ -427,17 +429,32 @@ def conv3x3_wgrad_partial_flat(jobs, cout, cin, nwg):
     nfl = wgrad_partial_floats(cout, cin, cap)
     dys = [_chk(j["dy"], "dy", (N, cout, H, W)) for j in jobs]
     xs = [_chk(j["x"], "x", (N, cin, H, W)) for j in jobs]
-    parts = [torch.empty(nfl, device=jobs[0]["dy"].device, dtype=torch.float32) for _ in jobs]
+    dev = jobs[0]["dy"].device
+    parts = [torch.empty(nfl, device=dev, dtype=torch.float32) for _ in jobs]
     used = (ctypes.c_int * len(jobs))()
-    code = lib.larva_conv3x3_wgrad_partial_flat(
-        hip_lib.ptr_array(dys), hip_lib.ptr_array(xs), hip_lib.ptr_array([p.data_ptr() for p in parts]),
-        len(jobs), int(nwg), N, cout, cin, H, W, used, _stream())
+    if head is None:
+        code = lib.larva_conv3x3_wgrad_partial_flat(
+            hip_lib.ptr_array(dys), hip_lib.ptr_array(xs), hip_lib.ptr_array([p.data_ptr() for p in parts]),
+            len(jobs), int(nwg), N, cout, cin, H, W, used, _stream())
+    else:
+        hcap = int(lib.larva_wgrad_flat_head_splits(len(jobs), int(nwg), tiles))
+        hper = wgrad_partial_floats(48, 16, 1)
+        hpart = torch.empty(hper * hcap, device=dev, dtype=torch.float32)
+        hused = ctypes.c_int(0)
+        code = lib.larva_conv3x3_wgrad_partial_flat_head(
+            hip_lib.ptr_array(dys), hip_lib.ptr_array(xs), hip_lib.ptr_array([p.data_ptr() for p in parts]), len(jobs),
+            _chk(head["dy"], "head dy", (N, 48, H, W)), _chk(head["x"], "head x", (N, 16, H, W)), hpart.data_ptr(),
+            int(nwg), N, H, W, used, ctypes.byref(hused), _stream())
     if code == 801:
         return None
     hip_lib.check(code, "larva_conv3x3_wgrad_partial_flat")
     splits = [int(v) for v in used]
     per = wgrad_partial_floats(cout, cin, 1)
-    return [p[:per * s] for p, s in zip(parts, splits)], splits
+    out = [p[:per * s] for p, s in zip(parts, splits)]
+    if head is not None:
+        out.append(hpart[:hper * int(hused.value)])
+        splits.append(int(hused.value))
+    return out, splits
 
 
 def _loss_terms(terms, scales):

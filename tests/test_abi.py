@@ -57,3 +57,46 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(d, f)
+
+
+def test_flat_wgrad_partition_covers_every_tile_once_within_the_advertised_image_counts():
+    """The flat weight-gradient grid (larva_conv3x3_wgrad_partial_flat[_head]): workgroup w owns
+    [G w / nwg, G (w + 1) / nwg) of the sequence of njobs x tiles tiles followed by the head's pseudo-tiles.  Replayed
+    here in Python for seeded (njobs, nwg, tiles): every tile of every layer and of the head falls into exactly one
+    share, and the workgroups touching a layer / the head never exceed what the two host-side size helpers
+    (pure host code) tell the caller to allocate."""
+    import random
+    from larvanet_amd import hip_lib
+    lib = hip_lib.load()
+    rnd = random.Random(7)
+    cases = [(40, 256, 256), (8, 256, 256), (1, 3, 96), (5, 7, 6), (64, 1024, 30), (3, 64, 2)]
+    cases += [(rnd.randint(1, 64), rnd.randint(1, 600), rnd.randint(1, 400)) for _ in range(60)]
+    for njobs, nwg, tiles in cases:
+        for with_head in (False, True):
+            hu = (tiles * 7 + 9) // 10 if with_head else 0
+            T = njobs * tiles
+            G = T + hu
+            n = min(nwg, G)
+            owners = [[] for _ in range(njobs)]
+            covered = [0] * njobs
+            head_owner, head_cov = [], 0
+            for w in range(n):
+                g0, g1 = G * w // n, G * (w + 1) // n
+                g, g_end = g0, min(g1, T)
+                while g < g_end:
+                    jb = g // tiles
+                    seg_end = min(g_end, (jb + 1) * tiles)
+                    owners[jb].append(w)
+                    covered[jb] += seg_end - g
+                    g = seg_end
+                if hu and g1 > T:
+                    p0, p1 = max(g0, T) - T, g1 - T
+                    head_owner.append(w)
+                    head_cov += p1 * tiles // hu - p0 * tiles // hu
+            assert covered == [tiles] * njobs, (njobs, nwg, tiles, with_head)
+            cap = lib.larva_wgrad_flat_max_splits(njobs, nwg, tiles)
+            assert all(o == list(range(o[0], o[0] + len(o))) and len(o) <= cap for o in owners), (njobs, nwg, tiles)
+            if with_head:
+                assert head_cov == tiles and head_owner == list(range(head_owner[0], n)), (njobs, nwg, tiles)
+                assert len(head_owner) == lib.larva_wgrad_flat_head_splits(njobs, nwg, tiles), (njobs, nwg, tiles)
+

@@ -788,6 +788,53 @@ def test_flat_wgrad_grid_over_all_layers(hip_device, njobs, nwg, N, H, W):
     assert all(torch.equal(a, j["dw"]) for a, j in zip(first, jobs))
 
 
+@pytest.mark.parametrize("njobs,nwg,N,H,W", [(5, 7, 2, 9, 48), (1, 3, 2, 9, 48), (3, 64, 1, 6, 48), (8, 256, 16, 48, 48),
+                                              (2, 5, 3, 10, 52)])
+def test_flat_wgrad_grid_with_the_head_as_its_tail(hip_device, njobs, nwg, N, H, W):
+    """larva_conv3x3_wgrad_partial_flat_head: the 3 -> 48 head's weight gradient (a (48, 16) layer on the
+    zero-padded input) taken by the last workgroups of the flat grid -- every layer and the head against torch in
+    float64 (the head makes the sequence longer, so the 48 -> 48 layers' shares differ from the head-less grid's
+    and only the tolerance is asserted); run to run the same bits."""
+    from larvanet_amd import kernels as K
+    gen = torch.Generator().manual_seed(njobs * 1000 + nwg)
+    jobs = []
+    for _ in range(njobs):
+        jobs.append({"dy": (torch.randn(N, 48, H, W, generator=gen) * 1e-3).to(hip_device),
+                     "x": (torch.randn(N, 48, H, W, generator=gen) * 20).to(hip_device),
+                     "dw": torch.full((48, 48, 3, 3), float("nan"), device=hip_device),
+                     "db": torch.full((48,), float("nan"), device=hip_device)})
+    x3 = (torch.rand(N, 3, H, W, generator=gen) * 255).to(hip_device)
+    x16 = torch.zeros(N, 16, H, W, device=hip_device)
+    x16[:, :3] = x3
+    head = {"dy": (torch.randn(N, 48, H, W, generator=gen) * 1e-3).to(hip_device), "x": x16,
+            "dw": torch.full((48, 3, 3, 3), float("nan"), device=hip_device),
+            "db": torch.full((48,), float("nan"), device=hip_device), "cin_off": 0, "cin_valid": 3}
+
+    def run():
+        res = K.conv3x3_wgrad_partial_flat(jobs, 48, 48, nwg, head=head)
+        assert res is not None
+        parts, splits = res
+        rj = [dict(j, partial=p, splits=s, cout=48, cin=48) for j, p, s in zip(jobs, parts, splits)]
+        rj.append(dict(head, partial=parts[-1], splits=splits[-1], cout=48, cin=16))
+        K.wgrad_reduce(rj)
+        torch.cuda.synchronize()
+        return splits
+
+    splits = run()
+    assert len(splits) == njobs + 1 and splits[-1] >= 1
+    for j, cin_x in [(j, j["x"]) for j in jobs] + [(head, x3)]:
+        dw_ref = torch.nn.grad.conv2d_weight(cin_x.double().cpu(), tuple(j["dw"].shape), j["dy"].double().cpu(), padding=1)
+        db_ref = j["dy"].double().cpu().sum((0, 2, 3))
+        dw, db = j["dw"].cpu().double(), j["db"].cpu().double()
+        assert float((dw - dw_ref).abs().max()) <= 3e-5 * float(dw_ref.abs().max())
+        assert float((db - db_ref).abs().max()) <= 3e-5 * float(db_ref.abs().max()) + 1e-9
+    first = [j["dw"].clone() for j in jobs + [head]]
+    for j in jobs + [head]:
+        j["dw"].fill_(float("nan"))
+    run()
+    assert all(torch.equal(a, j["dw"]) for a, j in zip(first, jobs + [head]))
+
+
 def test_reduce_launch_carries_the_loss_and_adamw_launch_the_copy(hip_device):
     """larva_wgrad_reduce_with_loss == larva_wgrad_reduce + larva_loss_from_partials (same bits), and
     larva_adamw_step_host_copy == larva_adamw_step_host + a 4-byte copy."""
