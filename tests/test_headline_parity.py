@@ -109,6 +109,42 @@ def test_headline_train_step_matches_reference_fixture_f11(hip_device, golden, o
     np.testing.assert_allclose(m.get_lr(), g["lrs"][-1])
 
 
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_headline_train_steps_v2_against_the_oracle(hip_device, use_graph):
+    """LarvaNetV2 (models/LarvaNetV2.py:101-123, 314-365) at the same size -- M4B4, 16 x 3 x 48 x 48, so the merge
+    conv reads four 7 MB feature tensors as K = 192 and the tail is a fifth exit: three train_step_larva steps
+    against oracle/larva_torch.py (which F8 pins to the reference's V2) with the same initial weights: every loss,
+    every gradient element of the first step, the weights after the third AdamW step."""
+    from oracle import larva_torch as T
+    m = _model("LarvaNetV2", FLAGS, training=True, seed=3)
+    m.use_hip_graph = use_graph
+    m.volume_per_step = 48 * 48 * 16 * 3
+    sd = {k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()}
+    x, truth = _canonical_batch()
+    _, ref_grads = T.train_steps(dict(sd), x, truth, BLOCKS, steps=1, lr=m.get_lr(), v2=True)
+    ref_losses, _ = T.train_steps(sd, x, truth, BLOCKS, steps=3, lr=m.get_lr(), v2=True)   # (sd: the weights after 3 steps;
+    args = types.SimpleNamespace(train_path="/tmp")                                          #  V2's default lr is 1e-4)
+    xd, td = x.to(hip_device), truth.to(hip_device)
+    losses = []
+    for step in range(3):
+        losses.append(m.train_step_larva(args, FakeValLoader(7), xd, td, None))
+        if step == 0:
+            # 5e-4 of each tensor's largest element: the L1 gradient is sign(out - truth), and of the 8.8 M
+            # (output, truth) pairs of the five exits a handful lie closer together than the forward's own 1e-4
+            # error -- a flipped sign moves single weight-gradient elements by up to 3.5e-4 of the tensor's
+            # maximum (measured against a float64 run of the oracle as well: it is not summation order)
+            for k, p in m.model.named_parameters():
+                got, ref = p.grad.detach().cpu().numpy(), ref_grads[k].numpy()
+                assert float(np.abs(got - ref).max()) <= 5e-4 * max(float(np.abs(ref).max()), 1e-30), k
+    assert m.use_hip_graph == use_graph
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    # AdamW's first steps move a weight by lr * g / (|g| + eps): where |g| is of the order of eps = 1e-8 the move depends
+    # on g's last bits, so single elements may sit up to steps * lr apart; everything else within 2e-5
+    for k, v in m.model.state_dict().items():
+        d = np.abs(v.cpu().numpy() - sd[k].numpy())
+        assert float((d > 2e-5).mean()) < 1e-3 and float(d.max()) <= 3.1 * m.get_lr(), (k, float(d.max()), float((d > 2e-5).mean()))
+
+
 def test_headline_wgrad_launch_shape_32_layers_by_8_splits(hip_device):
     """The weight-gradient launch exactly as the step issues it (32 layers x 8 workgroups at
     16x48x48x48, pipelined kernel + fixed-order reduction) against torch's CPU conv2d_weight."""
