@@ -23,7 +23,9 @@ The JSON line also carries
                       launches per layer, timed live with events around a captured graph
   roofline_single_chain   the same layer as one whole-batch launch (round 1's dominant kernel)
   roofline_c32/_c64   the same kernel at 32 and 64 channels (BASELINE configs 2 and 5)
-  roofline_wgrad      the weight-gradient launch as the step issues it
+  roofline_wgrad      all weight gradients of the step (one flat grid over the 40 layers + the head, one
+                      reduction) priced on what the step pays (captured forward+backward with and without
+                      them); `isolated_loop`: the launch pair alone, back to back
   cpu_baseline        the same training step in the torch CPU restatement (oracle/, kind "port") on
                       the host cores of this box, bounded sample
   infer               inference-forward throughput (LarvaNetModule.forward) on the batch
@@ -328,9 +330,11 @@ def roofline_block(dev, c=CH, full=True, dual=False):
     return blk
 
 
-def wgrad_block(dev, jobs=32, iters=20):
-    """Second kernel of the step (28 % of it): the weight-gradient launch as the step issues it
-    (32 layers x 8 workgroups, partial images + fixed-order reduction), timed with an event pair."""
+def wgrad_block(dev, jobs=40, iters=10):
+    """Second kernel of the step (28 % of it): the weight-gradient launch as the step issues it since round 2 -- ONE
+    flat grid of 256 workgroups over the tiles of all 40 48 -> 48 layers (partial images) + the fixed-order
+    reduction -- replayed from a captured graph and timed with an event pair.  (The 3 -> 48 head, which the step
+    appends to the same grid, is not part of this block: its FLOPs are not in `flop_per_layer` either.)"""
     import torch
     from larvanet_amd import kernels as K
     g = torch.Generator().manual_seed(6)
@@ -338,27 +342,41 @@ def wgrad_block(dev, jobs=32, iters=20):
     xs = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 20).to(dev)
     js = [{"dy": dy + 0, "x": xs + 0, "dw": torch.empty(CH, CH, 3, 3, device=dev), "db": torch.empty(CH, device=dev)}
           for _ in range(jobs)]
-    parts = K.conv3x3_wgrad(js, CH, CH, 256 // jobs)
-    for j, p in zip(js, parts):
-        j["partial"] = p
-    for _ in range(5):  # the chip needs a few hundred microseconds of load to settle its clock
-        K.conv3x3_wgrad(js, CH, CH, 256 // jobs)
+
+    def pair():
+        res = K.conv3x3_wgrad_partial_flat(js, CH, CH, 256)
+        if res is None:   # (the flat grid does not apply: the per-layer launch)
+            K.conv3x3_wgrad(js[:32], CH, CH, 8)
+            return False
+        K.wgrad_reduce([dict(j, partial=p, splits=s, cout=CH, cin=CH) for j, p, s in zip(js, *res)])
+        return True
+
+    flat = pair()
+    nlayers = jobs if flat else 32
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        pair()
+    for _ in range(3):  # the chip needs a few hundred microseconds of load to settle its clock
+        graph.replay()
     torch.cuda.synchronize()
     runs = []
-    for _ in range(3):   # (launched from Python: a host hiccup would show up as GPU time; median of 3)
+    for _ in range(3):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(iters):
-            K.conv3x3_wgrad(js, CH, CH, 256 // jobs)
+            graph.replay()
         e.record()
         torch.cuda.synchronize()
         runs.append(s.elapsed_time(e) / iters)
     ms = sorted(runs)[1]
-    achieved = conv_flop(CH) * jobs / (ms * 1e-3) / 1e12
+    achieved = conv_flop(CH) * nlayers / (ms * 1e-3) / 1e12
+    kernel = ("wgrad3x3_pipe_flat_kernel<48, 48> (one grid of 256 workgroups over %d layers) + wgrad_reduce_kernel" % nlayers
+              if flat else "wgrad3x3_pipe_kernel<48, 48> + wgrad_reduce_kernel, 32 layers x 8 workgroups")
     return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "kernel": "wgrad3x3_pipe_kernel<48, 48> + wgrad_reduce_kernel, "
-            "%d layers x %d workgroups, 16x48x48x48 fp32" % (jobs, 256 // jobs), "ms_per_launch_pair": ms,
-            "flop_per_layer": conv_flop(CH)}
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "kernel": kernel + ", 16x48x48x48 fp32", "layers": nlayers,
+            "ms_per_launch_pair": ms, "flop_per_layer": conv_flop(CH),
+            "timing": "HIP event pair around %d replays of a captured graph of the launch pair, back to back (median of 3)" % iters}
 
 
 def wgrad_in_step(model, x, truth, reps=30):
@@ -690,9 +708,19 @@ def main():
     # runs as two half-batch chains, else the whole-batch launch
     line["roofline"] = dual if dual is not None else single
     line["roofline_single_chain"] = single
-    line["roofline_wgrad"] = wgrad_block(dev)
+    iso = wgrad_block(dev)
+    line["roofline_wgrad"] = iso
     if extras:
-        line["roofline_wgrad"]["in_step"] = wgrad_in_step(model, x, truth)
+        # priced, like `roofline`, on what the STEP pays: the captured forward+backward with and without its
+        # weight-gradient launches; the back-to-back loop of the launch pair alone (clock pulled down by
+        # sustained fp32-MFMA load, operands streamed cold from HBM every replay) stays beside it
+        ins = wgrad_in_step(model, x, truth)
+        line["roofline_wgrad"] = {
+            "bound": "mfma", "achieved": ins["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ins["frac"],
+            "kernel": "all weight-gradient launches of the step: " + iso["kernel"].replace(", 16x48x48x48 fp32", "") +
+                      " with the 3 -> 48 head's tiles as the tail of the grid, 16x48x48x48 fp32",
+            "ms_all_weight_gradients": ins["ms_all_weight_gradients"], "flop": ins["flop"], "layers": ins["layers"],
+            "timing": ins["what"], "in_step": ins, "isolated_loop": iso}
     line["infer"] = {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
                      "unit": "HR Mpixels/s"}
     if extras:
