@@ -66,6 +66,14 @@ HBM_TRAFFIC_SOURCE = ("profiles/r02_pmc_conv_strip_vs_wide.csv (rocprofv3 --pmc 
                       "`bench.py --roofline-only`, tools/pmc_conv.sh; a constant, not measured by this run)")
 
 
+# The weight-gradient kernel's HBM-side bytes per LAYER, from the committed PMC passes over a 32-layer launch
+# (profiles/r02_pmc_wgrad_pipe_traffic.csv: FETCH_SIZE 224 093 KB doubled, WRITE_SIZE 20 849 KB) and its reduction
+# (profiles/r02_pmc_reduce_traffic.csv: FETCH_SIZE 11 117 KB doubled, WRITE_SIZE 2 598 KB); constants, not measured here
+WGRAD_TRAFFIC_PER_LAYER = (2 * 224093 + 20849 + 2 * 11117 + 2598) * 1024 / 32
+WGRAD_TRAFFIC_SOURCE = ("profiles/r02_pmc_wgrad_pipe_traffic.csv + profiles/r02_pmc_reduce_traffic.csv (separate rocprofv3 --pmc "
+                        "FETCH_SIZE / WRITE_SIZE passes, tools/pmc_wgrad.sh, tools/pmc_reduce.sh; constants, not measured by this run)")
+
+
 def conv_flop(c):
     return 2 * 9 * c * c * BATCH * PATCH * PATCH         # 1.5288 GFLOP per 48->48 layer
 
@@ -376,6 +384,9 @@ def wgrad_block(dev, jobs=40, iters=10):
     return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "kernel": kernel + ", 16x48x48x48 fp32", "layers": nlayers,
             "ms_per_launch_pair": ms, "flop_per_layer": conv_flop(CH),
+            "traffic": WGRAD_TRAFFIC_PER_LAYER * nlayers, "traffic_source": WGRAD_TRAFFIC_SOURCE,
+            "traffic_is": "HBM-side bytes of the launch pair = per-layer figure x layers (dy + x read once, partial images written and read once)",
+            "algorithmic_bytes_per_layer": 2 * BATCH * CH * PATCH * PATCH * 4 + 4 * (9 * CH * CH + CH),
             "timing": "HIP event pair around %d replays of a captured graph of the launch pair, back to back (median of 3)" % iters}
 
 
@@ -720,6 +731,7 @@ def main():
             "kernel": "all weight-gradient launches of the step: " + iso["kernel"].replace(", 16x48x48x48 fp32", "") +
                       " with the 3 -> 48 head's tiles as the tail of the grid, 16x48x48x48 fp32",
             "ms_all_weight_gradients": ins["ms_all_weight_gradients"], "flop": ins["flop"], "layers": ins["layers"],
+            "traffic": iso.get("traffic"), "traffic_source": iso.get("traffic_source"),
             "timing": ins["what"], "in_step": ins, "isolated_loop": iso}
     line["infer"] = {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
                      "unit": "HR Mpixels/s"}
