@@ -231,9 +231,11 @@ int larva_l1_partial(const float* a, const float* b, long long numel, float* par
 int larva_loss_from_partials(const float* const* terms, const int* count, const float* scale, int n,
                              float divisor, float* out, void* stream);
 /* `return loss.item()` (models/LarvaNet.py:139) without waiting for the rest of the step: larva_host_cell_alloc
- * hands out one float of coherent, device-mapped pinned host memory (NaN on return); the _to_host variant stores the
- * loss there as well (system-scope release store) and the host polls the cell instead of synchronising.
- * host_cell may be NULL (= larva_loss_from_partials). */
+ * hands out 8 bytes {float value; uint32 sequence} of coherent, device-mapped pinned host memory (NaN, 0 on return);
+ * the _to_host variant stores the loss there as well, together with sequence + 1, as ONE system-scope 8-byte release
+ * store, and the host polls the cell instead of synchronising: it counts its launches and takes the value once the
+ * sequence number is its own count (a late store of an earlier launch cannot be mistaken for this one's).
+ * host_cell may be NULL (= larva_loss_from_partials).  larva_host_cell_free waits for the device before it frees. */
 int larva_loss_from_partials_to_host(const float* const* terms, const int* count, const float* scale, int n,
                                      float divisor, float* out, float* host_cell, void* stream);
 int larva_host_cell_alloc(float** cell);

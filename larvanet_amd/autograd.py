@@ -175,11 +175,20 @@ class DualChain:
 
     @classmethod
     def join(cls):
-        if cls._forked:
-            cur = torch.cuda.current_stream()
-            for k in range(2):
-                cur.wait_stream(cls._stream(k))
+        try:
+            if cls._forked:
+                cur = torch.cuda.current_stream()
+                for k in range(2):
+                    cur.wait_stream(cls._stream(k))
+        finally:
+            # (also when a wait raises -- a stream capture that died mid-chain: the next step must fork afresh)
             cls._forked = False
+            cls._keep.clear()
+
+    @classmethod
+    def reset(cls):
+        """Forget a fork without waiting (after a failed capture + a device synchronisation)."""
+        cls._forked = False
         cls._keep.clear()
 
     @classmethod
@@ -554,8 +563,9 @@ class StepScope:
         key = (tuple(shape), str(device))
         buf = cls._padded.get(key)
         if buf is None:
-            if len(cls._padded) > 8:
-                cls._padded.clear()
+            # Never evicted: captured graphs (the training step, up to four inference shapes per model) bake this
+            # buffer's address in, and a freed buffer's memory would be handed to somebody else.  Scoped shapes are
+            # the training batch shapes and the captured inference shapes -- a handful of N x 16 x H x W buffers.
             buf = cls._padded[key] = torch.zeros(shape, device=device, dtype=torch.float32)
         return buf
 
@@ -599,6 +609,7 @@ class StepScope:
             if exc_type is None and JointInputGrad._parked:
                 raise RuntimeError("larvanet_amd: an exit parked its input gradient but the next body never ran backward")
         finally:
+            DualChain.reset()
             StepScope.depth -= 1
             StepScope.seed_grad = None
             StepScope.early_loss = False

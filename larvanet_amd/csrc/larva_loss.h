@@ -15,11 +15,17 @@ struct TermList {
   int n;
 };
 
-// Call with all 256 threads of a block.  host_cell (may be null): a float in coherent pinned host memory that
-// receives the value too -- the host polls it instead of synchronising with the stream (larva_host_cell_alloc).
+// Call with all 256 threads of a block.  host_cell (may be null): a {float value, uint32 sequence} pair in coherent
+// pinned host memory that receives the value too -- the host polls it instead of synchronising with the stream
+// (larva_host_cell_alloc).  Every store bumps the sequence number and both words leave as ONE 8-byte store, so the
+// host can tell this launch's value from an earlier launch's (it counts its own launches).
 __device__ __forceinline__ void loss_terms_block(const TermList& l, float divisor, float* __restrict__ out,
                                                  float* __restrict__ host_cell = nullptr) {
   __shared__ float ws[4];
+  // (the sequence number comes over PCIe: asked for first, needed last)
+  unsigned long long seq = 0ull;
+  if (host_cell && threadIdx.x == 0)
+    seq = __hip_atomic_load(reinterpret_cast<unsigned long long*>(host_cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> 32;
   float total = 0.f;
   for (int i = 0; i < l.n; ++i) {
     float s = 0.f;
@@ -35,7 +41,9 @@ __device__ __forceinline__ void loss_terms_block(const TermList& l, float diviso
     const float v = total / divisor;
     out[0] = v;
     if (host_cell) {
-      __hip_atomic_store(host_cell, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_cell),
+                         ((seq + 1ull) << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

@@ -357,24 +357,29 @@ __global__ void pixel_unshuffle4_kernel(const float* __restrict__ in, float* __r
 // decoupled weight decay, bias-corrected moments, eps added after the sqrt).  `step_lr` holds
 // {step count as float, lr} on the device so that a captured graph can be replayed.
 // ---------------------------------------------------------------------------------------------
-struct AdamwCoef {   // per-step scalars of torch.optim.AdamW: step_size = lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), 1 - lr * wd
-  float step_size, inv_bc2_sqrt, decay;
+struct AdamwCoef {   // per-step scalars of torch.optim.AdamW: step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t), 1 - lr * wd
+  float step_size, bc2_sqrt, decay;
 };
 
 __device__ __forceinline__ AdamwCoef adamw_coef_device(float step, float lr, float beta1, float beta2, float wd) {
   const float bc1 = 1.f - powf(beta1, step);
   const float bc2 = 1.f - powf(beta2, step);
-  return AdamwCoef{lr / bc1, 1.f / sqrtf(bc2), 1.f - lr * wd};
+  return AdamwCoef{lr / bc1, sqrtf(bc2), 1.f - lr * wd};
 }
 
 // (Explicit roundings: the 16-byte walk and the element-wise walk must give the same bits whatever the compiler
 // would contract in each.)
 __device__ __forceinline__ void adamw_update(float& param, float& mi, float& vi, float grad, const AdamwCoef& c,
                                              float beta1, float beta2, float eps) {
-  mi = __fmaf_rn(__fsub_rn(grad, mi), 1.f - beta1, mi);  // lerp, as torch does
-  vi = __fmaf_rn(__fmul_rn(1.f - beta2, grad), grad, __fmul_rn(vi, beta2));
-  const float denom = __fmaf_rn(__fsqrt_rn(vi), c.inv_bc2_sqrt, eps);
-  param = __fmaf_rn(-c.step_size, __fdiv_rn(mi, denom), __fmul_rn(param, c.decay));
+  // torch.optim.AdamW's single-tensor step, operation by operation (each separately rounded where ATen's is):
+  //   param.mul_(1 - lr * wd); exp_avg.lerp_(grad, 1 - beta1)            [lerp: fma(weight, end - start, start)]
+  //   exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)        [self + (value * t1) * t2]
+  //   denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)       [a division, then the add]
+  //   param.addcdiv_(exp_avg, denom, value=-step_size)                    [self + (value * t1) / t2]
+  mi = __fmaf_rn(1.f - beta1, __fsub_rn(grad, mi), mi);
+  vi = __fadd_rn(__fmul_rn(vi, beta2), __fmul_rn(__fmul_rn(1.f - beta2, grad), grad));
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), c.bc2_sqrt), eps);
+  param = __fadd_rn(__fmul_rn(param, c.decay), __fdiv_rn(__fmul_rn(-c.step_size, mi), denom));
 }
 
 // step_lr != null: {step count as float, lr} live on the device (a captured graph can be replayed) and the
@@ -596,7 +601,8 @@ int larva_l1_partial_grad_batch(const float* const* a, const float* b, int n, fl
 }
 
 // out[0] = ( sum_i scale[i] * (sum of count[i] floats at terms[i]) ) / divisor, n <= 8 terms; host_cell (may be
-// NULL, else from larva_host_cell_alloc) receives the same float with a system-scope release store.
+// NULL, else from larva_host_cell_alloc) receives the same float and the next sequence number with one system-scope
+// 8-byte release store.
 int larva_loss_from_partials_to_host(const float* const* terms, const int* count, const float* scale, int n,
                                      float divisor, float* out, float* host_cell, void* stream) {
   if (!terms || !count || !scale || n < 1 || n > 8 || !out) return (int)hipErrorInvalidValue;
@@ -617,9 +623,11 @@ int larva_loss_from_partials(const float* const* terms, const int* count, const 
   return larva_loss_from_partials_to_host(terms, count, scale, n, divisor, out, nullptr, stream);
 }
 
-// One float (in a 64-byte line of its own) of coherent, device-mapped pinned host memory: a kernel stores into it
-// with system scope, the host reads it without synchronising with any stream (`return loss.item()`,
-// models/LarvaNet.py:139, while the rest of the step still runs).  *cell holds NaN on return.
+// One {float value, uint32 sequence} pair (in a 64-byte line of its own) of coherent, device-mapped pinned host
+// memory: a kernel stores into it with system scope (one 8-byte store: the value and the sequence number of the
+// store, which starts at 0 and grows by one per launch), the host reads it without synchronising with any stream
+// (`return loss.item()`, models/LarvaNet.py:139, while the rest of the step still runs).  On return the value is NaN
+// and the sequence number 0.
 int larva_host_cell_alloc(float** cell) {
   if (!cell) return (int)hipErrorInvalidValue;
   void* p = nullptr;
@@ -627,10 +635,16 @@ int larva_host_cell_alloc(float** cell) {
   if (e != hipSuccess) return (int)e;
   *cell = static_cast<float*>(p);
   (*cell)[0] = __builtin_nanf("");
+  reinterpret_cast<unsigned*>(p)[1] = 0u;
   return 0;
 }
 
-int larva_host_cell_free(float* cell) { return cell ? (int)hipHostFree(cell) : 0; }
+// Waits for the device first: a launch (or a captured graph's replay) that stores into the cell may be in flight.
+int larva_host_cell_free(float* cell) {
+  if (!cell) return 0;
+  (void)hipDeviceSynchronize();
+  return (int)hipHostFree(cell);
+}
 
 // L1 backward written in the pixel-unshuffled layout: a, b [N][C][4H][4W] -> ga [N][16C][H][W],
 // ga = sign(a - b) * (gout[0] * gscale) / numel (gscale: e.g. the 1/M of the mean over exits).
@@ -710,7 +724,7 @@ int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int
   if (!p || !g || !m || !v || n <= 0 || step < 1 || (copy_dst && !copy_src)) return (int)hipErrorInvalidValue;
   // the per-step scalars in double, like torch.optim.AdamW computes them on the host
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const AdamwCoef coef{(float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), (float)(1.0 - (double)lr * (double)weight_decay)};
+  const AdamwCoef coef{(float)((double)lr / bc1), (float)sqrt(bc2), (float)(1.0 - (double)lr * (double)weight_decay)};
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                      (const float*)nullptr, coef, beta1, beta2, eps, weight_decay, grad_scale, n, adamw_vec_ok(p, g, m, v),
                      copy_src, copy_dst);

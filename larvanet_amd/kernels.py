@@ -4,6 +4,7 @@ its grid assume (device, dtype, contiguity, shapes) before launching.
 """
 import ctypes
 import os
+import struct
 
 import torch
 
@@ -621,27 +622,41 @@ def l1_partial_grad_batch(outs, truth, gvalue, gscale):
 
 
 class HostCell:
-    """One float of coherent pinned host memory a kernel can store into (larva_host_cell_alloc): the host reads it
-    without synchronising with a stream.  NaN means "nothing stored since reset()"."""
+    """{float value, uint32 sequence} in coherent pinned host memory a kernel can store into (larva_host_cell_alloc):
+    the host reads it without synchronising with a stream.  Every store of a kernel bumps the sequence number; the
+    owner counts its launches (expect()) and take() returns a value only once the launch it waits for has stored."""
 
     def __init__(self):
         p = ctypes.c_void_p()
         hip_lib.check(hip_lib.load().larva_host_cell_alloc(ctypes.byref(p)), "larva_host_cell_alloc")
         self.ptr = int(p.value)
-        self._cell = ctypes.c_float.from_address(self.ptr)
+        self._cell = ctypes.c_uint64.from_address(self.ptr)
+        self.expected = 0
 
-    def reset(self):
-        self._cell.value = float("nan")
+    def expect(self):
+        """Call once per launch (or graph replay) that stores into the cell, before it is issued."""
+        self.expected = (self.expected + 1) & 0xFFFFFFFF
+
+    def take(self):
+        """The value of the launch announced last, or None while it has not stored yet."""
+        raw = self._cell.value            # one aligned 8-byte load: value and sequence number belong together
+        if (raw >> 32) != self.expected:
+            return None
+        return struct.unpack("<f", struct.pack("<I", raw & 0xFFFFFFFF))[0]
 
     @property
     def value(self):
-        return self._cell.value
+        return struct.unpack("<f", struct.pack("<I", self._cell.value & 0xFFFFFFFF))[0]
+
+    @property
+    def sequence(self):
+        return self._cell.value >> 32
 
     def __del__(self):
         ptr, self.ptr = getattr(self, "ptr", 0), 0
         if ptr:
             try:
-                hip_lib.load().larva_host_cell_free(ptr)
+                hip_lib.load().larva_host_cell_free(ptr)   # (synchronises with the device first)
             except Exception:   # interpreter shutdown
                 pass
 

@@ -244,7 +244,7 @@ class LarvaNet(BaseModel):
         self.sync_loss = True
         # sync_loss with a captured step: `return loss.item()` (models/LarvaNet.py:139) waits for the forward only.
         # "poll": one graph; the launch that finishes the loss right after the exits also stores it into a float
-        # of coherent pinned host memory (kernels.HostCell), which the host polls.  "split": forward | backward
+        # (+ a sequence number) of coherent pinned host memory (kernels.HostCell), which the host polls.  "split": forward | backward
         # as two graphs, the loss is copied out between them on a side stream and the host waits for that event.
         # False: the host waits for the whole step.
         self.early_loss = {"0": False, "split": "split"}.get(os.environ.get("LARVA_EARLY_LOSS", "poll"), "poll")
@@ -566,6 +566,7 @@ class LarvaNet(BaseModel):
                     self.use_hip_graph = False
                     self.hip_graph_fell_back = "%s: %s" % (type(e).__name__, e)
                     torch.cuda.synchronize()
+                    DualChain.reset()   # (a capture that died mid-chain must not leave the chains marked as forked)
                     return self._forward_backward(input_tensor, truth_tensor)
             # (a producer that filled input_buffers() in place hands the very same storage back)
             if input_tensor.data_ptr() != self._static_in.data_ptr():
@@ -573,7 +574,7 @@ class LarvaNet(BaseModel):
             if truth_tensor.data_ptr() != self._static_truth.data_ptr():
                 self._static_truth.copy_(truth_tensor)
             if self._graph_polls:
-                self._loss_cell.reset()   # NaN = "not there yet"
+                self._loss_cell.expect()   # this replay's store carries the next sequence number
                 self._loss_in_flight = "poll"
             self._graph.replay()  # gradients are overwritten in place: no zero_grad needed
             if self._graph_back is not None:
@@ -690,18 +691,28 @@ class LarvaNet(BaseModel):
         return loss_copy if loss_copy is not None else loss.detach().clone()
 
     def _poll_loss(self):
-        """The step's loss as soon as the launch that finishes it has stored it into the host cell (NaN = not yet).
-        A loss that IS NaN shows after one full synchronisation; from then on every step waits that way."""
+        """The step's loss as soon as the launch that finishes it has stored it into the host cell.  The store carries a
+        sequence number, so a late store of an earlier replay is never taken for this one's (and a loss that IS NaN is
+        just a value).  A short spin -- the loss is normally there within the forward's ~0.6 ms --, then the core is
+        yielded between looks; after 5 s the stream is synchronised (the launch must then have stored)."""
         cell = self._loss_cell
-        if not getattr(self, "_loss_is_nan", False):
-            deadline = time.perf_counter() + 5.0
-            while time.perf_counter() < deadline:
-                v = cell.value
-                if v == v:
-                    return v
+        t0 = time.perf_counter()
+        spins = 0
+        while True:
+            v = cell.take()
+            if v is not None:
+                return v
+            spins += 1
+            if spins > 2000:   # ~1 ms of looking without a break
+                dt = time.perf_counter() - t0
+                if dt > 5.0:
+                    break
+                time.sleep(0 if dt < 0.02 else 0.0005)
         torch.cuda.current_stream().synchronize()
-        v = cell.value
-        self._loss_is_nan = v != v
+        v = cell.take()
+        if v is None:
+            raise RuntimeError("larvanet_amd: the captured step finished without storing its loss "
+                               "(host cell at sequence %d, expected %d)" % (cell.sequence, cell.expected))
         return v
 
     def _write_summary(self, summary, loss, input_tensor, out, truth_tensor):

@@ -150,3 +150,67 @@ def train_steps(sd, x, truth, blocks, steps=1, lr=4e-4, v2=False):
     for k in sd:
         sd[k] = params[k].detach()
     return losses, grads
+
+
+def image_psnr_protocol(out, truth):
+    """validate.py:17-27 on one image pair (CHW float arrays): round half to even, clip to 0..255, uint8; the truth
+    cropped top-left to the output's size; 10 log10(255^2 / mean squared error) over all RGB values."""
+    import numpy as np
+    o8 = np.clip(np.round(out), 0, 255).astype(np.uint8)
+    t8 = np.clip(np.round(truth), 0, 255).astype(np.uint8)[:, :o8.shape[1], :o8.shape[2]]
+    d = np.float32(t8) - np.float32(o8)
+    return 10.0 * np.log10(255.0 ** 2 / np.mean(np.power(d, 2)))   # (a float32 scalar, as in the reference)
+
+
+def train_trajectory(sd, batches, steps, blocks, val_pairs, volume_per_step, val_volume, lr=4e-4, lr_decay=0.5,
+                     patience=3, cooldown=6, threshold=1e-3, min_lr=1e-8, v2=False):
+    """The plugin's step loop with its bookkeeping (models/LarvaNet.py:98-139): global_step / temp_volume counters,
+    the multi-exit step, validation at step 1 (:116-117) and whenever temp_volume >= val_volume (:119-124:
+    total_volume += temp_volume, temp_volume = 0, validate_for_train, save), validate_for_train's mean PSNR over
+    the validation pairs stepping ReduceLROnPlateau(mode max, abs threshold; :90-92,141-161), and the file name
+    save() writes (:183-185).  Step s trains on batches[s % len(batches)].  Returns a dict of per-step losses,
+    learning rates, volumes, and per-validation steps / PSNRs / checkpoint names; sd is updated in place."""
+    import numpy as np
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=lr)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="max", factor=lr_decay, patience=patience,
+                                                       cooldown=cooldown, threshold=threshold, threshold_mode="abs",
+                                                       min_lr=min_lr)
+    rec = {"losses": [], "lrs": [], "total_volume": [], "temp_volume": [], "val_steps": [], "psnrs": [], "ckpt_names": []}
+    global_step, total_volume, temp_volume = 0, 0.0, 0
+
+    def validate():
+        vals = []
+        with torch.no_grad():
+            for lr_img, hr_img in val_pairs:
+                x = torch.from_numpy(np.asarray(lr_img, np.float32))[None].to(next(iter(params.values())).dtype)
+                out = (forward_v2(params, x, blocks) if v2 else forward(params, x, blocks))[0].numpy()
+                vals.append(image_psnr_protocol(out, hr_img))
+        avg = np.mean(vals)   # (models/LarvaNet.py:158: the mean of float32 scalars stays float32)
+        rec["val_steps"].append(global_step)
+        rec["psnrs"].append(float(avg))
+        sched.step(avg)
+
+    for s in range(steps):
+        global_step += 1
+        temp_volume += volume_per_step
+        x, truth = batches[s % len(batches)]
+        loss = multi_exit_loss(params, x, truth, blocks, v2=v2)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if global_step == 1:
+            validate()
+        if temp_volume >= val_volume:
+            total_volume += temp_volume
+            temp_volume = 0
+            validate()
+            rec["ckpt_names"].append("model_step%d_vol%.0fG.pth" % (global_step, total_volume / 1e9))
+        rec["losses"].append(float(loss.item()))
+        rec["lrs"].append(opt.param_groups[0]["lr"])
+        rec["total_volume"].append(total_volume)
+        rec["temp_volume"].append(temp_volume)
+    for k in sd:
+        sd[k] = params[k].detach()
+    rec["scheduler"] = sched
+    return rec

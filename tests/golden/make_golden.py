@@ -114,6 +114,145 @@ def main_r2(only):
                  psnr_vs_truth=psnr, out_img0_f32=y[0].astype(np.float32)[:, ::3, ::3].copy())
 
 
+def trajectory_batches(nb=4, seed0=1300):
+    """The training batches of F13 (2 x 3 x 12 x 12 -> 2 x 3 x 48 x 48), step s uses batch s mod nb."""
+    pool = []
+    for i in range(nb):
+        g = torch.Generator().manual_seed(seed0 + i)
+        pool.append((torch.rand(2, 3, 12, 12, generator=g) * 255, torch.rand(2, 3, 48, 48, generator=g) * 255))
+    return pool
+
+
+F13_ARGV = ["--num_modules=2", "--num_blocks=2,2", "--lr=2e-3", "--val_volume=1.2e9"]
+F13_STEPS = 72
+F13_VOLUME_PER_STEP = 400000000   # 3 steps per validation; file names run through vol1G, vol2G, vol4G ...
+
+
+def main_r3(only):
+    """Round-3 fixtures.  F13 = the reference's own train_step_larva driven through its validation branch
+    (models/LarvaNet.py:116-137: temp_volume >= val_volume -> total_volume bookkeeping -> validate_for_train ->
+    scheduler.step(avg_psnr) at :161 -> save() name at :183-185) for 72 steps at M2B2 on four cycling batches,
+    long enough for ReduceLROnPlateau (patience 3, cooldown 6, factor .5, :90-92) to halve the learning rate.
+    F14 = LarvaNetV2.train_step_larva (models/LarvaNetV2.py:101-148) at M4B4 on 16x3x48x48 for 3 steps, recorded
+    like F11.  `python make_golden.py r3` writes only these."""
+    import contextlib
+    import io
+    import tempfile
+
+    def f13_run(perturb_seed=None):
+        model = make_ref_model("LarvaNet", F13_ARGV, seed=0)
+        if perturb_seed is not None:
+            # the reference's own sensitivity: initial weights moved by about one fp32 ulp (relative 1e-7 * N(0,1))
+            gen = torch.Generator().manual_seed(perturb_seed)
+            with torch.no_grad():
+                for p in model.model.parameters():
+                    p.mul_(1 + 1e-7 * torch.randn(p.shape, generator=gen))
+        attach_training(model)
+        model.volume_per_step = F13_VOLUME_PER_STEP
+        val = FakeValLoader(7)
+        tmp = tempfile.mkdtemp()
+        args = types.SimpleNamespace(train_path=tmp)
+        pool = trajectory_batches()
+        losses, lrs, vols, val_steps, psnrs = [], [], [], [], []
+        for step in range(F13_STEPS):
+            x, t = pool[step % len(pool)]
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                losses.append(model.train_step_larva(args, val, x, t, None))
+            lrs.append(model.get_lr())
+            vols.append((model.total_volume, model.temp_volume))
+            for line in buf.getvalue().splitlines():
+                if "psnr=" in line:
+                    val_steps.append(model.global_step)
+                    psnrs.append(float(line.split("psnr=")[1].split(",")[0]))
+        return model, tmp, losses, lrs, vols, val_steps, psnrs
+
+    def f13_cleanup(tmp):
+        for n in os.listdir(tmp):
+            os.remove(os.path.join(tmp, n))
+        os.rmdir(tmp)
+
+    if "f13" in only:
+        model, tmp, losses, lrs, vols, val_steps, psnrs = f13_run()
+        after = sd_to_np(model.model.state_dict())
+        flat_after = np.concatenate([after[k].ravel() for k in sorted(after)])
+        ckpts = sorted(os.listdir(tmp), key=lambda n: int(n.split("_")[1][4:]))
+        last = torch.load(os.path.join(tmp, ckpts[-1]))
+        assert all(np.array_equal(last[k].numpy(), after[k]) for k in after)   # the last save is the final weights
+        sch = model.scheduler
+        f13_cleanup(tmp)
+        # How far the REFERENCE moves when its initial weights move by one ulp: this trajectory (lr 2e-3, 72 AdamW
+        # steps) amplifies rounding-level differences, so "equal to the reference" can only mean "inside the tube
+        # the reference itself sweeps out".  Four perturbed runs; per step / per validation the largest deviation
+        # from the unperturbed run, then its running maximum.
+        env_loss, env_psnr, env_w, lrs_same = np.zeros(F13_STEPS), np.zeros(len(psnrs)), 0.0, True
+        for seed in (11, 12, 13, 14):
+            m2, tmp2, l2, lr2, _, _, p2 = f13_run(perturb_seed=seed)
+            f13_cleanup(tmp2)
+            env_loss = np.maximum(env_loss, np.abs(np.array(l2) / np.array(losses) - 1))
+            env_psnr = np.maximum(env_psnr, np.abs(np.array(p2) - np.array(psnrs)))
+            a2 = sd_to_np(m2.model.state_dict())
+            env_w = max(env_w, float(np.abs(np.concatenate([a2[k].ravel() for k in sorted(a2)]) - flat_after).mean()))
+            lrs_same = lrs_same and lr2 == lrs
+        np.savez(os.path.join(OUT, "f13_val_trajectory.npz"), losses=np.array(losses, np.float64),
+                 lrs=np.array(lrs, np.float64), total_volume=np.array([v[0] for v in vols], np.float64),
+                 temp_volume=np.array([v[1] for v in vols], np.float64), val_steps=np.array(val_steps),
+                 psnrs=np.array(psnrs, np.float64), ckpt_names=np.array(ckpts),
+                 sched_best=np.array(float(sch.best)), sched_num_bad=np.array(int(sch.num_bad_epochs)),
+                 sched_cooldown=np.array(int(sch.cooldown_counter)),
+                 after_sample=flat_after[::61].copy(), after_sha=np.array(sha(flat_after)),
+                 global_step=np.array(model.global_step),
+                 ulp_tube_loss=np.maximum.accumulate(env_loss), ulp_tube_psnr=np.maximum.accumulate(env_psnr),
+                 ulp_tube_weights_mean=np.array(env_w), ulp_tube_same_lrs=np.array(lrs_same))
+
+    if "f14" in only:
+        argv = ["--num_modules=4", "--num_blocks=4,4,4,4"]
+        x = torch.rand(16, 3, 48, 48, generator=torch.Generator().manual_seed(0)) * 255
+        truth = torch.rand(16, 3, 192, 192, generator=torch.Generator().manual_seed(1)) * 255
+        model = make_ref_model("LarvaNetV2", argv, seed=3)
+        attach_training(model)
+        model.volume_per_step = 48 * 48 * 16 * 3
+        val = FakeValLoader(7)
+        args = types.SimpleNamespace(train_path="/tmp")
+        losses, lrs, rec = [], [], {}
+        before = sd_to_np(model.model.state_dict())
+        flat_before = np.concatenate([before[k].ravel() for k in sorted(before)])
+        for step in range(3):
+            losses.append(model.train_step_larva(args, val, x, truth, None))
+            lrs.append(model.get_lr())
+            if step == 0:
+                for k, p in model.model.named_parameters():
+                    gnp = p.grad.detach().numpy()
+                    idx = np.random.RandomState(len(k)).choice(gnp.size, min(64, gnp.size), replace=False)
+                    rec["gidx." + k] = idx
+                    rec["gval." + k] = gnp.ravel()[idx].copy()
+                    rec["gmax." + k] = np.array(np.abs(gnp).max())
+                    rec["gabs." + k] = np.array(np.abs(gnp.astype(np.float64)).sum())
+                    rec["gsha." + k] = np.array(sha(gnp))
+        after = sd_to_np(model.model.state_dict())
+        flat_after = np.concatenate([after[k].ravel() for k in sorted(after)])
+        # The same first step by the reference in float64 (same initial weights): how far the reference's OWN fp32
+        # gradients are from the exact ones -- the L1 gradient is sign(out - truth), a handful of the 8.8 M pairs of
+        # the five exits sit within the forward's rounding error of each other, and a flipped sign moves single
+        # weight-gradient elements by a few 1e-4 of the tensor's maximum.
+        model64 = make_ref_model("LarvaNetV2", argv, seed=3)
+        model64.model.double()
+        attach_training(model64)
+        model64.volume_per_step = 48 * 48 * 16 * 3
+        model64.global_step = 1   # (not step 1: its validation would feed float32 images to the float64 module)
+        model64.train_step_larva(args, val, x.double(), truth.double(), None)
+        ref32_vs_64 = 0.0
+        for k, p in model64.model.named_parameters():
+            g64 = p.grad.detach().numpy().ravel()[rec["gidx." + k]]
+            rec["gval64." + k] = g64.copy()
+            ref32_vs_64 = max(ref32_vs_64, float(np.abs(g64 - rec["gval." + k]).max() / max(float(rec["gmax." + k]), 1e-30)))
+        rec["ref32_vs_ref64_worst"] = np.array(ref32_vs_64)
+        np.savez(os.path.join(OUT, "f14_v2_m4b4_train_steps.npz"), losses=np.array(losses, np.float64),
+                 lrs=np.array(lrs, np.float64), before_sha=np.array(sha(flat_before)), before_sample=flat_before[::211].copy(),
+                 after3_sample=flat_after[::211].copy(), after3_sha=np.array(sha(flat_after)),
+                 global_step=np.array(model.global_step), temp_volume=np.array(model.temp_volume), **rec)
+
+
 def main():
     sys.path.insert(0, REF)
     sys.modules.setdefault("cv2", types.ModuleType("cv2"))
@@ -121,6 +260,9 @@ def main():
     torch.use_deterministic_algorithms(False)
     if len(sys.argv) > 1 and sys.argv[1] == "r2":
         main_r2(sys.argv[2:] or ["f11", "f12"])
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "r3":
+        main_r3(sys.argv[2:] or ["f13", "f14"])
         return
 
     # ---------------- F1/F2: M2B2 weights, staged outputs on a 2x3x12x12 input ----------------

@@ -110,39 +110,137 @@ def test_headline_train_step_matches_reference_fixture_f11(hip_device, golden, o
 
 
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
-def test_headline_train_steps_v2_against_the_oracle(hip_device, use_graph):
-    """LarvaNetV2 (models/LarvaNetV2.py:101-123, 314-365) at the same size -- M4B4, 16 x 3 x 48 x 48, so the merge
+def test_headline_train_steps_v2_match_reference_fixture_f14(hip_device, golden, use_graph):
+    """LarvaNetV2 (models/LarvaNetV2.py:101-148, 314-365) at the headline size -- M4B4, 16 x 3 x 48 x 48, so the merge
     conv reads four 7 MB feature tensors as K = 192 and the tail is a fifth exit: three train_step_larva steps
-    against oracle/larva_torch.py (which F8 pins to the reference's V2) with the same initial weights: every loss,
-    every gradient element of the first step, the weights after the third AdamW step."""
+    against F14 = the reference's own three steps from the same weights (seed 3; lr 1e-4, V2's default): every
+    loss, sampled values and |g| sums of all 88 first-step gradients, the weights after the third AdamW step; and
+    every gradient element against oracle/larva_torch.py (pinned to F14 on the CPU)."""
     from oracle import larva_torch as T
+    g = golden("f14_v2_m4b4_train_steps.npz")
     m = _model("LarvaNetV2", FLAGS, training=True, seed=3)
     m.use_hip_graph = use_graph
     m.volume_per_step = 48 * 48 * 16 * 3
     sd = {k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()}
+    flat0 = np.concatenate([sd[k].numpy().ravel() for k in sorted(sd)])
+    assert np.array_equal(flat0[::211], g["before_sample"])    # the reference's initial weights, bit for bit
     x, truth = _canonical_batch()
     _, ref_grads = T.train_steps(dict(sd), x, truth, BLOCKS, steps=1, lr=m.get_lr(), v2=True)
-    ref_losses, _ = T.train_steps(sd, x, truth, BLOCKS, steps=3, lr=m.get_lr(), v2=True)   # (sd: the weights after 3 steps;
-    args = types.SimpleNamespace(train_path="/tmp")                                          #  V2's default lr is 1e-4)
+    args = types.SimpleNamespace(train_path="/tmp")
     xd, td = x.to(hip_device), truth.to(hip_device)
-    losses = []
+    losses, worst = [], {"fixture": 0.0, "oracle": 0.0, "gabs": 0.0, "fixture64": 0.0}
     for step in range(3):
         losses.append(m.train_step_larva(args, FakeValLoader(7), xd, td, None))
         if step == 0:
-            # 5e-4 of each tensor's largest element: the L1 gradient is sign(out - truth), and of the 8.8 M
-            # (output, truth) pairs of the five exits a handful lie closer together than the forward's own 1e-4
-            # error -- a flipped sign moves single weight-gradient elements by up to 3.5e-4 of the tensor's
-            # maximum (measured against a float64 run of the oracle as well: it is not summation order)
+            assert len(list(m.model.named_parameters())) == 88
             for k, p in m.model.named_parameters():
-                got, ref = p.grad.detach().cpu().numpy(), ref_grads[k].numpy()
-                assert float(np.abs(got - ref).max()) <= 5e-4 * max(float(np.abs(ref).max()), 1e-30), k
+                got = p.grad.detach().cpu().numpy()
+                gmax = max(float(g["gmax." + k]), 1e-30)
+                worst["fixture"] = max(worst["fixture"], float(np.abs(got.ravel()[g["gidx." + k]] - g["gval." + k]).max()) / gmax)
+                worst["fixture64"] = max(worst["fixture64"], float(np.abs(got.ravel()[g["gidx." + k]] - g["gval64." + k]).max()) / gmax)
+                worst["oracle"] = max(worst["oracle"], float(np.abs(got - ref_grads[k].numpy()).max()) / gmax)
+                gabs = float(np.abs(got.astype(np.float64)).sum())
+                worst["gabs"] = max(worst["gabs"], abs(gabs - float(g["gabs." + k])) / float(g["gabs." + k]))
+    own = float(g["ref32_vs_ref64_worst"])
+    print("F14 %s: gradient deviations (of each tensor's max): %s; the reference's own fp32 run against its fp64 run: %.2e"
+          % ("hipgraph" if use_graph else "eager", worst, own))
+    # Bars.  DESIGN section 6's gradient bar is 2e-4 of each tensor's largest element, and V1 (F11) meets it.  Here it
+    # cannot be met BY THE REFERENCE ITSELF: the L1 gradient is sign(out - truth), of the 8.8 M (output, truth) pairs of
+    # the five exits a handful lie closer together than the forward's rounding error, and a flipped sign moves single
+    # weight-gradient elements by a few 1e-4 of the tensor's maximum -- F14 holds the reference's first step in float64
+    # as well, and its own fp32 gradients sit 4.9e-4 from those.  So: every element within 5e-4 of the fp32 reference
+    # / oracle, no sampled element further from the EXACT (fp64) gradient than the reference's own fp32 run is
+    # (measured 2.5e-4 / 3.1e-4 / see the printed line), each tensor's |g| sum within 2e-4 (measured 2.4e-5).
+    assert worst["fixture"] <= 5e-4 and worst["oracle"] <= 5e-4 and worst["gabs"] <= 2e-4, worst
+    assert worst["fixture64"] <= max(own, 2e-4), (worst, own)
     assert m.use_hip_graph == use_graph
-    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5)
+    np.testing.assert_allclose(m.get_lr(), g["lrs"][-1])
+    assert m.global_step == int(g["global_step"]) and m.temp_volume == int(g["temp_volume"])
     # AdamW's first steps move a weight by lr * g / (|g| + eps): where |g| is of the order of eps = 1e-8 the move depends
     # on g's last bits, so single elements may sit up to steps * lr apart; everything else within 2e-5
-    for k, v in m.model.state_dict().items():
-        d = np.abs(v.cpu().numpy() - sd[k].numpy())
-        assert float((d > 2e-5).mean()) < 1e-3 and float(d.max()) <= 3.1 * m.get_lr(), (k, float(d.max()), float((d > 2e-5).mean()))
+    after = {k: v.cpu().numpy() for k, v in m.model.state_dict().items()}
+    flat = np.concatenate([after[k].ravel() for k in sorted(after)])
+    d = np.abs(flat[::211] - g["after3_sample"])
+    assert float((d > 2e-5).mean()) < 1e-3 and float(d.max()) <= 3.1 * m.get_lr(), (float(d.max()), float((d > 2e-5).mean()))
+
+
+def _trajectory_batches(nb=4, seed0=1300):
+    """The training batches of F13 (tests/golden/make_golden.py trajectory_batches): step s uses batch s mod nb."""
+    pool = []
+    for i in range(nb):
+        gen = torch.Generator().manual_seed(seed0 + i)
+        pool.append((torch.rand(2, 3, 12, 12, generator=gen) * 255, torch.rand(2, 3, 48, 48, generator=gen) * 255))
+    return pool
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_validation_branch_trajectory_matches_reference_fixture_f13(hip_device, golden, tmp_path, capsys, use_graph):
+    """F13: the plugin's train_step_larva driven for 72 steps through the reference's validation branch
+    (models/LarvaNet.py:116-137: temp_volume >= val_volume -> total_volume bookkeeping -> validate_for_train ->
+    scheduler.step(avg_psnr) at :161 -> save() name at :183-185) against what the reference itself did from the same
+    weights on the same four cycling batches: 25 validations, ReduceLROnPlateau (patience 3, cooldown 6) halving the
+    learning rate after the validation of step 54, 24 checkpoints.
+
+    What must be EXACT: the learning-rate sequence (i.e. every plateau decision), the validation steps, both volume
+    counters after every step, the checkpoint file names, the scheduler's counters at the end.
+    What drifts: fp32 summation order differs between the MFMA kernels and ATen's CPU convolution (1e-6 relative per
+    layer), and 72 AdamW steps at lr 2e-3 amplify rounding-level differences: the REFERENCE re-run from initial weights
+    one ulp away (F13's ulp_tube_*) stays within 0.012 dB / 1.2e-3 relative loss of itself up to step 51 and then
+    jumps to 0.12 dB / 1.5e-2 at the loss spike of steps 54-59.  Measured on MI355X (printed below): the same picture --
+    max 1.5e-2 on the loss at step 59, 1.0e-3 at step 72, 0.12 dB at the validation of step 54.  Bars: see (a), (b)."""
+    g = golden("f13_val_trajectory.npz")
+    m = _model("LarvaNet", ["--num_modules=2", "--num_blocks=2,2", "--lr=2e-3", "--val_volume=1.2e9"], training=True)
+    m.use_hip_graph = use_graph
+    m.volume_per_step = 400000000
+    args = types.SimpleNamespace(train_path=str(tmp_path))
+    val = FakeValLoader(7)
+    pool = [(a.to(hip_device), b.to(hip_device)) for a, b in _trajectory_batches()]
+    losses, lrs, tot, tmp, val_steps, psnrs = [], [], [], [], [], []
+    capsys.readouterr()
+    for step in range(72):
+        x, t = pool[step % len(pool)]
+        losses.append(m.train_step_larva(args, val, x, t, None))
+        lrs.append(m.get_lr())
+        tot.append(m.total_volume)
+        tmp.append(m.temp_volume)
+        for line in capsys.readouterr().out.splitlines():
+            if "psnr=" in line:
+                val_steps.append(m.global_step)
+                psnrs.append(float(line.split("psnr=")[1].split(",")[0]))
+    assert m.use_hip_graph == use_graph
+    loss_dev = np.abs(np.array(losses) / g["losses"] - 1)
+    psnr_dev = np.abs(np.array(psnrs) - g["psnrs"]) if len(psnrs) == len(g["psnrs"]) else None
+    with capsys.disabled():
+        print("\nF13 %s: max relative loss deviation %.2e (step %d; at step 72 %.2e), max PSNR deviation %s dB" % (
+            "hipgraph" if use_graph else "eager", loss_dev.max(), int(loss_dev.argmax()) + 1, loss_dev[-1],
+            None if psnr_dev is None else "%.2e" % psnr_dev.max()))
+    assert val_steps == list(g["val_steps"])
+    assert np.array_equal(np.array(lrs), g["lrs"]), [i + 1 for i in range(72) if lrs[i] != g["lrs"][i]]
+    assert np.array_equal(np.array(tot, np.float64), g["total_volume"]) and np.array_equal(np.array(tmp, np.float64), g["temp_volume"])
+    import os
+    names = sorted((n for n in os.listdir(str(tmp_path)) if n.startswith("model_step")), key=lambda n: int(n.split("_")[1][4:]))
+    assert names == list(g["ckpt_names"])
+    sch = m.scheduler
+    assert (sch.num_bad_epochs, sch.cooldown_counter) == (int(g["sched_num_bad"]), int(g["sched_cooldown"]))
+    assert abs(sch.best - float(g["sched_best"])) < 0.01
+    # (a) before the trajectory turns chaotic (the reference's own one-ulp tube is < 0.012 dB wide up to step 51):
+    #     north_star's 0.02 dB and 2e-3 relative on the loss
+    early = np.array(val_steps) <= 48
+    assert loss_dev[:48].max() < 2e-3 and psnr_dev[early].max() < 0.02, (loss_dev[:48].max(), psnr_dev[early].max())
+    # (b) all 72 steps: inside (3 x) the tube the REFERENCE sweeps out when its initial weights move by one fp32 ulp
+    #     (F13's ulp_tube_*: four perturbed runs of the reference, running maximum of the deviation; it jumps to 0.12 dB /
+    #     1.5e-2 at the loss spike of steps 54-59 -- every one of those runs takes the same plateau decisions)
+    assert bool(g["ulp_tube_same_lrs"])
+    assert (loss_dev <= 3 * g["ulp_tube_loss"] + 1e-5).all(), np.argwhere(loss_dev > 3 * g["ulp_tube_loss"] + 1e-5).ravel()
+    assert (psnr_dev <= 3 * g["ulp_tube_psnr"] + 2e-3).all(), np.argwhere(psnr_dev > 3 * g["ulp_tube_psnr"] + 2e-3).ravel()
+    # the last checkpoint is the reference-format bare state_dict of the final weights
+    last = torch.load(os.path.join(str(tmp_path), names[-1]), map_location="cpu")
+    flat = np.concatenate([last[k].numpy().ravel() for k in sorted(last)])
+    d = np.abs(flat[::61] - g["after_sample"])
+    with capsys.disabled():
+        print("F13 weights after 72 steps: max |dw| %.2e, mean %.2e (weights are O(0.01-0.1))" % (d.max(), d.mean()))
+    assert d.mean() < 3 * float(g["ulp_tube_weights_mean"])
 
 
 def test_headline_wgrad_launch_shape_32_layers_by_8_splits(hip_device):

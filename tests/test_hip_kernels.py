@@ -895,6 +895,13 @@ def test_adamw_host_scalars_match_torch_and_unaligned_views(hip_device):
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-8)
+    # The kernel follows torch.optim.AdamW's single-tensor step operation by operation (lerp as an fma, the second
+    # moment as mul + addcmul, sqrt / bias_correction2_sqrt then + eps, addcdiv): against ATen's CPU kernels the
+    # moments and the parameters come out bit for bit after five steps.
+    st = opt.state[ref]
+    same = [float((a.cpu() == b).float().mean()) for a, b in ((outs[0][0], ref.detach()), (outs[0][1], st["exp_avg"]),
+                                                               (outs[0][2], st["exp_avg_sq"]))]
+    assert min(same) == 1.0, same
 
 
 def test_timed_launches_compute_what_the_plain_launches_compute(hip_device):
@@ -986,3 +993,73 @@ def test_strip_tiles_at_32_channels(hip_device, kind):
     torch.cuda.synchronize()
     assert torch.equal(out[1:], wide[1:]) and bool((out[0] == -1.0).all())
     _report("c32 strips[%s]" % kind, wide.cpu().numpy(), ref, 2e-5)
+
+
+@pytest.fixture(scope="module")
+def canonical_wide_case():
+    """16 x C x 48 x 48 operands for C in (32, 64) with their CPU references (torch's own operators: conv2d,
+    conv2d_input, conv2d_weight -- float64 for the weight gradient, whose K is 36 864), computed once."""
+    import torch.nn.functional as F
+    torch.set_num_threads(8)
+    cases = {}
+    for C in (32, 64):
+        gen = torch.Generator().manual_seed(3200 + C)
+        x = torch.randn(16, C, 48, 48, generator=gen) * 20           # SURVEY 8(d): N(0,1) * 20 activations
+        w = torch.randn(C, C, 3, 3, generator=gen) * 0.05
+        b = torch.randn(C, generator=gen)
+        dy = torch.randn(16, C, 48, 48, generator=gen) * 1e-3
+        r0 = torch.randn(16, C, 48, 48, generator=gen) * 20
+        r1 = torch.randn(16, C, 48, 48, generator=gen) * 20
+        y = F.conv2d(x, w, b, padding=1)
+        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1)
+        dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1).float()
+        db = dy.double().sum((0, 2, 3)).float()
+        cases[C] = dict(x=x, w=w, b=b, dy=dy, r0=r0, r1=r1, y=y, dx=dx, dw=dw, db=db)
+    return cases
+
+
+@pytest.mark.parametrize("C", [32, 64])
+def test_canonical_batch_at_32_and_64_channels(hip_device, canonical_wide_case, C):
+    """BASELINE configs 2 / 5 name 32- and 64-channel bodies; bench.py times roofline_c32 / _c64 and
+    roofline_wgrad_c32 / _c64 at 16 x C x 48 x 48.  The launches exactly as they are timed -- 256-workgroup wide
+    grid, XCD remap, the strip tables of the two half-batch chains, the 8-way split weight gradient -- checked by
+    value at that size against torch's CPU operators: conv + bias + ReLU, the residual and mask epilogues, dgrad
+    (tap-mirrored weight image), wgrad + bias gradient."""
+    from larvanet_amd import kernels as K
+    c = canonical_wide_case[C]
+    d = {k: v.to(hip_device) for k, v in c.items() if k in ("x", "w", "b", "dy", "r0", "r1")}
+    fwd, bwd = K.pack_weights(d["w"])
+    scale = float(c["y"].abs().max())
+
+    def close(got, ref, tol, what):
+        err = float((got.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+        assert err < tol, (what, C, err)
+
+    # wide tiles: conv + bias + ReLU, both residual operands, the ReLU-backward mask
+    relu_wide = K.conv3x3(d["x"], fwd, C, bias=d["b"], relu=True)
+    close(relu_wide, c["y"].clamp_min(0), 1e-5, "conv+ReLU wide")
+    res2 = K.conv3x3(d["x"], fwd, C, bias=d["b"], res0=d["r0"], res1=d["r1"])
+    close(res2, (c["y"] + c["r0"]) + c["r1"], 1e-5, "conv+res0+res1 wide")
+    # dgrad of the layer (+ the mask epilogue the residual blocks' backward uses)
+    dx = K.conv3x3(d["dy"], bwd, C)
+    close(dx, c["dx"], 2e-5, "dgrad wide")
+    dxm = K.conv3x3(d["dy"], bwd, C, mask=relu_wide)
+    close(dxm, c["dx"] * (c["y"].clamp_min(0) > 0), 2e-5, "dgrad+mask wide")
+    # the two half-batch chains' launches (strip tables of both phases where the width has them; at 64 channels the
+    # call runs the wide tiles over the image range): bit-identical to the full-batch wide launch
+    for kw, ref in ((dict(bias=d["b"], relu=True), relu_wide), (dict(bias=d["b"], res0=d["r0"], res1=d["r1"]), res2)):
+        out = torch.full_like(ref, float("nan"))
+        K.conv3x3(d["x"], fwd, C, out=out, images=(0, 8), strips=True, **kw)
+        K.conv3x3(d["x"], fwd, C, out=out, images=(8, 16), strips=2, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), ("half-batch strips", C, sorted(kw))
+    # weight + bias gradient, 8-way split (256 workgroups per layer at the canonical size would be splits = 256;
+    # 8 is the step's launch shape) and a single split
+    for splits in (8, 1):
+        dw = torch.full((C, C, 3, 3), float("nan"), device=hip_device)
+        db = torch.full((C,), float("nan"), device=hip_device)
+        K.conv3x3_wgrad([{"dy": d["dy"], "x": d["x"], "dw": dw, "db": db}], C, C, splits)
+        torch.cuda.synchronize()
+        close(dw, c["dw"], 3e-5, "wgrad splits=%d" % splits)
+        close(db, c["db"], 3e-5, "bias grad splits=%d" % splits)
+    assert scale > 10   # (the activations really are at the 0-255 scale's order of magnitude)

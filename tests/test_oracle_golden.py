@@ -239,3 +239,65 @@ def test_torch_restatement_canonical_uint8_protocol_f12(golden):
     assert np.array_equal(y8[0], g["u8_img0"]) and np.array_equal(y8[15], g["u8_img15"])
     psnr = np.array([R.image_psnr(y8[i], t8[i]) for i in range(16)])
     np.testing.assert_allclose(psnr, g["psnr_vs_truth"], rtol=0, atol=1e-6)
+
+
+def _trajectory_batches(nb=4, seed0=1300):
+    """The training batches of F13 (tests/golden/make_golden.py trajectory_batches): step s uses batch s mod nb."""
+    pool = []
+    for i in range(nb):
+        g = torch.Generator().manual_seed(seed0 + i)
+        pool.append((torch.rand(2, 3, 12, 12, generator=g) * 255, torch.rand(2, 3, 48, 48, generator=g) * 255))
+    return pool
+
+
+def _fake_val_pairs(seed=7):
+    rng = np.random.RandomState(seed)
+    pairs = []
+    for (h, w) in ((10, 12), (9, 14)):
+        lr = rng.randint(0, 256, size=(3, h, w)).astype(np.float32)
+        hr = rng.randint(0, 256, size=(3, 4 * h + 1, 4 * w + 2)).astype(np.float32)
+        pairs.append((lr, hr))
+    return pairs
+
+
+def test_torch_restatement_validation_trajectory_f13(golden):
+    """F13: 72 steps of the reference's own train_step_larva through its validation branch (models/LarvaNet.py:116-137,
+    141-161, 183-185): volumes, 25 validations, the plateau scheduler halving the learning rate at step 54, 24
+    checkpoint names.  The oracle calls the same torch CPU operators, so everything is equal to the last bit but the
+    PSNR the reference only PRINTS (8 decimals)."""
+    g = golden("f13_val_trajectory.npz")
+    torch.set_num_threads(4)
+    sd = T.init_state_dict([2, 2], seed=0)
+    rec = T.train_trajectory(sd, _trajectory_batches(), 72, [2, 2], _fake_val_pairs(), 400000000, 1.2e9, lr=2e-3)
+    np.testing.assert_allclose(rec["losses"], g["losses"], rtol=1e-6)
+    assert np.array_equal(rec["lrs"], g["lrs"]) and len(set(rec["lrs"])) == 2   # one halving
+    assert rec["val_steps"] == list(g["val_steps"]) and rec["ckpt_names"] == list(g["ckpt_names"])
+    np.testing.assert_allclose(rec["psnrs"], g["psnrs"], rtol=0, atol=2e-8)
+    assert np.array_equal(rec["total_volume"], g["total_volume"]) and np.array_equal(rec["temp_volume"], g["temp_volume"])
+    sch = rec["scheduler"]
+    assert abs(sch.best - float(g["sched_best"])) < 1e-7
+    assert (sch.num_bad_epochs, sch.cooldown_counter) == (int(g["sched_num_bad"]), int(g["sched_cooldown"]))
+    flat = np.concatenate([sd[k].numpy().ravel() for k in sorted(sd)])
+    np.testing.assert_allclose(flat[::61], g["after_sample"], rtol=0, atol=1e-6)
+
+
+def test_torch_restatement_v2_headline_steps_f14(golden):
+    """F14: LarvaNetV2.train_step_larva (models/LarvaNetV2.py:101-148) at M4B4 on 16x3x48x48, three steps: losses,
+    sampled gradients of all 88 tensors, weights after the third AdamW step (lr 1e-4, V2's default)."""
+    g = golden("f14_v2_m4b4_train_steps.npz")
+    torch.set_num_threads(8)
+    blocks = [4, 4, 4, 4]
+    sd = T.init_state_dict(blocks, v2=True, seed=3)
+    flat0 = np.concatenate([sd[k].numpy().ravel() for k in sorted(sd)])
+    assert np.array_equal(flat0[::211], g["before_sample"])   # same init draw order as the reference's V2 module
+    x = torch.rand(16, 3, 48, 48, generator=torch.Generator().manual_seed(0)) * 255
+    truth = torch.rand(16, 3, 192, 192, generator=torch.Generator().manual_seed(1)) * 255
+    _, grads = T.train_steps(dict(sd), x, truth, blocks, steps=1, lr=1e-4, v2=True)
+    assert len(grads) == 88
+    for k, gr in grads.items():
+        got = gr.numpy().ravel()[g["gidx." + k]]
+        assert np.abs(got - g["gval." + k]).max() <= 1e-4 * max(float(g["gmax." + k]), 1e-30), k   # (summation order varies with the thread count)
+    losses, _ = T.train_steps(sd, x, truth, blocks, steps=3, lr=1e-4, v2=True)
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-6)
+    flat = np.concatenate([sd[k].numpy().ravel() for k in sorted(sd)])
+    np.testing.assert_allclose(flat[::211], g["after3_sample"], rtol=0, atol=1e-6)
