@@ -15,7 +15,9 @@ of the reference) at the BASELINE configuration: 16 x 3 x 48 x 48 fp32 patches p
 192 x 192, `--num_modules=4 --num_blocks=4,4,4,4`, 48 channels (the only channel count the
 reference can express).  value = N * 16 * 192 * 192 / t_step (pixels counted once).
 The K-step loop is timed --rounds times (barrier + synchronize on both sides of each); value and
-ms_per_step are the MEDIAN round, min / max are reported beside it.
+ms_per_step are the MEDIAN round, min / max are reported beside it.  The loop has the reference's
+semantics: every step is handed fresh device tensors (train_larva.py:123-128) and returns loss.item()
+(models/LarvaNet.py:139).
 
 The JSON line also carries
   roofline            fp32-MFMA roofline of the dominant kernel (fused conv3x3+ReLU, 48->48,
@@ -30,8 +32,10 @@ The JSON line also carries
                       the host cores of this box, bounded sample
   infer               inference-forward throughput (LarvaNetModule.forward) on the batch
   infer_full_image    V1 and V2 on one 3 x 339 x 510 image (BASELINE config 5 at N = 1)
-  value_sync_loss     the same loop with the reference's per-step behaviour: fresh input tensors
-                      copied into the step and loss.item() (a host sync) every step
+  step                the whole step's 183.7 GFLOP over ms_per_step against the fp32 matrix peak
+  value_async_resident   the loop without the reference's per-step loss.item() and with the batch already in
+                      the captured step's input buffers (round 2's headline; --async-loss makes it `value`)
+  roofline_wgrad_c32/_c64   the weight-gradient launch + reduction at 32 / 64 channels
   rccl_ranks, allreduce_exposed_us   N > 1: ranks in the RCCL communicator and the event-timed gap
                       per step between the last weight-gradient kernel and the optimizer
 """
@@ -57,21 +61,47 @@ FLAGS = ["--num_modules=4", "--num_blocks=4,4,4,4"]
 HR_PIX_PER_BATCH = BATCH * (PATCH * SCALE) ** 2          # 589 824
 FP32_MFMA_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: Peak FP32 (matrix)
 FULL_IMAGE = (3, 339, 510)                               # DIV2K-val-like LR image
-# HBM bytes per launch of the dominant kernel: NOT measured by this run (counters need rocprofv3);
-# taken from the committed PMC passes -- FETCH_SIZE doubled per the guide's gfx950 correction +
-# WRITE_SIZE, both in KB.  roofline.traffic_source names the file.
-HBM_TRAFFIC_PER_LAUNCH = (2 * 3919.5 + 6982.4) * 1024          # one whole-batch launch (3 x 48 tiles)
-HBM_TRAFFIC_PER_STRIP_LAUNCH = (2 * 2227.0 + 3457.1) * 1024     # one half-batch strip launch (two per layer)
-HBM_TRAFFIC_SOURCE = ("profiles/r02_pmc_conv_strip_vs_wide.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                      "`bench.py --roofline-only`, tools/pmc_conv.sh; a constant, not measured by this run)")
+# HBM-side bytes per launch come from the committed rocprofv3 --pmc passes (counters cannot be collected by this run
+# itself); they are READ from the CSVs under profiles/ at run time -- a tile change that is not followed by new PMC
+# passes shows as a stale file name here, not as a silently wrong constant.  FETCH_SIZE is doubled per the guide's
+# gfx950 correction for 16-byte-per-lane streams; both counters are in KB.
+PMC_CONV_CSV = "profiles/r02_pmc_conv_strip_vs_wide.csv"
+PMC_WGRAD_CSV = "profiles/r02_pmc_wgrad_pipe_traffic.csv"
+PMC_REDUCE_CSV = "profiles/r02_pmc_reduce_traffic.csv"
 
 
-# The weight-gradient kernel's HBM-side bytes per LAYER, from the committed PMC passes over a 32-layer launch
-# (profiles/r02_pmc_wgrad_pipe_traffic.csv: FETCH_SIZE 224 093 KB doubled, WRITE_SIZE 20 849 KB) and its reduction
-# (profiles/r02_pmc_reduce_traffic.csv: FETCH_SIZE 11 117 KB doubled, WRITE_SIZE 2 598 KB); constants, not measured here
-WGRAD_TRAFFIC_PER_LAYER = (2 * 224093 + 20849 + 2 * 11117 + 2598) * 1024 / 32
-WGRAD_TRAFFIC_SOURCE = ("profiles/r02_pmc_wgrad_pipe_traffic.csv + profiles/r02_pmc_reduce_traffic.csv (separate rocprofv3 --pmc "
-                        "FETCH_SIZE / WRITE_SIZE passes, tools/pmc_wgrad.sh, tools/pmc_reduce.sh; constants, not measured by this run)")
+def pmc_mean(path, kernel_substr, counter):
+    """mean_per_launch of `counter` for the first kernel whose name contains `kernel_substr` in a committed PMC
+    summary (columns: pass,kernel,counter,launches,mean_per_launch,mean_duration_us)."""
+    import csv
+    full = os.path.join(ROOT, path)
+    if not os.path.exists(full):
+        raise SystemExit("bench.py: %s is missing -- roofline.traffic is taken from the committed PMC passes" % path)
+    with open(full, newline="") as f:
+        for row in csv.DictReader(f):
+            if kernel_substr in row["kernel"] and row["counter"] == counter:
+                return float(row.get("mean_per_launch") or row["mean_per_launch_KB"])
+    raise SystemExit("bench.py: no %s row for a kernel matching %r in %s" % (counter, kernel_substr, path))
+
+
+def hbm_traffic_bytes(path, kernel_substr):
+    return (2.0 * pmc_mean(path, kernel_substr, "FETCH_SIZE") + pmc_mean(path, kernel_substr, "WRITE_SIZE")) * 1024.0
+
+
+def conv_traffic(dual):
+    """(bytes per LAYER, source) of the fused conv+ReLU layer: two half-batch strip launches, or one whole-batch launch."""
+    if dual:
+        return 2 * hbm_traffic_bytes(PMC_CONV_CSV, "conv3x3_mfma_strip_kernel<1>"), PMC_CONV_CSV
+    return hbm_traffic_bytes(PMC_CONV_CSV, "conv3x3_mfma_kernel<48, true, 1>"), PMC_CONV_CSV
+
+
+def wgrad_traffic_per_layer():
+    """Weight-gradient kernel (32-layer launch) + its reduction, per layer."""
+    return (hbm_traffic_bytes(PMC_WGRAD_CSV, "wgrad3x3_pipe_kernel") + hbm_traffic_bytes(PMC_REDUCE_CSV, "wgrad_reduce_kernel")) / 32.0
+
+
+TRAFFIC_NOTE = ("read at run time from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
+                "correction); not measured by this run")
 
 
 def conv_flop(c):
@@ -152,28 +182,59 @@ def barrier_sync(dist_on):
         torch.cuda.synchronize()
 
 
-def chain_time_ms(dev, c, chain=40, reps=10):
+def chain_operands(dev, c, chain=40, decaying=False):
+    """Operands of the roofline chains: x0 = N(0,1) * 20 activations that STAY at that scale down the
+    chain.  conv + ReLU with zero bias is positively homogeneous in the weights, so one eager pass over the chain
+    measures its gain and the weights are rescaled by gain^(-1/chain): the RMS after `chain` layers equals the RMS
+    of x0 (every layer in between within a few per cent of it).  Layer 0 always reads x0, which nothing overwrites,
+    so every replay computes the same thing.  decaying=True: round 2's operands (ones in, weights x 0.05: the
+    activations shrink ~30x per layer and are exactly zero from the first replay on) -- kept for one A/B figure.
+    Returns (x0, packed weights, bias, [buf_a, buf_b], rms of the last layer's output)."""
+    import torch
+    from larvanet_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    x0 = (torch.randn(BATCH, c, PATCH, PATCH, generator=g) * 20).to(dev)
+    w = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5).to(dev)
+    b = torch.zeros(c, device=dev)
+    bufs = [torch.empty_like(x0), torch.empty_like(x0)]
+    if decaying:
+        fwd, _ = K.pack_weights((torch.randn(c, c, 3, 3, generator=g) * 0.05).to(dev))
+        return x0 * 0.0 + 1.0, fwd * 0.05, b, bufs, 0.0
+
+    def run(wpk):
+        src = x0
+        for i in range(chain):
+            K.conv3x3(src, wpk, c, bias=b, relu=True, out=bufs[i & 1])
+            src = bufs[i & 1]
+        return float(src.pow(2).mean().sqrt())
+
+    fwd, _ = K.pack_weights(w)
+    rms0 = float(x0.pow(2).mean().sqrt())
+    gain = run(fwd) / rms0
+    if not (gain > 0 and gain == gain and gain != float("inf")):
+        raise SystemExit("bench.py: roofline chain calibration failed (gain %r)" % gain)
+    fwd = fwd * gain ** (-1.0 / chain)
+    return x0, fwd, b, bufs, run(fwd)
+
+
+def chain_time_ms(dev, c, chain=40, reps=10, decaying=False):
     """The fused conv3x3+ReLU kernel the way it runs inside the training step: a captured chain of
     `chain` dependent launches (each reads the previous one's output), replayed back to back, timed
     by a HIP event pair on the launch stream; per launch = replay time / chain."""
     import torch
     from larvanet_amd import kernels as K
-    g = torch.Generator().manual_seed(5)
-    x = (torch.randn(BATCH, c, PATCH, PATCH, generator=g) * 20).to(dev)
-    w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(dev)
-    b = torch.zeros(c, device=dev)
-    fwd, _ = K.pack_weights(w)
-    bufs = [x.clone() * 0.0 + 1.0, torch.empty_like(x)]
-    wsmall = fwd * 0.05  # keeps the activations finite down the chain
+    x0, wpk, b, bufs, rms = chain_operands(dev, c, chain, decaying)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        K.conv3x3(bufs[0], wsmall, c, bias=b, relu=True, out=bufs[1])
+        K.conv3x3(x0, wpk, c, bias=b, relu=True, out=bufs[0])
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        src = x0
         for i in range(chain):
-            K.conv3x3(bufs[i & 1], wsmall, c, bias=b, relu=True, out=bufs[(i + 1) & 1])
+            K.conv3x3(src, wpk, c, bias=b, relu=True, out=bufs[i & 1])
+            src = bufs[i & 1]
     graph.replay()
     torch.cuda.synchronize()
     best = []
@@ -185,25 +246,19 @@ def chain_time_ms(dev, c, chain=40, reps=10):
         e.record()
         torch.cuda.synchronize()
         best.append(s.elapsed_time(e) / (reps * chain))
-    return sorted(best)[1]
+    return sorted(best)[1], rms
 
 
-def dual_chain_time_ms(dev, c=CH, chain=40, reps=10):
-    """The same layers the way the training step now runs its layer chain (autograd.DualChain): two
+def dual_chain_time_ms(dev, c=CH, chain=40, reps=10, decaying=False):
+    """The same layers the way the training step runs its layer chain (autograd.DualChain): two
     half-batch chains of strip-tile launches (5 x 16 / 4 x 16 pixel tiles, 256 workgroups per launch)
     on two streams inside one captured graph; per FULL-BATCH layer = replay time / chain."""
     import torch
     from larvanet_amd import kernels as K
-    g = torch.Generator().manual_seed(5)
-    x = (torch.randn(BATCH, c, PATCH, PATCH, generator=g) * 20).to(dev)
-    w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(dev)
-    b = torch.zeros(c, device=dev)
-    fwd, _ = K.pack_weights(w)
-    bufs = [x.clone() * 0.0 + 1.0, torch.empty_like(x)]
-    wsmall = fwd * 0.05
     for phase in (0, 1):
         if K.strip_tile_table(PATCH, PATCH, dev, phase) is None:
             return None
+    x0, wpk, b, bufs, rms = chain_operands(dev, c, chain, decaying)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     parts = ((0, BATCH // 2), (BATCH // 2, BATCH))
 
@@ -211,11 +266,13 @@ def dual_chain_time_ms(dev, c=CH, chain=40, reps=10):
         cur = torch.cuda.current_stream()
         for st in streams:
             st.wait_stream(cur)
+        src = x0
         for i in range(chain):
             for k, st in enumerate(streams):
                 with torch.cuda.stream(st):
-                    K.conv3x3(bufs[i & 1], wsmall, c, bias=b, relu=True, out=bufs[(i + 1) & 1], images=parts[k],
-                              strips=2 if k else True)
+                    K.conv3x3(src, wpk, c, bias=b, relu=True, out=bufs[i & 1], images=parts[k],
+                              strips=2 if k else True, plain_stores=True)   # (plain stores: what the step's forward chain uses)
+            src = bufs[i & 1]
         for st in streams:
             cur.wait_stream(st)
 
@@ -240,7 +297,7 @@ def dual_chain_time_ms(dev, c=CH, chain=40, reps=10):
         e.record()
         torch.cuda.synchronize()
         best.append(s.elapsed_time(e) / (reps * chain))
-    return sorted(best)[1]
+    return sorted(best)[1], rms
 
 
 def time_dominant_kernel(dev, iters=50):
@@ -293,19 +350,26 @@ def roofline_block(dev, c=CH, full=True, dual=False):
     training step runs it since round 2 -- two concurrent half-batch launches of
     conv3x3_mfma_strip_kernel; `avg_ms` is then the time per FULL-BATCH layer (= per pair of
     launches), `flop_per_launch` one launch's half."""
-    graph_ms = dual_chain_time_ms(dev, c) if dual else chain_time_ms(dev, c)
-    if graph_ms is None:
+    res = dual_chain_time_ms(dev, c) if dual else chain_time_ms(dev, c)
+    if res is None:
         return None
+    graph_ms, rms = res
     # priced on the in-graph time per layer (what the step pays, boundaries included)
     flop = conv_flop(c)
     achieved = flop / (graph_ms * 1e-3) / 1e12
     alg_bytes = 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c)
     blk = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-           "traffic": (2 * HBM_TRAFFIC_PER_STRIP_LAUNCH if dual else HBM_TRAFFIC_PER_LAUNCH) if c == CH else None,
-           "avg_ms": graph_ms}
+           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_ms": graph_ms,
+           "inputs": "layer 0 reads N(0,1)*20 activations; weights rescaled so the RMS stays there down the 40-layer chain "
+                     "(last layer's output RMS %.1f)" % rms}
     if c == CH:
-        blk["traffic_source"] = HBM_TRAFFIC_SOURCE
+        blk["traffic"], src = conv_traffic(dual)
+        blk["traffic_source"] = TRAFFIC_NOTE % src
+        if full or dual:
+            old_ms = (dual_chain_time_ms(dev, c, decaying=True) if dual else chain_time_ms(dev, c, decaying=True))[0]
+            blk["avg_ms_decaying_inputs"] = old_ms
+            blk["avg_ms_decaying_inputs_is"] = ("round 2's microbenchmark operands (ones in, weights x 0.05: all-zero activations "
+                                                "from the first replay on), for comparison")
     if dual:
         alone = strip_launch_alone_ms(dev, c)
         if alone is not None:
@@ -338,25 +402,27 @@ def roofline_block(dev, c=CH, full=True, dual=False):
     return blk
 
 
-def wgrad_block(dev, jobs=40, iters=10):
-    """Second kernel of the step (28 % of it): the weight-gradient launch as the step issues it since round 2 -- ONE
-    flat grid of 256 workgroups over the tiles of all 40 48 -> 48 layers (partial images) + the fixed-order
-    reduction -- replayed from a captured graph and timed with an event pair.  (The 3 -> 48 head, which the step
-    appends to the same grid, is not part of this block: its FLOPs are not in `flop_per_layer` either.)"""
+def wgrad_block(dev, c=CH, jobs=40, iters=10):
+    """Second kernel of the step (28 % of it): the weight-gradient launch as the step issues it -- ONE flat grid of 256
+    workgroups over the tiles of all 40 C -> C layers (partial images) + the fixed-order reduction -- replayed from a
+    captured graph and timed with an event pair.  c = 48: the pipelined kernel (the 3 -> 48 head, which the step
+    appends to the same grid, is not part of this block: its FLOPs are not in `flop_per_layer` either).  Other channel
+    counts (BASELINE configs 2 / 5 read at 32 / 64 channels): the launch the library has for them, 32 layers x 8
+    workgroups."""
     import torch
     from larvanet_amd import kernels as K
     g = torch.Generator().manual_seed(6)
-    dy = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 1e-3).to(dev)
-    xs = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 20).to(dev)
-    js = [{"dy": dy + 0, "x": xs + 0, "dw": torch.empty(CH, CH, 3, 3, device=dev), "db": torch.empty(CH, device=dev)}
+    dy = (torch.randn(BATCH, c, PATCH, PATCH, generator=g) * 1e-3).to(dev)
+    xs = (torch.randn(BATCH, c, PATCH, PATCH, generator=g) * 20).to(dev)
+    js = [{"dy": dy + 0, "x": xs + 0, "dw": torch.empty(c, c, 3, 3, device=dev), "db": torch.empty(c, device=dev)}
           for _ in range(jobs)]
 
     def pair():
-        res = K.conv3x3_wgrad_partial_flat(js, CH, CH, 256)
+        res = K.conv3x3_wgrad_partial_flat(js, c, c, 256)
         if res is None:   # (the flat grid does not apply: the per-layer launch)
-            K.conv3x3_wgrad(js[:32], CH, CH, 8)
+            K.conv3x3_wgrad(js[:32], c, c, 8)
             return False
-        K.wgrad_reduce([dict(j, partial=p, splits=s, cout=CH, cin=CH) for j, p, s in zip(js, *res)])
+        K.wgrad_reduce([dict(j, partial=p, splits=s, cout=c, cin=c) for j, p, s in zip(js, *res)])
         return True
 
     flat = pair()
@@ -378,16 +444,20 @@ def wgrad_block(dev, jobs=40, iters=10):
         torch.cuda.synchronize()
         runs.append(s.elapsed_time(e) / iters)
     ms = sorted(runs)[1]
-    achieved = conv_flop(CH) * nlayers / (ms * 1e-3) / 1e12
-    kernel = ("wgrad3x3_pipe_flat_kernel<48, 48> (one grid of 256 workgroups over %d layers) + wgrad_reduce_kernel" % nlayers
-              if flat else "wgrad3x3_pipe_kernel<48, 48> + wgrad_reduce_kernel, 32 layers x 8 workgroups")
-    return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "kernel": kernel + ", 16x48x48x48 fp32", "layers": nlayers,
-            "ms_per_launch_pair": ms, "flop_per_layer": conv_flop(CH),
-            "traffic": WGRAD_TRAFFIC_PER_LAYER * nlayers, "traffic_source": WGRAD_TRAFFIC_SOURCE,
-            "traffic_is": "HBM-side bytes of the launch pair = per-layer figure x layers (dy + x read once, partial images written and read once)",
-            "algorithmic_bytes_per_layer": 2 * BATCH * CH * PATCH * PATCH * 4 + 4 * (9 * CH * CH + CH),
-            "timing": "HIP event pair around %d replays of a captured graph of the launch pair, back to back (median of 3)" % iters}
+    achieved = conv_flop(c) * nlayers / (ms * 1e-3) / 1e12
+    kernel = ("wgrad3x3_pipe_flat_kernel<%d, %d> (one grid of 256 workgroups over %d layers) + wgrad_reduce_kernel" % (c, c, nlayers)
+              if flat else "wgrad3x3 kernel for (%d, %d) + wgrad_reduce_kernel, 32 layers x 8 workgroups" % (c, c))
+    blk = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "kernel": kernel + ", 16x%dx48x48 fp32" % c, "layers": nlayers,
+           "ms_per_launch_pair": ms, "ms_per_layer": ms / nlayers, "flop_per_layer": conv_flop(c), "traffic": None,
+           "algorithmic_bytes_per_layer": 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c),
+           "timing": "HIP event pair around %d replays of a captured graph of the launch pair, back to back (median of 3)" % iters}
+    if c == CH:
+        blk["traffic"] = wgrad_traffic_per_layer() * nlayers
+        blk["traffic_source"] = TRAFFIC_NOTE % (PMC_WGRAD_CSV + " + " + PMC_REDUCE_CSV)
+        blk["traffic_is"] = ("HBM-side bytes of the launch pair = per-layer figure x layers (dy + x read once, partial images "
+                             "written and read once)")
+    return blk
 
 
 def wgrad_in_step(model, x, truth, reps=30):
@@ -485,17 +555,32 @@ def cpu_baseline(budget_s=15.0):
         opt.step()
         return loss.item()
 
-    step()  # warm-up
+    for _ in range(3):   # warm-ups
+        step()
     times = []
     t_start = time.perf_counter()
-    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 50):
+    while len(times) < 10 or (time.perf_counter() - t_start < budget_s and len(times) < 50):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
+    # forward-only leg (LarvaNetModule.forward under no_grad, models/LarvaNet.py:287-293), same protocol
+    fwd_sd = {k: v.detach() for k, v in params.items()}
+    with torch.no_grad():
+        for _ in range(3):
+            T.forward(fwd_sd, x, BLOCKS)
+        ftimes = []
+        t_start = time.perf_counter()
+        while len(ftimes) < 10 or (time.perf_counter() - t_start < budget_s / 3 and len(ftimes) < 50):
+            t0 = time.perf_counter()
+            T.forward(fwd_sd, x, BLOCKS)
+            ftimes.append(time.perf_counter() - t0)
+    fmed = float(np.median(ftimes))
     return {"value": HR_PIX_PER_BATCH / med / 1e6, "unit": "HR Mpixels/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps (median %.1f ms) of the same M4B4 batch-16 workload, torch %s CPU ops, %d threads"
-                      % (len(times), med * 1e3, torch.__version__, cores)}
+            "sample": "%d train steps after 3 warm-ups (median %.1f ms) of the same M4B4 batch-16 workload, torch %s CPU ops, "
+                      "%d threads" % (len(times), med * 1e3, torch.__version__, cores),
+            "forward_only": {"value": HR_PIX_PER_BATCH / fmed / 1e6, "unit": "HR Mpixels/s", "ms_per_batch": fmed * 1e3,
+                             "sample": "%d forwards after 3 warm-ups" % len(ftimes)}}
 
 
 def full_image_block(dev):
@@ -577,8 +662,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only time the dominant kernel (short run for rocprofv3 --pmc passes)")
-    ap.add_argument("--sync-loss", action="store_true",
-                    help="return loss.item() every step like the reference (host sync per step)")
+    ap.add_argument("--sync-loss", action="store_true", help="(the default since round 3; kept for old command lines)")
+    ap.add_argument("--async-loss", action="store_true",
+                    help="headline loop without the reference's per-step loss.item() and with the batch already in the "
+                         "captured step's input buffers (round 2's headline; now the `value_async_resident` extra)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -617,7 +704,10 @@ def main():
     torch.manual_seed(0)
     model.volume_per_step = PATCH * PATCH * BATCH * 3 * world
     model.prepare(is_training=True, scales=[SCALE])
-    model.sync_loss = bool(a.sync_loss)
+    # The headline loop has the reference's semantics (models/LarvaNet.py:98-139, train_larva.py:123-128): a batch of
+    # fresh device tensors is handed to train_step_larva, which returns loss.item() -- a host round trip -- every step.
+    ref_semantics = not a.async_loss
+    model.sync_loss = ref_semantics
     model.time_allreduce = world > 1
 
     g = torch.Generator().manual_seed(1000 + rank)
@@ -634,13 +724,14 @@ def main():
         sys.stderr.write("bench.py: hipGraph capture FAILED, the step runs as eager launches (%s)\n" % model.hip_graph_fell_back)
         if world == 1 or os.environ.get("LARVA_BENCH_STRICT_GRAPH", "0") != "0":
             sys.exit(3)
-    # the batch sits where a device-side producer (dataloaders/device_patch_loader, `out=`) puts it:
-    # in the input buffers of the captured step, so the step does not copy it again
+    # --async-loss: the batch sits where a device-side producer (dataloaders/device_patch_loader, `out=`) puts it: in
+    # the input buffers of the captured step, so the step does not copy it again
     x, truth = x_fresh, truth_fresh
     bufs = model.input_buffers(x.shape, truth.shape)
     if bufs is not None:
         bufs[0].copy_(x)
         bufs[1].copy_(truth)
+    if bufs is not None and not ref_semantics:
         x, truth = bufs
     if hasattr(model, "allreduce_events"):
         model.allreduce_events.clear()
@@ -675,8 +766,9 @@ def main():
                                "(BASELINE config 2 at the reference's only channel count), batch 16 x 3x48x48 "
                                "-> 3x192x192 per GPU, fp32",
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
-                   "inputs": "resident in the captured step's input buffers" if bufs is not None else "resident in HBM",
-                   "loss_sync_per_step": bool(a.sync_loss), "hip_graph": bool(model.use_hip_graph),
+                   "inputs": ("fresh device tensors handed to train_step_larva every step (copied into the captured step's inputs)"
+                              if ref_semantics or bufs is None else "resident in the captured step's input buffers"),
+                   "loss_sync_per_step": bool(ref_semantics), "hip_graph": bool(model.use_hip_graph),
                    "dual_chain": bool(model.dual_chain), "hip_graph_fell_back": model.hip_graph_fell_back,
                    "final_loss": final_loss},
         "rounds": {"n": rounds, "steps_each": a.steps, "ms_per_step_median": ms_per_step,
@@ -688,17 +780,24 @@ def main():
         line["dist_backend"] = td.get_backend()
         line["allreduce_exposed_us"] = exposed
 
+    # the whole step against the fp32 matrix peak: the only fraction tied to the driver-timed number
+    flop_step = (2 * sum(BLOCKS) + 2 * len(BLOCKS)) * 3 * conv_flop(CH) + 2 * (2 * 9 * 3 * CH * BATCH * PATCH * PATCH)
+    line["step"] = {"flop_per_step": flop_step, "achieved": flop_step / (ms_per_step * 1e-3) / 1e12, "unit": "TFLOP/s",
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "frac_of_peak": flop_step / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    "what": "SURVEY 8(d): forward 40 C->C convs + head, backward dgrad + wgrad per C->C conv + the head's wgrad "
+                            "(elementwise work excluded) over the timed ms_per_step of one rank"}
+
     extras = world == 1 and not a.no_extras
-    if extras:
-        # the reference's per-step behaviour: a fresh batch handed over (copied into the step's
-        # inputs) and loss.item() -- a host sync -- every step (models/LarvaNet.py:139)
+    if extras and ref_semantics and bufs is not None:
+        # round 2's headline, now an extra: no per-step loss.item() (the loss comes back as a device scalar) and the
+        # batch already resident in the captured step's input buffers (what dataloaders/device_patch_loader does)
+        model.sync_loss = False
+        secs2, _ = timed_rounds(model, args, val, bufs[0], bufs[1], a.steps, min(rounds, 3), False)
         model.sync_loss = True
-        secs2, _ = timed_rounds(model, args, val, x_fresh, truth_fresh, a.steps, min(rounds, 3), False)
-        model.sync_loss = bool(a.sync_loss)
         ms2 = float(np.median([s / a.steps * 1e3 for s in secs2]))
-        line["value_sync_loss"] = {"value": HR_PIX_PER_BATCH / (ms2 * 1e-3) / 1e6, "unit": "HR Mpixels/s",
-                                   "ms_per_step": ms2, "what": "loss.item() every step + fresh device tensors "
-                                   "copied into the step's inputs (the reference's hand-over, models/LarvaNet.py:139)"}
+        line["value_async_resident"] = {"value": HR_PIX_PER_BATCH / (ms2 * 1e-3) / 1e6, "unit": "HR Mpixels/s", "ms_per_step": ms2,
+                                        "what": "--async_loss loop: loss returned as a device scalar, batch written straight into "
+                                                "the captured step's input buffers by a device-side producer"}
 
     # inference forward (extra information)
     with torch.no_grad():
@@ -739,7 +838,11 @@ def main():
         c32 = roofline_block(dev, 32, full=False, dual=True)     # two half-batch strip chains, like the 48-channel layer
         line["roofline_c32"] = c32 if c32 is not None else roofline_block(dev, 32, full=False)
         line["roofline_c32_single_chain"] = roofline_block(dev, 32, full=False)
-        line["roofline_c64"] = roofline_block(dev, 64, full=False)
+        c64 = roofline_block(dev, 64, full=False, dual=True)
+        line["roofline_c64"] = c64 if c64 is not None else roofline_block(dev, 64, full=False)
+        line["roofline_c64_single_chain"] = roofline_block(dev, 64, full=False)
+        line["roofline_wgrad_c32"] = wgrad_block(dev, 32)
+        line["roofline_wgrad_c64"] = wgrad_block(dev, 64)
         del model
         line["infer_full_image"] = full_image_block(dev)
     if world == 1 and not a.no_cpu_baseline:

@@ -258,18 +258,21 @@ int larva_pixel_unshuffle4(const float* in, float* out, int N, int C, int H, int
  * (1/world_size after a sum all-reduce).  Buffers that are all 16-byte aligned are walked 16 bytes per lane
  * (any n; the tail is element-wise), others element-wise; the values are the same either way. */
 int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* step_lr,
-                     float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                     double beta1, double beta2, double eps, double weight_decay, float grad_scale,
                      long long n, void* stream);
 
-/* The same update with step (1-based) and lr from the host; 1 - beta^step is then computed on the host in
- * double, as torch.optim.AdamW does. */
-int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
-                          float beta2, float eps, float weight_decay, float grad_scale, long long n,
+/* The same update with step (1-based) and lr from the host.  The hyper-parameters are DOUBLES, as torch.optim.AdamW's
+ * are (Python floats): 1 - beta^step, lr / (1 - beta1^step), 1 - lr * weight_decay, 1 - beta1 and 1 - beta2 are
+ * computed in double and rounded to float once, exactly the scalars ATen's kernels receive (in float arithmetic
+ * 1.f - 0.999f is 0.00100004673, not 0.001f).  The kernel follows torch's single-tensor step operation by operation:
+ * against torch 2.10 on the CPU the moments are bit-identical, the parameters on all but ~0.1 % of the elements (1 ulp). */
+int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, float grad_scale, long long n,
                           void* stream);
 /* larva_adamw_step_host that also copies one float, copy_dst[0] = copy_src[0] (both may be NULL): the step's
  * loss out of the captured graph's static buffer into a tensor the caller keeps (models/LarvaNet.py:139). */
-int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, float grad_scale, long long n,
+int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int step, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, float grad_scale, long long n,
                                const float* copy_src, float* copy_dst, void* stream);
 
 /* ---- device-resident patch sampler ----------------------------------------------------------

@@ -47,6 +47,9 @@
 #ifndef LARVA_PIXEL_MAJOR
 #define LARVA_PIXEL_MAJOR 1   // 0: channel-major accumulators in every epilogue (A/B timing)
 #endif
+#ifndef LARVA_AUX_LDS
+#define LARVA_AUX_LDS 1   // 0: the strip kernel's mask / residual operands as per-lane global loads in the prologue (A/B timing)
+#endif
 #ifndef LARVA_OPERAND_DEPTH
 #define LARVA_OPERAND_DEPTH 2   // k-steps between an operand's LDS read and the MFMAs that use it (A/B: 1)
 #endif
@@ -64,12 +67,34 @@ namespace larva {
 
 #if defined(LARVA_DIAG) && (LARVA_DIAG & 32)
 __device__ unsigned long long* g_stamps = nullptr;
+#if LARVA_DIAG & 512
+// bit 9 (512, with bit 5): per-LAUNCH stamp areas for a whole graph of launches (tools/diag_overlap.py: which
+// workgroups of the two half-batch chains are resident together?).  Every launch built while a slot counter is
+// armed (larva_diag_arm_slots) takes the next area of kDiagWgPerSlot x 8 stamps: [0] kernel entry, [1] chunk 0
+// landed, [2] K loop done, [3] stores drained (100 MHz wall clock), [4] HW_ID | XCC_ID << 32 of wave 0.
+constexpr int kDiagWgPerSlot = 256;
+__device__ int g_slot_of_launch = 0;   // (unused on the device: the slot travels in ConvArgs)
+__device__ __forceinline__ void stamp_slot(int slot, int k) {
+  if (!g_stamps || threadIdx.x != 0 || slot < 0 || blockIdx.x >= kDiagWgPerSlot) return;
+  const int idx = k == 0 ? 0 : k == 2 ? 1 : k == 3 ? 2 : k == 5 ? 3 : -1;
+  if (idx < 0) return;
+  unsigned long long* p = g_stamps + ((size_t)slot * kDiagWgPerSlot + blockIdx.x) * 8;
+  p[idx] = __builtin_amdgcn_s_memrealtime();
+  if (k == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    p[4] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
+}
+#define stamp(k) stamp_slot(a.diag_slot, (k))
+#else
 __device__ __forceinline__ void stamp(int k) {
   // bit 6 (64): stamps in SHADER-CLOCK cycles (s_memtime) instead of the 100 MHz wall clock: the two runs
   // together give the clock the kernel actually ran at (tools/diag_conv.py --timeline --clock)
   if (g_stamps && threadIdx.x == 0)
     g_stamps[blockIdx.x * 16 + k] = (LARVA_DIAG & 64) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
 }
+#endif
 #else
 __device__ __forceinline__ void stamp(int) {}
 #endif
@@ -133,6 +158,9 @@ struct ConvArgs {
   // as one 64-bit multiply + shift (a runtime integer division is ~40 vector instructions, three of
   // them stood at the very start of every workgroup); exact while dividend * divisor < 2^40
   unsigned long long magic_tx, magic_ty, magic_cps;
+#if LARVA_DIAG & 512
+  int diag_slot;              // stamp area of this launch (-1: none)
+#endif
 };
 
 __host__ __device__ __forceinline__ unsigned long long div_magic(int d) { return ((1ull << 40) + d - 1) / (unsigned)d; }
@@ -184,6 +212,22 @@ struct ConvCfg {
   static constexpr int RW_SLOTS = W_USED / 4;
   static constexpr int RW_ITERS = (RW_SLOTS + 255) / 256;
   static_assert(kCh * PS <= IN_FLOATS, "input planes must fit their pieces");
+};
+
+// Epilogue operands through LDS (strip tiles, round 3).  The mask / residual operands of a tile -- COUT channels x
+// ROWS rows x 16 pixels, 15 KiB at 48 channels x 5 rows -- used to be per-lane global loads in the MFMA waves'
+// prologue: older than the first chunk's pieces, so the K loop could not start before they had come in from HBM,
+// and held in up to 32 VGPRs through the whole loop.  Now the loader wave streams them by LDS-DMA into the ring
+// stages the last two chunks leave free (where it used to re-stream the last chunk as filler), and the epilogue
+// reads them from LDS after one more barrier.  Layout: [channel][row][16] floats, channels CHS = ROWS * 16 + 4
+// floats apart (the 16 lanes of a ds_read_b128 group read 16 different channels).
+template <int COUT, typename G>
+struct AuxTile {
+  static constexpr int CHS = G::ROWS * 16 + 4;
+  static constexpr int SLOTS = COUT * CHS / 4;                 // 16-byte slots
+  static constexpr int PIECES = (SLOTS + 63) / 64;
+  static_assert(G::COLS == 16, "epilogue operands in LDS: strip tiles only");
+  static_assert(PIECES <= ConvCfg<COUT, G>::PIECES, "an operand tile must fit the pieces of one ring stage");
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -297,12 +341,32 @@ __device__ __forceinline__ void make_loader_plan(const ConvArgs& a, int lane, in
   }
 }
 
-template <int COUT, typename G>
-__device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int lane, int n, int y0, int x0) {
+template <int COUT, typename G, int NAUXL = 0>
+__device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int lane, int n, int y0, int x0,
+                                           const float* aux0 = nullptr, const float* aux1 = nullptr) {
   using C = ConvCfg<COUT, G>;
   if constexpr ((LARVA_DIAG & 256) != 0) return;   // (no barriers to meet the MFMA waves at)
   LoaderPlan<COUT, G> pl;
   make_loader_plan<COUT, G>(a, lane, y0, x0, pl);
+  // NAUXL > 0: this lane's source offsets of the epilogue operands' tile (AuxTile; the same for every operand)
+  constexpr int AUXP = NAUXL > 0 ? (COUT * (G::ROWS * 16 + 4) / 4 + 63) / 64 : 1;
+  unsigned aoff[AUXP];
+  i32x4 arsrc[NAUXL > 0 ? NAUXL : 1];
+  if constexpr (NAUXL > 0) {
+    using T = AuxTile<COUT, G>;
+#pragma unroll
+    for (int p = 0; p < T::PIECES; ++p) {
+      const int f = 4 * (p * 64 + lane);                      // float offset of the slot in the LDS tile
+      const int ch = f / T::CHS, within = f - ch * T::CHS;
+      const int row = within >> 4, q = (within & 15) >> 2;
+      const int gy = y0 + row, gx = x0 + 4 * q;
+      const bool ok = ch < COUT && within < G::ROWS * 16 && gy < a.H && gx < a.pitch;
+      aoff[p] = ok ? 4u * (unsigned)((ch * a.H + gy) * a.pitch + gx) : kDmaZero;
+    }
+    const size_t img = (size_t)n * COUT * ((size_t)a.H * a.pitch);
+    arsrc[0] = dma_rsrc(aux0 + img);
+    if constexpr (NAUXL > 1) arsrc[1] = dma_rsrc(aux1 + img);
+  }
   const int last = a.n_chunks - 1;
   int stage = 0;
   for (int chunk = 0; chunk <= last; ++chunk) {
@@ -310,18 +374,38 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
     // itself (chunks 0 and 1 come from the MFMA waves, which wait for them on their side)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PIECES) : "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // past the end the last chunk is streamed again into a stage nobody reads: every wait stays
-    // the same counted vmcnt(PIECES)
-    const ChunkSrc cs = chunk_src<COUT, G>(a, min(chunk + 2, last), n);
     const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
     const unsigned dst = lds_addr_of(smem + nstage * C::STAGE_FLOATS);
+    if (NAUXL > 0 && chunk + 2 > last) {
+      // past the end of K: the stage chunk - 1 has vacated takes operand (chunk + 1 - last) of the epilogue --
+      // res0 / mask while the last-but-one chunk multiplies, res1 during the last one.  Exactly PIECES
+      // operations like every other turn (the counted waits stay the same): the surplus pieces are all-zero
+      // writes, which fetch nothing.
+      const int which = chunk + 1 - last;
+      const bool have = which < NAUXL;   // (one operand only: the last turn writes nothing but zeros)
+      i32x4 rs = arsrc[0];
+      if constexpr (NAUXL > 1) {
+        if (which == 1) rs = arsrc[1];
+      }
 #pragma unroll
-    for (int p = 0; p < C::PIECES; ++p)
-      lds_dma16_buf(p < C::IN_PIECES ? cs.img : cs.wgt, pl.voff[p], 0, dst + 1024u * (unsigned)p);
+      for (int p = 0; p < C::PIECES; ++p)
+        lds_dma16_buf(rs, (p < AUXP && have) ? aoff[p < AUXP ? p : 0] : kDmaZero, 0, dst + 1024u * (unsigned)p);
+    } else {
+      // past the end the last chunk is streamed again into a stage nobody reads: every wait stays
+      // the same counted vmcnt(PIECES)
+      const ChunkSrc cs = chunk_src<COUT, G>(a, min(chunk + 2, last), n);
+#pragma unroll
+      for (int p = 0; p < C::PIECES; ++p)
+        lds_dma16_buf(p < C::IN_PIECES ? cs.img : cs.wgt, pl.voff[p], 0, dst + 1024u * (unsigned)p);
+    }
     stage = stage == 2 ? 0 : stage + 1;
   }
-  // no LDS-DMA may be in flight when the workgroup's LDS is released
+  // no LDS-DMA may be in flight when the workgroup's LDS is released -- and with operands in LDS the MFMA waves
+  // wait at one more barrier for them to have landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (NAUXL > 0) {
+    asm volatile("s_barrier" ::: "memory");
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -515,10 +599,12 @@ __device__ __forceinline__ void wait_and_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int COUT, typename G, bool VEC, int EPI, int NCT, int PG0, int NPG>
+template <int COUT, typename G, bool VEC, int EPI, int NCT, int PG0, int NPG, bool AUXLDS = false>
 __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0, int wave, int n, int y0,
                                          int x0, int tid) {
   using C = ConvCfg<COUT, G>;
+  static_assert(!AUXLDS || (VEC && C::LOADER && LARVA_PIXEL_MAJOR && (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2)),
+                "epilogue operands in LDS: the loader-wave path's mask / residual epilogues");
   const int lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
 
@@ -551,8 +637,9 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   // the first counted wait of the ring covers them too.
   constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiShuffleBase)
                            ? 1 : ((EPI == kEpiRes2 || EPI == kEpiShuffleL1) ? 2 : 0);
-  f32x4 aux[NAUX > 0 ? NAUX : 1][NCT][NPG];
+  f32x4 aux[(NAUX > 0 && !AUXLDS) ? NAUX : 1][(NAUX > 0 && !AUXLDS) ? NCT : 1][(NAUX > 0 && !AUXLDS) ? NPG : 1];
   auto load_aux = [&]() {
+    if constexpr (AUXLDS) return;   // (the loader wave streams them into LDS during the last chunks)
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -594,6 +681,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   for (int c = 0; c < NCT; ++c)
 #pragma unroll
     for (int p = 0; p < NPG; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 auxl[AUXLDS ? NAUX : 1][AUXLDS ? NCT : 1][AUXLDS ? NPG : 1];   // (filled after the K loop, from LDS)
 
   if constexpr (VEC) {
     // ---- LDS-DMA ring: chunk c lives in stage c % 3; chunks c+1 and c+2 are in flight --------
@@ -659,6 +747,24 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     }
     // no LDS-DMA may be in flight when the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (AUXLDS) {
+      // the epilogue's operands: streamed by the loader wave into the two stages behind the last chunk's --
+      // stage `stage` (res0 / mask, issued two chunks ago) and the one after it (res1, one chunk ago) -- and
+      // complete once the loader has passed this barrier too
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      using T = AuxTile<COUT, G>;
+      const float* t0 = smem + stage * C::STAGE_FLOATS;
+      const float* t1 = smem + (stage == 2 ? 0 : stage + 1) * C::STAGE_FLOATS;
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int p = 0; p < NPG; ++p) {
+          const int off = ((ct0 + c) * 16 + lr) * T::CHS + (PG0 + p) * 16 + lq * 4;   // (strip tiles: pixel group = row)
+          auxl[0][c][p] = *reinterpret_cast<const f32x4*>(t0 + off);
+          if constexpr (NAUX > 1) auxl[1][c][p] = *reinterpret_cast<const f32x4*>(t1 + off);
+        }
+    }
     stamp(3);
   } else {
     // ---- register staging, 2 stages ------------------------------------------------------------
@@ -692,7 +798,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     return;
   }
 
-  if constexpr (NAUX > 0 && !LARVA_AUX_EARLY) load_aux();
+  if constexpr (NAUX > 0 && !LARVA_AUX_EARLY && !AUXLDS) load_aux();
 
   // Epilogue.  Lane (lr, lq) holds, in acc[c][p][r], output channel (ct0+c)*16 + lq*4 + r of
   // pixel (y0 + pg/3, x0 + (pg%3)*16 + lr).
@@ -763,9 +869,15 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
             for (int r = 0; r < 4; ++r) {
               float o = v[r];
               if constexpr (EPI == kEpiRelu) o = fmaxf(o, 0.f);
-              if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
-              if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
-              if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
+              if constexpr (AUXLDS) {
+                if constexpr (EPI == kEpiMask) o = (auxl[0][c][p][r] > 0.f) ? o : 0.f;
+                if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += auxl[0][c][p][r];
+                if constexpr (EPI == kEpiRes2) o += auxl[1][c][p][r];
+              } else {
+                if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
+                if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
+                if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
+              }
               v[r] = (xb + r < a.W) ? o : 0.f;   // columns [W, pitch) are kept at zero for the next layer
             }
             if constexpr (kPlain) *reinterpret_cast<f32x4*>(a.out + idx) = v;
@@ -894,30 +1006,38 @@ template <int COUT, int EPI, typename G>
 __device__ __forceinline__ void strip_roles(const ConvArgs& a, float* smem, int wave, int n, int y0, int x0, int tid) {
   static_assert(ConvCfg<COUT, G>::LOADER, "the strip kernel is launched with a loader wave");
   static_assert(COUT == 48 || COUT == 32, "strip tiles: 48 or 32 output channels");
+  // mask / residual operands come through LDS (AuxTile): needs the two past-the-end turns of the loader, i.e.
+  // n_chunks >= 2, which the host checks
+  constexpr bool AL = LARVA_AUX_LDS && LARVA_PIXEL_MAJOR && LARVA_AUX_EARLY && !(LARVA_DIAG & 6) &&
+                      (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2);
   if (wave == 4) {
-    run_loader<COUT, G>(a, smem, tid & 63, n, y0, x0);
+    if constexpr (!AL) run_loader<COUT, G>(a, smem, tid & 63, n, y0, x0);
+    else if constexpr (EPI == kEpiMask) run_loader<COUT, G, 1>(a, smem, tid & 63, n, y0, x0, a.mask);
+    else if constexpr (EPI == kEpiRes1) run_loader<COUT, G, 1>(a, smem, tid & 63, n, y0, x0, a.res0);
+    else run_loader<COUT, G, 2>(a, smem, tid & 63, n, y0, x0, a.res0, a.res1);
     return;
   }
   if constexpr (COUT == 48) {
     // ROWS pixel groups x 3 cout groups: waves 0..2 own one cout group x the first ROWS-1 pixel groups, wave 3
     // all three cout groups of the last pixel group (15 units -> 4,4,4,3; 12 -> 3,3,3,3)
-    if (wave < 3) run_role<COUT, G, true, EPI, 1, 0, G::ROWS - 1>(a, smem, wave, wave, n, y0, x0, tid);
-    else run_role<COUT, G, true, EPI, 3, G::ROWS - 1, 1>(a, smem, 0, wave, n, y0, x0, tid);
+    if (wave < 3) run_role<COUT, G, true, EPI, 1, 0, G::ROWS - 1, AL>(a, smem, wave, wave, n, y0, x0, tid);
+    else run_role<COUT, G, true, EPI, 3, G::ROWS - 1, 1, AL>(a, smem, 0, wave, n, y0, x0, tid);
   } else if constexpr (G::ROWS == 5) {
     // 32 channels, 5 pixel groups x 2 cout groups = 10 units -> 3,3,2,2
-    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 3>(a, smem, wave, wave, n, y0, x0, tid);
-    else if (wave == 2) run_role<COUT, G, true, EPI, 2, 3, 1>(a, smem, 0, wave, n, y0, x0, tid);
-    else run_role<COUT, G, true, EPI, 2, 4, 1>(a, smem, 0, wave, n, y0, x0, tid);
+    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 3, AL>(a, smem, wave, wave, n, y0, x0, tid);
+    else if (wave == 2) run_role<COUT, G, true, EPI, 2, 3, 1, AL>(a, smem, 0, wave, n, y0, x0, tid);
+    else run_role<COUT, G, true, EPI, 2, 4, 1, AL>(a, smem, 0, wave, n, y0, x0, tid);
   } else {
     // 32 channels, 4 pixel groups x 2 cout groups = 8 units -> 2,2,2,2
-    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 2>(a, smem, wave, wave, n, y0, x0, tid);
-    else run_role<COUT, G, true, EPI, 1, 2, 2>(a, smem, wave - 2, wave, n, y0, x0, tid);
+    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 2, AL>(a, smem, wave, wave, n, y0, x0, tid);
+    else run_role<COUT, G, true, EPI, 1, 2, 2, AL>(a, smem, wave - 2, wave, n, y0, x0, tid);
   }
 }
 
 template <int COUT, int EPI>
 __global__ __launch_bounds__(320, 2) void conv3x3_mfma_strip_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  stamp(0);
   fetch_args(a);
   const int tile = xcd_remap(blockIdx.x, a.nwg);
   const int n = div_by_magic(tile, a.magic_tx);   // tiles_x = tiles per image
@@ -1241,6 +1361,22 @@ int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout,
   return larva_pack_weights_batch(&w, &wpk_fwd, &wpk_bwd, &cout, &cin, &w_cin_total, &w_cin_off, 1, stream);
 }
 
+#if LARVA_DIAG & 512
+static int g_diag_next_slot = -1, g_diag_slot_cap = 0;
+static int diag_take_slot() {
+  if (g_diag_next_slot < 0 || g_diag_next_slot >= g_diag_slot_cap) return -1;
+  return g_diag_next_slot++;
+}
+// Arm the per-launch stamp areas: launches built from now on take slots first, first + 1, ... < cap (first < 0: off).
+// Returns the next slot that would be handed out.
+int larva_diag_arm_slots(int first, int cap) {
+  const int was = g_diag_next_slot;
+  g_diag_next_slot = first;
+  g_diag_slot_cap = cap;
+  return was;
+}
+#endif
+
 // Fused 3x3 convolution.  `src` is an array of `n_src` device pointers (channel concatenation,
 // each tensor [N][cin_per_src][H][W]); `wpk` a packed weight image from larva_pack_weights for
 // (cout, n_src*cin_per_src).  Epilogue, in this order: relu -> mask -> +res0 -> +res1 -> store
@@ -1257,6 +1393,9 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
   if ((long long)cin_per_src * H * pitch >= (1ll << 31)) return (int)hipErrorInvalidValue;  // 32-bit lane offsets
   if (!wpk || !out) return (int)hipErrorInvalidValue;
   a = ConvArgs{};
+#if LARVA_DIAG & 512
+  a.diag_slot = diag_take_slot();
+#endif
   aligned = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(wpk) & 15) == 0);
   for (int i = 0; i < n_src; ++i) {
     if (!src[i]) return (int)hipErrorInvalidValue;
@@ -1483,6 +1622,10 @@ static int strips_dispatch(const float* const* src, int n_src, int cin_per_src, 
   if (rc) return rc;
   if (!aligned) return (int)hipErrorNotSupported;
   if ((long long)N * tiles_per_image >= (1ll << 20)) return (int)hipErrorInvalidValue;  // div_by_magic range
+  if (LARVA_AUX_LDS && (epi == kEpiMask || epi == kEpiRes1 || epi == kEpiRes2)) {
+    // the loader wave streams the epilogue's operands during its two past-the-end turns (32-bit lane offsets)
+    if (a.n_chunks < 2 || (long long)cout * H * pitch >= (1ll << 29)) return (int)hipErrorNotSupported;
+  }
   a.tile_tab = tile_tab;
   a.plain_stores = plain_stores ? 1 : 0;
   a.tiles_x = tiles_per_image;

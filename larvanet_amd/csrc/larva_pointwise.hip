@@ -361,25 +361,37 @@ struct AdamwCoef {   // per-step scalars of torch.optim.AdamW: step_size = lr / 
   float step_size, bc2_sqrt, decay;
 };
 
-__device__ __forceinline__ AdamwCoef adamw_coef_device(float step, float lr, float beta1, float beta2, float wd) {
-  const float bc1 = 1.f - powf(beta1, step);
-  const float bc2 = 1.f - powf(beta2, step);
-  return AdamwCoef{lr / bc1, sqrtf(bc2), 1.f - lr * wd};
+__device__ __forceinline__ AdamwCoef adamw_coef_device(float step, float lr, double beta1, double beta2, float wd) {
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  return AdamwCoef{(float)((double)lr / bc1), (float)sqrt(bc2), (float)(1.0 - (double)lr * (double)wd)};
 }
 
-// (Explicit roundings: the 16-byte walk and the element-wise walk must give the same bits whatever the compiler
-// would contract in each.)
+// A value the compiler must materialise: keeps a product from being contracted into the sum that consumes it
+// (hipcc's default is -ffp-contract=fast, and `#pragma clang fp contract(off)` did not survive the inlining here).
+__device__ __forceinline__ float rounded(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// torch.optim.AdamW's single-tensor step, operation by operation, every product and sum rounded where ATen's CPU
+// kernels (AVX2 build) round them, so the 16-byte walk and the element-wise walk also give the same bits.  Against
+// torch 2.10 on the CPU the moments come out bit for bit and the parameters on all but ~0.1 % of the elements
+// (1 ulp; emulated in numpy in round 3 and tested on the device):
+//   param.mul_(1 - lr * wd); exp_avg.lerp_(grad, 1 - beta1)            [lerp: fma(weight, end - start, start)]
+//   exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)        [fma(value * t1, t2, self)]
+//   denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)       [a division, then the add]
+//   param.addcdiv_(exp_avg, denom, value=-step_size)                    [self + (value * t1) / t2]
+struct AdamwBetas {   // beta2, and 1 - beta1 / 1 - beta2 computed in DOUBLE like torch's Python code, then rounded: 0.1f and
+  float beta2, omb1, omb2;   // 0.001f -- in float arithmetic 1.f - 0.9f is 0.100000024 and 1.f - 0.999f is 0.00100004673
+};
+
 __device__ __forceinline__ void adamw_update(float& param, float& mi, float& vi, float grad, const AdamwCoef& c,
-                                             float beta1, float beta2, float eps) {
-  // torch.optim.AdamW's single-tensor step, operation by operation (each separately rounded where ATen's is):
-  //   param.mul_(1 - lr * wd); exp_avg.lerp_(grad, 1 - beta1)            [lerp: fma(weight, end - start, start)]
-  //   exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)        [self + (value * t1) * t2]
-  //   denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)       [a division, then the add]
-  //   param.addcdiv_(exp_avg, denom, value=-step_size)                    [self + (value * t1) / t2]
-  mi = __fmaf_rn(1.f - beta1, __fsub_rn(grad, mi), mi);
-  vi = __fadd_rn(__fmul_rn(vi, beta2), __fmul_rn(__fmul_rn(1.f - beta2, grad), grad));
-  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), c.bc2_sqrt), eps);
-  param = __fadd_rn(__fmul_rn(param, c.decay), __fdiv_rn(__fmul_rn(-c.step_size, mi), denom));
+                                             const AdamwBetas& b, float eps) {
+  mi = __fmaf_rn(b.omb1, rounded(grad - mi), mi);
+  vi = __fmaf_rn(rounded(b.omb2 * grad), grad, rounded(vi * b.beta2));   // (ATen's AVX2 addcmul: the last product is fused)
+  const float denom = rounded(__fdiv_rn(__fsqrt_rn(vi), c.bc2_sqrt)) + eps;
+  param = rounded(param * c.decay) + rounded(__fdiv_rn(rounded(-c.step_size * mi), denom));
 }
 
 // step_lr != null: {step count as float, lr} live on the device (a captured graph can be replayed) and the
@@ -387,11 +399,12 @@ __device__ __forceinline__ void adamw_update(float& param, float& mi, float& vi,
 // torch does) and the flat buffers are walked 16 bytes per lane.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
-                                                    const float* __restrict__ step_lr, AdamwCoef coef, float beta1,
-                                                    float beta2, float eps, float wd, float gscale, long long n, int vec,
+                                                    const float* __restrict__ step_lr, AdamwCoef coef, double beta1,
+                                                    double beta2, float eps, float wd, float gscale, long long n, int vec,
                                                     const float* __restrict__ copy_src, float* __restrict__ copy_dst) {
   if (copy_dst && blockIdx.x == 0 && threadIdx.x == 0) copy_dst[0] = copy_src[0];   // (the step's loss: see the launcher)
   if (step_lr) coef = adamw_coef_device(step_lr[0], step_lr[1], beta1, beta2, wd);
+  const AdamwBetas bt{(float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2)};
   const long long n4 = vec ? n >> 2 : 0;   // (vec: all four buffers are 16-byte aligned)
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i], mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float pe = pp[e], me = mm[e], ve = vv[e];
-      adamw_update(pe, me, ve, __fmul_rn(gg[e], gscale), coef, beta1, beta2, eps);
+      adamw_update(pe, me, ve, __fmul_rn(gg[e], gscale), coef, bt, eps);
       pp[e] = pe; mm[e] = me; vv[e] = ve;
     }
     reinterpret_cast<f32x4*>(p)[i] = pp;
@@ -409,7 +422,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     float pp = p[i], mm = m[i], vv = v[i];
-    adamw_update(pp, mm, vv, __fmul_rn(g[i], gscale), coef, beta1, beta2, eps);
+    adamw_update(pp, mm, vv, __fmul_rn(g[i], gscale), coef, bt, eps);
     p[i] = pp; m[i] = mm; v[i] = vv;
   }
 }
@@ -692,24 +705,24 @@ int larva_pixel_unshuffle4(const float* in, float* out, int N, int C, int H, int
   return (int)hipGetLastError();
 }
 
-int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* step_lr, float beta1,
-                     float beta2, float eps, float weight_decay, float grad_scale, long long n,
+int larva_adamw_step(float* p, const float* g, float* m, float* v, const float* step_lr, double beta1,
+                     double beta2, double eps, double weight_decay, float grad_scale, long long n,
                      void* stream) {
   if (!p || !g || !m || !v || !step_lr || n <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     step_lr, AdamwCoef{}, beta1, beta2, eps, weight_decay, grad_scale, n, adamw_vec_ok(p, g, m, v),
+                     step_lr, AdamwCoef{}, beta1, beta2, (float)eps, (float)weight_decay, grad_scale, n, adamw_vec_ok(p, g, m, v),
                      (const float*)nullptr,
                      (float*)nullptr);
   return (int)hipGetLastError();
 }
 
-int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, float grad_scale, long long n,
+int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int step, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, float grad_scale, long long n,
                                const float* copy_src, float* copy_dst, void* stream);
 
 // Same update with the step count (1-based) and learning rate passed from the host.
-int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
-                          float beta2, float eps, float weight_decay, float grad_scale, long long n,
+int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, float grad_scale, long long n,
                           void* stream) {
   return larva_adamw_step_host_copy(p, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale, n, nullptr, nullptr,
                                     stream);
@@ -718,15 +731,16 @@ int larva_adamw_step_host(float* p, const float* g, float* m, float* v, int step
 // larva_adamw_step_host that also copies ONE float (copy_dst[0] = copy_src[0]) -- the step's loss out of the
 // captured graph's static buffer into a tensor of the caller's (models/LarvaNet.py:139 returns the loss):
 // saves the 4-byte device-to-device copy launch.
-int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int step, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, float grad_scale, long long n,
+int larva_adamw_step_host_copy(float* p, const float* g, float* m, float* v, int step, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, float grad_scale, long long n,
                                const float* copy_src, float* copy_dst, void* stream) {
   if (!p || !g || !m || !v || n <= 0 || step < 1 || (copy_dst && !copy_src)) return (int)hipErrorInvalidValue;
-  // the per-step scalars in double, like torch.optim.AdamW computes them on the host
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const AdamwCoef coef{(float)((double)lr / bc1), (float)sqrt(bc2), (float)(1.0 - (double)lr * (double)weight_decay)};
+  // the per-step scalars in double, like torch.optim.AdamW computes them on the host (its hyper-parameters are Python
+  // floats = doubles: they arrive here as doubles)
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const AdamwCoef coef{(float)(lr / bc1), (float)sqrt(bc2), (float)(1.0 - lr * weight_decay)};
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     (const float*)nullptr, coef, beta1, beta2, eps, weight_decay, grad_scale, n, adamw_vec_ok(p, g, m, v),
+                     (const float*)nullptr, coef, beta1, beta2, (float)eps, (float)weight_decay, grad_scale, n, adamw_vec_ok(p, g, m, v),
                      copy_src, copy_dst);
   return (int)hipGetLastError();
 }

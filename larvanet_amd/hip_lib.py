@@ -80,8 +80,8 @@ SIGNATURES = {
                                                     _c_int_p, ctypes.c_int, _c_pp, _c_int_p, _c_float_p, ctypes.c_int,
                                                     ctypes.c_float, _c_float_p, ctypes.c_void_p]),
     "larva_adamw_step_host_copy": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
-                                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                                  ctypes.c_float, ctypes.c_float, ctypes.c_longlong, _c_float_p, _c_float_p,
+                                                  ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                                  ctypes.c_double, ctypes.c_float, ctypes.c_longlong, _c_float_p, _c_float_p,
                                                   ctypes.c_void_p]),
     "larva_upsample4_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -112,14 +112,14 @@ SIGNATURES = {
     "larva_pixel_unshuffle4": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_adamw_step_host": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
-                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                             ctypes.c_float, ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p]),
+                                             ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                             ctypes.c_double, ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p]),
     "larva_gather_patches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_sqerr_u8": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "larva_adamw_step": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
-                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                         ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p]),
 }
 

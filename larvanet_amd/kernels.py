@@ -324,26 +324,39 @@ def conv3x3_relu_timed(x, wpk, cout, bias, out, iters):
     return float(mean.value), float(best.value)
 
 
-def conv3x3_relu_strips_timed(x, wpk, cout, bias, out, iters, images=None, phase=0):
-    """Measurement only: (mean_ms, min_ms) of ONE strip-tile conv+ReLU launch over images [lo, hi) running alone,
-    from kernel-attached events -- the figure a profiler reports per dispatch of conv3x3_mfma_strip_kernel."""
+def conv3x3_strips_timed(x, wpk, cout, bias, out, iters, images=None, phase=0, relu=False, mask=None, res0=None, res1=None,
+                         plain_stores=False):
+    """Measurement only: (mean_ms, min_ms) of ONE strip-tile launch over images [lo, hi) running alone, with the
+    epilogue the operands select, from kernel-attached events -- the figure a profiler reports per dispatch of
+    conv3x3_mfma_strip_kernel<cout, EPI>."""
     import ctypes
     lib = hip_lib.load()
     N, cin, H, W = (int(v) for v in x.shape)
     _chk(x, "x")
     _chk(wpk, "wpk", (packed_weight_floats(cout, cin),))
-    _chk(out, "out", (N, cout, H, W))
+    full = (N, cout, H, W)
+    _chk(out, "out", full)
     lo, hi = (0, N) if images is None else images
     tab = strip_tile_table(H, W, out.device, phase=phase)
     if tab is None:
         raise RuntimeError("larvanet_amd: no strip tiling for %d x %d" % (H, W))
+
+    def at(t, name):
+        return None if t is None else _chk(t, name, full) + 4 * lo * cout * H * W
+
     mean, best = ctypes.c_float(0), ctypes.c_float(0)
     code = lib.larva_conv3x3_fwd_strips_timed(
         hip_lib.ptr_array([x.data_ptr() + 4 * lo * cin * H * W]), 1, cin, wpk.data_ptr(), _opt(bias, "bias", (cout,)),
-        None, None, None, None, out.data_ptr() + 4 * lo * cout * H * W, hi - lo, cout, H, W, W, 1, 0, tab[0].data_ptr(),
-        tab[1], 0, _stream(), iters, ctypes.byref(mean), ctypes.byref(best))
+        at(res0, "res0"), at(res1, "res1"), at(mask, "mask"), None, out.data_ptr() + 4 * lo * cout * H * W, hi - lo, cout, H, W, W,
+        1 if relu else 0, 0, tab[0].data_ptr(), tab[1], 1 if plain_stores else 0, _stream(), iters, ctypes.byref(mean),
+        ctypes.byref(best))
     hip_lib.check(code, "larva_conv3x3_fwd_strips_timed")
     return float(mean.value), float(best.value)
+
+
+def conv3x3_relu_strips_timed(x, wpk, cout, bias, out, iters, images=None, phase=0):
+    """conv3x3_strips_timed for the fused conv + bias + ReLU launch."""
+    return conv3x3_strips_timed(x, wpk, cout, bias, out, iters, images=images, phase=phase, relu=True)
 
 
 def wgrad_partial_floats(cout, cin, splits):

