@@ -576,7 +576,27 @@ def cpu_baseline(budget_s=15.0):
             T.forward(fwd_sd, x, BLOCKS)
             ftimes.append(time.perf_counter() - t0)
     fmed = float(np.median(ftimes))
+    # BASELINE configs[0]: EDSR-baseline x4 (64 features, 16 residual blocks), batch 4 of 48x48 LR patches, the
+    # reference's own CPU case (models/edsr.py:75-108 through train.py:83-105) -- oracle/edsr_torch.py, pinned by F15
+    from oracle import edsr_torch as E
+    estep = E.make_trainer(E.init_state_dict(seed=0), 16)
+    ex = torch.rand(4, 3, PATCH, PATCH, generator=torch.Generator().manual_seed(2)) * 255
+    et = torch.rand(4, 3, PATCH * SCALE, PATCH * SCALE, generator=torch.Generator().manual_seed(3)) * 255
+    for _ in range(3):
+        estep(ex, et)
+    etimes = []
+    t_start = time.perf_counter()
+    while len(etimes) < 10 or (time.perf_counter() - t_start < budget_s / 3 and len(etimes) < 30):
+        t0 = time.perf_counter()
+        estep(ex, et)
+        etimes.append(time.perf_counter() - t0)
+    emed = float(np.median(etimes))
+    edsr = {"value": 4 * (PATCH * SCALE) ** 2 / emed / 1e6, "unit": "HR Mpixels/s", "ms_per_step": emed * 1e3,
+            "sample": "%d EDSR.train_step steps after 3 warm-ups (64 features, 16 residual blocks, batch 4 x 3x48x48 -> "
+                      "3x192x192, Adam), BASELINE configs[0]; CPU only: EDSR is not on the hot path and has no HIP kernels"
+                      % len(etimes)}
     return {"value": HR_PIX_PER_BATCH / med / 1e6, "unit": "HR Mpixels/s", "cores": cores, "kind": "port",
+            "edsr_train_step": edsr,
             "sample": "%d train steps after 3 warm-ups (median %.1f ms) of the same M4B4 batch-16 workload, torch %s CPU ops, "
                       "%d threads" % (len(times), med * 1e3, torch.__version__, cores),
             "forward_only": {"value": HR_PIX_PER_BATCH / fmed / 1e6, "unit": "HR Mpixels/s", "ms_per_batch": fmed * 1e3,
@@ -626,10 +646,15 @@ def timed_rounds(model, args, val, x, truth, steps, rounds, dist_on):
             loss = model.train_step_larva(args, val, x, truth)
         barrier_sync(dist_on)
         secs.append(time.perf_counter() - t0)
+    per_rank = None
     if dist_on:
         t = torch.tensor(secs, dtype=torch.float64, device=model.device)
+        every = [torch.empty_like(t) for _ in range(td.get_world_size())]
+        td.all_gather(every, t)
+        per_rank = [[float(v) for v in r.cpu()] for r in every]   # each rank's own wall time of every round
         td.all_reduce(t, op=td.ReduceOp.MAX)
         secs = [float(v) for v in t.cpu()]
+    timed_rounds.per_rank = per_rank
     return secs, loss
 
 
@@ -779,6 +804,14 @@ def main():
         line["rccl_ranks"] = td.get_world_size() if td.get_backend() == "nccl" else 0
         line["dist_backend"] = td.get_backend()
         line["allreduce_exposed_us"] = exposed
+        if getattr(timed_rounds, "per_rank", None):
+            # every rank's own ms_per_step (median round): a straggler or an exposed collective shows here
+            per = [float(np.median([s / a.steps * 1e3 for s in r])) for r in timed_rounds.per_rank]
+            line["ms_per_step_per_rank"] = {"min": min(per), "max": max(per), "ranks": per}
+        line["wgrad_schedule"] = ("data parallel: the deferred weight gradients go out as two launch groups (the layers of the "
+                                  "bucket's upper ~80 %, then the rest + the head), so that the first group's slice is all-reduced "
+                                  "beside the second group's kernels; `dp_schedule_1gpu` in the N = 1 line prices that schedule "
+                                  "without collectives")
 
     # the whole step against the fp32 matrix peak: the only fraction tied to the driver-timed number
     flop_step = (2 * sum(BLOCKS) + 2 * len(BLOCKS)) * 3 * conv_flop(CH) + 2 * (2 * 9 * 3 * CH * BATCH * PATCH * PATCH)
@@ -798,6 +831,30 @@ def main():
         line["value_async_resident"] = {"value": HR_PIX_PER_BATCH / (ms2 * 1e-3) / 1e6, "unit": "HR Mpixels/s", "ms_per_step": ms2,
                                         "what": "--async_loss loop: loss returned as a device scalar, batch written straight into "
                                                 "the captured step's input buffers by a device-side producer"}
+
+    if extras:
+        # The weight-gradient schedule a data-parallel rank runs (two launch groups instead of one flat grid, see
+        # DESIGN section 5) on this one GPU, without collectives: the cost of making the all-reduce overlappable.
+        os.environ["LARVA_FORCE_SPLIT"] = "1"
+        try:
+            m2 = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
+            m2.parse_args(list(FLAGS))
+            torch.manual_seed(0)
+            m2.volume_per_step = PATCH * PATCH * BATCH * 3
+            m2.prepare(is_training=True, scales=[SCALE])
+            m2.sync_loss = ref_semantics
+            for _ in range(max(a.warmup, 1)):
+                m2.train_step_larva(args, val, x_fresh, truth_fresh)
+            secs3, _ = timed_rounds(m2, args, val, x_fresh, truth_fresh, a.steps, min(rounds, 3), False)
+            ms3 = float(np.median([s / a.steps * 1e3 for s in secs3]))
+            line["dp_schedule_1gpu"] = {"ms_per_step": ms3, "value": HR_PIX_PER_BATCH / (ms3 * 1e-3) / 1e6, "unit": "HR Mpixels/s",
+                                        "late_graph": m2._graph_late is not None,
+                                        "what": "the same step with the data-parallel weight-gradient schedule (LARVA_FORCE_SPLIT=1: two "
+                                                "launch groups + two reductions, the second in a graph of its own), no collectives: what a "
+                                                "rank of an N-GPU run computes per step"}
+            del m2
+        finally:
+            os.environ.pop("LARVA_FORCE_SPLIT", None)
 
     # inference forward (extra information)
     with torch.no_grad():

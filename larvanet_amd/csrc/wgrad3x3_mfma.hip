@@ -1092,6 +1092,11 @@ int larva_conv3x3_wgrad_partial(const float* const* dy, const float* const* x, f
   else if (cout == 48 && cin == 16) e = launch_wgrad<48, 16>(b, njobs, splits, s);
   else if (cout == 32 && cin == 32) e = launch_wgrad<32, 32>(b, njobs, splits, s);
   else if (cout == 64 && cin == 64) e = launch_wgrad<64, 64>(b, njobs, splits, s);
+  // --num_filters = 32 / 64 networks: the head (on its 16-channel padded input) and the legs' last conv (48 outputs)
+  else if (cout == 32 && cin == 16) e = launch_wgrad<32, 16>(b, njobs, splits, s);
+  else if (cout == 64 && cin == 16) e = launch_wgrad<64, 16>(b, njobs, splits, s);
+  else if (cout == 48 && cin == 32) e = launch_wgrad<48, 32>(b, njobs, splits, s);
+  else if (cout == 48 && cin == 64) e = launch_wgrad<48, 64>(b, njobs, splits, s);
   else return (int)hipErrorInvalidValue;
   return (int)e;
 }

@@ -35,6 +35,11 @@ from .base import BaseModel
 SUPPORTED_INTERPOLATE = ("bicubic", "bilinear")
 
 NUM_FILTERS = 48  # = 3 * 4**2: PixelShuffle(4) of the leg output must give RGB (models/LarvaNet.py:226,261)
+# --num_filters (build-side extension, SURVEY 8a N1: BASELINE configs 2 / 5 name 32- and 64-channel bodies, which the
+# reference cannot express): the width of the head's output, the bodies and the legs' first conv; every leg's LAST
+# conv keeps 48 outputs, so the exits are still RGB.  48 is the reference's network, bit for bit; other widths have no
+# reference counterpart and are checked against oracle/larva_torch.py only.
+SUPPORTED_NUM_FILTERS = (32, 48, 64)
 
 
 def create_model():
@@ -92,9 +97,9 @@ class ResidualBlock(nn.Module):
 class LarvaHead(nn.Module):
     """models/LarvaNet.py:223-233"""
 
-    def __init__(self):
+    def __init__(self, num_filters=NUM_FILTERS):
         super().__init__()
-        self.feature_extraction = _conv(3, NUM_FILTERS)
+        self.feature_extraction = _conv(3, num_filters)
         init_conv(self.feature_extraction)
         self._pc = PackedConv(self.feature_extraction.weight, self.feature_extraction.bias, cin_pad=16)
 
@@ -108,10 +113,10 @@ class LarvaHead(nn.Module):
 class LarvaLeg(nn.Module):
     """models/LarvaNet.py:251-267"""
 
-    def __init__(self):
+    def __init__(self, num_filters=NUM_FILTERS):
         super().__init__()
-        self.recon_block = nn.Sequential(_conv(NUM_FILTERS, NUM_FILTERS), nn.ReLU(inplace=True),
-                                         _conv(NUM_FILTERS, NUM_FILTERS))
+        self.recon_block = nn.Sequential(_conv(num_filters, num_filters), nn.ReLU(inplace=True),
+                                         _conv(num_filters, NUM_FILTERS))   # 48 = 3 * 4**2 outputs whatever the width
         init_conv(self.recon_block[0])
         init_conv(self.recon_block[2])
         self.upsample = nn.PixelShuffle(4)  # kept for introspection; fused into the conv store
@@ -129,10 +134,10 @@ class LarvaLeg(nn.Module):
 class LarvaBody(nn.Module):
     """models/LarvaNet.py:236-248"""
 
-    def __init__(self, num_blocks):
+    def __init__(self, num_blocks, num_filters=NUM_FILTERS):
         super().__init__()
-        self.res_blocks = nn.Sequential(*[ResidualBlock(NUM_FILTERS) for _ in range(num_blocks)])
-        self.leg = LarvaLeg()
+        self.res_blocks = nn.Sequential(*[ResidualBlock(num_filters) for _ in range(num_blocks)])
+        self.leg = LarvaLeg(num_filters)
         self._pcs = []
         for blk in self.res_blocks:
             self._pcs += [PackedConv(blk.body[0].weight, blk.body[0].bias),
@@ -168,9 +173,12 @@ class LarvaNetModule(nn.Module):
         # inference on widths that are not a multiple of 4: row-padded activations (16-byte LDS-DMA
         # staging) instead of the register-staged conv path; False only to test the latter
         self.pad_odd_widths = True
-        self.head = LarvaHead()
+        self.num_filters = int(getattr(args, "num_filters", NUM_FILTERS))
+        if self.num_filters not in SUPPORTED_NUM_FILTERS:
+            raise ValueError("larvanet_amd: --num_filters must be one of %s" % (SUPPORTED_NUM_FILTERS,))
+        self.head = LarvaHead(self.num_filters)
         for i, nb in enumerate(parse_num_blocks(args)):
-            setattr(self, "body_%d" % i, LarvaBody(num_blocks=nb))
+            setattr(self, "body_%d" % i, LarvaBody(num_blocks=nb, num_filters=self.num_filters))
         self._join_input_grads()
 
     def _join_input_grads(self):
@@ -265,6 +273,9 @@ class LarvaNet(BaseModel):
         self.overlap_allreduce = os.environ.get("LARVA_OVERLAP_ALLREDUCE", "1") != "0"
         # the body chain as two half-batch chains of strip-tile launches on two streams (autograd.DualChain)
         self.dual_chain = os.environ.get("LARVA_DUAL_CHAIN", "1") != "0"
+        # measurement: run the data-parallel step's weight-gradient schedule (two launch groups, so that the first
+        # group's slice of the bucket can be all-reduced beside the second) on ONE GPU, without collectives
+        self.force_split_backward = os.environ.get("LARVA_FORCE_SPLIT", "0") != "0"
 
     # ------------------------------------------------------------------ flags
     def _add_args(self, parser):
@@ -280,6 +291,13 @@ class LarvaNet(BaseModel):
         parser.add_argument("--min_lr", type=float, default=1e-8, help="Minimum learning rate.")
         parser.add_argument("--patience", type=int, default=3, help="Plateau patience.")
         parser.add_argument("--cooldown", type=int, default=6, help="Plateau cooldown.")
+        self._add_build_args(parser)
+
+    def _add_build_args(self, parser):
+        """Flags the reference does not have (build-side extensions; the defaults are the reference's network)."""
+        parser.add_argument("--num_filters", type=int, default=NUM_FILTERS, choices=SUPPORTED_NUM_FILTERS,
+                            help="Channels of the head / bodies / legs (the legs' last conv keeps 48). "
+                                 "The reference hard-wires 48.")
 
     def parse_args(self, args):
         parser = argparse.ArgumentParser()
@@ -451,7 +469,7 @@ class LarvaNet(BaseModel):
         """Data parallel with in-place gradients: backward ends in two halves so that the
         all-reduce of the first overlaps the weight-gradient kernels of the second."""
         bucket = getattr(self, "grad_bucket", None)
-        return (self.overlap_allreduce and self.defer_wgrad and ldist.world_size() > 1
+        return (self.overlap_allreduce and self.defer_wgrad and (ldist.world_size() > 1 or self.force_split_backward)
                 and bucket is not None and bucket.intact(self.model))
 
     def _note_early(self, scope):

@@ -23,18 +23,18 @@ def create_model():
 class LarvaTail(nn.Module):
     """models/LarvaNetV2.py:314-334"""
 
-    def __init__(self, num_modules):
+    def __init__(self, num_modules, num_filters=NUM_FILTERS):
         super().__init__()
-        self.merge_conv = _conv(NUM_FILTERS * num_modules, NUM_FILTERS)
-        self.recon_block = nn.Sequential(_conv(NUM_FILTERS, NUM_FILTERS), nn.ReLU(inplace=True),
-                                         _conv(NUM_FILTERS, NUM_FILTERS))
+        self.merge_conv = _conv(num_filters * num_modules, num_filters)
+        self.recon_block = nn.Sequential(_conv(num_filters, num_filters), nn.ReLU(inplace=True),
+                                         _conv(num_filters, NUM_FILTERS))
         # the reference initialises [recon_block, merge_conv] in that order (:324)
         init_conv(self.recon_block[0])
         init_conv(self.recon_block[2])
         init_conv(self.merge_conv)
         self.upsample = nn.PixelShuffle(4)
         self._pc = PackedConv(self.merge_conv.weight, self.merge_conv.bias,
-                              slices=[(i * NUM_FILTERS, NUM_FILTERS) for i in range(num_modules)])
+                              slices=[(i * num_filters, num_filters) for i in range(num_modules)])
         self._pcs = [PackedConv(self.recon_block[0].weight, self.recon_block[0].bias),
                      PackedConv(self.recon_block[2].weight, self.recon_block[2].bias)]
 
@@ -54,7 +54,7 @@ class LarvaNetModule(V1.LarvaNetModule):
 
     def __init__(self, args):
         super().__init__(args)
-        self.tail = LarvaTail(self.len)
+        self.tail = LarvaTail(self.len, self.num_filters)
 
     def features(self, x):
         fea = self.head(x)
@@ -88,6 +88,7 @@ class LarvaNet(V1.LarvaNet):
         parser.add_argument("--threshold", type=float, default=0.001)
         parser.add_argument("--min_lr", type=float, default=1e-7)
         parser.add_argument("--patience", type=int, default=3)
+        self._add_build_args(parser)
 
     def _make_scheduler(self):
         return torch.optim.lr_scheduler.ReduceLROnPlateau(

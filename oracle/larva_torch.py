@@ -87,8 +87,9 @@ def multi_exit_loss(sd, x, truth, blocks, v2=False, mode="bicubic"):
     return loss / len(blocks)
 
 
-def init_state_dict(blocks, v2=False, seed=None):
-    """Reference initialisation (models/LarvaNet.py:22-31,215,229,260): kaiming_normal_(fan_in,
+def init_state_dict(blocks, v2=False, seed=None, nf=48):
+    """nf: the width of the head / bodies / first leg convs (--num_filters; the reference's is 48, the legs' last conv
+    always has 48 = 3 * 4**2 outputs).  Reference initialisation (models/LarvaNet.py:22-31,215,229,260): kaiming_normal_(fan_in,
     a=0) * 0.1, zero bias, drawn in module-construction order (head, then per body: blocks'
     conv1, conv2 ..., then the leg's two convs; V2: tail.merge_conv is constructed first but
     initialised after tail.recon_block, models/LarvaNetV2.py:317-324)."""
@@ -110,24 +111,24 @@ def init_state_dict(blocks, v2=False, seed=None):
         sd[prefix + ".weight"] *= 0.1
         sd[prefix + ".bias"].zero_()
 
-    conv("head.feature_extraction", 48, 3)
+    conv("head.feature_extraction", nf, 3)
     reinit("head.feature_extraction")
     for i, nb in enumerate(blocks):
         for j in range(nb):
             p = "body_%d.res_blocks.%d.body" % (i, j)
-            conv(p + ".0", 48, 48)
-            conv(p + ".2", 48, 48)
+            conv(p + ".0", nf, nf)
+            conv(p + ".2", nf, nf)
             reinit(p + ".0")
             reinit(p + ".2")
         p = "body_%d.leg.recon_block" % i
-        conv(p + ".0", 48, 48)
-        conv(p + ".2", 48, 48)
+        conv(p + ".0", nf, nf)
+        conv(p + ".2", 48, nf)
         reinit(p + ".0")
         reinit(p + ".2")
     if v2:
-        conv("tail.merge_conv", 48, 48 * len(blocks))
-        conv("tail.recon_block.0", 48, 48)
-        conv("tail.recon_block.2", 48, 48)
+        conv("tail.merge_conv", nf, nf * len(blocks))
+        conv("tail.recon_block.0", nf, nf)
+        conv("tail.recon_block.2", 48, nf)
         reinit("tail.recon_block.0")
         reinit("tail.recon_block.2")
         reinit("tail.merge_conv")

@@ -205,6 +205,38 @@ def main_r3(only):
                  ulp_tube_loss=np.maximum.accumulate(env_loss), ulp_tube_psnr=np.maximum.accumulate(env_psnr),
                  ulp_tube_weights_mean=np.array(env_w), ulp_tube_same_lrs=np.array(lrs_same))
 
+    if "f15" in only:
+        # BASELINE configs[0]: the reference's EDSR through train.py's loop (train.py:83-105: get_next_train_scale,
+        # a batch of lists of CHW arrays, model.train_step(input_list, scale, truth_list, summary)), small width here
+        edsr = importlib.import_module("models.edsr")
+        argv = ["--edsr_conv_features=16", "--edsr_res_blocks=2", "--edsr_learning_rate_decay_steps=2"]
+        model = edsr.create_model()
+        model.parse_args(argv)
+        torch.manual_seed(4)
+        model.prepare(is_training=True, scales=[4])
+        before = sd_to_np(model.model.state_dict())
+        rng = np.random.RandomState(15)
+        xs = [rng.randint(0, 256, size=(3, 12, 12)).astype(np.float32) for _ in range(2)]
+        ts = [rng.randint(0, 256, size=(3, 48, 48)).astype(np.float32) for _ in range(2)]
+        losses, lrs = [], []
+        for step in range(4):
+            scale = model.get_next_train_scale()
+            losses.append(model.train_step(input_list=xs, scale=scale, truth_list=ts, summary=None))
+            lrs.append(model.optim.param_groups[0]["lr"])
+        after = sd_to_np(model.model.state_dict())
+        with torch.no_grad():
+            up = model.upscale(input_list=xs[:1], scale=4)[0]
+        full = edsr.create_model()
+        full.parse_args([])
+        torch.manual_seed(4)
+        full.prepare(is_training=False, scales=[4])
+        full_sd = full.model.state_dict()
+        np.savez(os.path.join(OUT, "f15_edsr_train_steps.npz"), x=np.stack(xs), truth=np.stack(ts),
+                 losses=np.array(losses, np.float64), lrs=np.array(lrs, np.float64), up_sample=up[:, ::3, ::3].copy(),
+                 global_step=np.array(model.global_step), default_keys=np.array(sorted(full_sd)),
+                 default_params=np.array(sum(v.numel() for v in full_sd.values())),
+                 **{"sd." + k: v for k, v in before.items()}, **{"after." + k: v for k, v in after.items()})
+
     if "f14" in only:
         argv = ["--num_modules=4", "--num_blocks=4,4,4,4"]
         x = torch.rand(16, 3, 48, 48, generator=torch.Generator().manual_seed(0)) * 255
@@ -262,7 +294,7 @@ def main():
         main_r2(sys.argv[2:] or ["f11", "f12"])
         return
     if len(sys.argv) > 1 and sys.argv[1] == "r3":
-        main_r3(sys.argv[2:] or ["f13", "f14"])
+        main_r3(sys.argv[2:] or ["f13", "f14", "f15"])
         return
 
     # ---------------- F1/F2: M2B2 weights, staged outputs on a 2x3x12x12 input ----------------

@@ -68,6 +68,12 @@ def test_state_dict_keys_are_the_reference_wire_format():
     v2.prepare(is_training=False, scales=[4])
     sd2 = v2.model.state_dict()
     assert len(sd2) == 88 and sum(v.numel() for v in sd2.values()) == 957264
+    # models/LarvaLegV2.py: V2's parameters and flag defaults (lr 1e-4, val_volume 3e9) plus --leg (default 4)
+    lv2, args, _ = _make("LarvaLegV2", ["--num_modules=4", "--num_blocks=4,4,4,4"])
+    lv2.prepare(is_training=False, scales=[4])
+    assert sorted(lv2.model.state_dict()) == sorted(sd2) and (args.leg, args.lr, args.val_volume) == (4, 1e-4, 3e9)
+    with pytest.raises(ValueError):
+        _make("LarvaLegV2", ["--num_modules=2", "--num_blocks=1,1", "--leg=3"])[0].prepare(is_training=False, scales=[4])
     assert tuple(sd2["tail.merge_conv.weight"].shape) == (48, 192, 3, 3)
 
 

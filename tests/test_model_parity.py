@@ -259,12 +259,16 @@ def test_v2_restore_takes_matching_keys_only(hip_device, tmp_path):
     assert torch.equal(v2.model.tail.merge_conv.weight.cpu(), tail_before)
 
 
-def test_early_exit_plugin_matches_staged_exits(hip_device, golden):
-    """models/LarvaLeg.py: --leg=k returns exit k; k = 0 the bicubic base alone."""
+@pytest.mark.parametrize("plugin", ["LarvaLeg", "LarvaLegV2"])
+def test_early_exit_plugin_matches_staged_exits(hip_device, golden, plugin):
+    """models/LarvaLeg.py:289-300 / models/LarvaLegV2.py:358-367: --leg=k returns exit k; k = 0 the bicubic base alone.
+    (LarvaLegV2 = the V2 network, tail.* parameters included but not evaluated; its trunk draws the same initial
+    weights as V1's under the same seed, so F1's staged exits are its exits too.)"""
     g = golden("f1_m2b2_forward.npz")
     x = [g["x"][0], g["x"][1]]
     for leg, ref in ((0, g["base"]), (1, g["exit_0"]), (2, g["exit_1"])):
-        m = _model("LarvaLeg", ["--num_modules=2", "--num_blocks=2,2", "--leg=%d" % leg])
+        m = _model(plugin, ["--num_modules=2", "--num_blocks=2,2", "--leg=%d" % leg])
+        assert ("tail.merge_conv.weight" in m.model.state_dict()) == (plugin == "LarvaLegV2")
         out = m.upscale(x, 4)
         np.testing.assert_allclose(out, ref, rtol=0, atol=2e-3)
 
@@ -524,3 +528,48 @@ def test_reference_checkpoint_file_restores_and_reproduces_its_outputs(hip_devic
     out = m.save(str(tmp_path))
     back = torch.load(out, map_location="cpu")
     assert sorted(back) == sorted(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+
+
+@pytest.mark.parametrize("name,nf,use_graph", [("LarvaNet", 32, True), ("LarvaNet", 64, True), ("LarvaNetV2", 32, False),
+                                               ("LarvaNetV2", 64, True), ("LarvaNet", 32, False)])
+def test_num_filters_extension_against_the_cpu_restatement(hip_device, name, nf, use_graph):
+    """--num_filters=32 / 64 (BASELINE configs 2 / 5 name 32- and 64-channel bodies; SURVEY 8a N1: a build-side
+    extension the reference cannot express -- its width is a constant 48 -- with every leg's last conv kept at 48
+    outputs).  No reference fixture can exist; the check is against oracle/larva_torch.py built at the same width
+    (same initial weights from the same seed, bit for bit): inference forward, two train_step_larva steps' losses,
+    EVERY gradient element of the first step, the weights after the second AdamW step."""
+    from oracle import larva_torch as T
+    v2 = name == "LarvaNetV2"
+    blocks = [2, 1]
+    m = _model(name, ["--num_modules=2", "--num_blocks=2,1", "--num_filters=%d" % nf], training=True, seed=11)
+    m.use_hip_graph = use_graph
+    sd = {k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()}
+    ref_sd = T.init_state_dict(blocks, v2=v2, seed=11, nf=nf)
+    assert sorted(sd) == sorted(ref_sd) and all(torch.equal(sd[k], ref_sd[k]) for k in sd)
+    assert tuple(sd["body_1.leg.recon_block.2.weight"].shape) == (48, nf, 3, 3)
+    assert tuple(sd["head.feature_extraction.weight"].shape) == (nf, 3, 3, 3)
+    g = torch.Generator().manual_seed(nf)
+    x = torch.rand(4, 3, 12, 16, generator=g) * 255
+    t = torch.rand(4, 3, 48, 64, generator=g) * 255
+    with torch.no_grad():
+        y = m.model(x.to(hip_device)).cpu()
+        y_ref = (T.forward_v2 if v2 else T.forward)(sd, x, blocks)
+    assert float((y - y_ref).abs().max()) < 2e-3
+    lr = m.get_lr()
+    _, ref_grads = T.train_steps(dict(sd), x, t, blocks, steps=1, lr=lr, v2=v2)
+    ref_losses, _ = T.train_steps(sd, x, t, blocks, steps=2, lr=lr, v2=v2)     # (sd: the weights after two steps)
+    args = types.SimpleNamespace(train_path="/tmp")
+    xd, td = x.to(hip_device), t.to(hip_device)
+    m.volume_per_step = 12 * 16 * 4 * 3
+    losses = []
+    for step in range(2):
+        losses.append(m.train_step_larva(args, FakeValLoader(7), xd, td))
+        if step == 0:
+            for k, p in m.model.named_parameters():
+                got, ref = p.grad.detach().cpu().numpy(), ref_grads[k].numpy()
+                assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), k
+    assert m.use_hip_graph == use_graph
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    for k, v in m.model.state_dict().items():
+        d = np.abs(v.cpu().numpy() - sd[k].numpy())
+        assert float((d > 2e-5).mean()) < 2e-3 and float(d.max()) <= 2.1 * lr, (k, float(d.max()))

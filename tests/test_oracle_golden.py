@@ -301,3 +301,35 @@ def test_torch_restatement_v2_headline_steps_f14(golden):
     np.testing.assert_allclose(losses, g["losses"], rtol=1e-6)
     flat = np.concatenate([sd[k].numpy().ravel() for k in sorted(sd)])
     np.testing.assert_allclose(flat[::211], g["after3_sample"], rtol=0, atol=1e-6)
+
+
+def test_edsr_restatement_train_steps_f15(golden):
+    """BASELINE configs[0] (EDSR-baseline x4 on PyTorch-CPU via train.py; plumbing, no HIP kernels): oracle/edsr_torch.py
+    against F15 = the reference's own EDSR.train_step (models/edsr.py:75-108) for 4 steps in train.py's call order,
+    with the learning-rate decay firing after step 2: initial weights from the same seed bit for bit (including the two
+    mean-shift layers, frozen RANDOM 1x1 convs: models/edsr.py:129-137 never installs their weights), losses,
+    learning rates, weights after the 4th Adam step, the upscaled image, and the default network's key set / size."""
+    from oracle import edsr_torch as E
+    g = golden("f15_edsr_train_steps.npz")
+    torch.set_num_threads(4)
+    sd = _tsd(g)
+    init = E.init_state_dict(16, 2, 4, seed=4)
+    assert sorted(init) == sorted(sd) and all(torch.equal(init[k], sd[k]) for k in sd)
+    step = E.make_trainer(sd, 2, lr_decay_steps=2)
+    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["truth"])
+    losses, lrs = [], []
+    for _ in range(4):
+        losses.append(step(x, t))
+        lrs.append(1e-4 * 0.5 ** ((step.state["global_step"] - 1) // 2))
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-6)
+    np.testing.assert_allclose(lrs, g["lrs"], rtol=0, atol=0)
+    assert step.state["global_step"] == int(g["global_step"])
+    for k in sd:
+        np.testing.assert_allclose(step.params[k].detach().numpy(), g["after." + k], rtol=0, atol=1e-6)
+        if k in E.FROZEN:
+            assert np.array_equal(g["after." + k], g["sd." + k])      # the reference never trains them either
+    with torch.no_grad():
+        up = E.forward({k: v.detach() for k, v in step.params.items()}, x[:1], 2)[0].numpy()
+    np.testing.assert_allclose(up[:, ::3, ::3], g["up_sample"], rtol=0, atol=1e-3)
+    full = E.init_state_dict()
+    assert sorted(full) == list(g["default_keys"]) and sum(v.numel() for v in full.values()) == int(g["default_params"])
