@@ -217,25 +217,11 @@ def chain_operands(dev, c, chain=40, decaying=False):
     return x0, fwd, b, bufs, run(fwd)
 
 
-def chain_time_ms(dev, c, chain=40, reps=10, decaying=False):
-    """The fused conv3x3+ReLU kernel the way it runs inside the training step: a captured chain of
-    `chain` dependent launches (each reads the previous one's output), replayed back to back, timed
-    by a HIP event pair on the launch stream; per launch = replay time / chain."""
+def replay_ms(graph, reps=10):
+    """Median of 3 event-timed runs of `reps` back-to-back replays -> ms per replay."""
     import torch
-    from larvanet_amd import kernels as K
-    x0, wpk, b, bufs, rms = chain_operands(dev, c, chain, decaying)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        K.conv3x3(x0, wpk, c, bias=b, relu=True, out=bufs[0])
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-        src = x0
-        for i in range(chain):
-            K.conv3x3(src, wpk, c, bias=b, relu=True, out=bufs[i & 1])
-            src = bufs[i & 1]
-    graph.replay()
+    for _ in range(3):
+        graph.replay()
     torch.cuda.synchronize()
     best = []
     for _ in range(3):
@@ -245,8 +231,38 @@ def chain_time_ms(dev, c, chain=40, reps=10, decaying=False):
             graph.replay()
         e.record()
         torch.cuda.synchronize()
-        best.append(s.elapsed_time(e) / (reps * chain))
-    return sorted(best)[1], rms
+        best.append(s.elapsed_time(e) / reps)
+    return sorted(best)[1]
+
+
+# Layers per captured chain: the per-layer figure is the SLOPE between a long and a short chain, (t(160) - t(40)) / 120,
+# i.e. what one more layer costs in the steady state.  A replay has a fixed cost on top -- graph launch, the chains
+# ramping up (the stamp profile profiles/r03_dual_chain_overlap.txt: ~55 us per replay, 1.4 us per layer when spread over
+# 40) -- which belongs to the replay, not to the kernel; `avg_ms_chain40` keeps round 2's "replay / 40" figure.
+CHAIN_SHORT, CHAIN_LONG = 40, 160
+
+
+def chain_time_ms(dev, c, chain=CHAIN_SHORT, reps=10, decaying=False):
+    """The fused conv3x3+ReLU kernel the way it runs inside the training step: captured chains of dependent launches
+    (each reads the previous one's output), replayed back to back, timed by a HIP event pair on the launch stream.
+    Returns (ms per launch = slope between the 160- and the 40-launch chain, RMS of the last output, replay / 40)."""
+    import torch
+    from larvanet_amd import kernels as K
+    x0, wpk, b, bufs, rms = chain_operands(dev, c, chain, decaying)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        K.conv3x3(x0, wpk, c, bias=b, relu=True, out=bufs[0])
+    torch.cuda.current_stream().wait_stream(side)
+    times = {}
+    for n in (CHAIN_SHORT, CHAIN_LONG):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            for i in range(n):
+                # (the calibrated chain is `chain` layers long: every `chain` layers it starts again from x0)
+                K.conv3x3(x0 if i % chain == 0 else bufs[(i - 1) & 1], wpk, c, bias=b, relu=True, out=bufs[i & 1])
+        times[n] = replay_ms(graph, reps)
+    return (times[CHAIN_LONG] - times[CHAIN_SHORT]) / (CHAIN_LONG - CHAIN_SHORT), rms, times[CHAIN_SHORT] / CHAIN_SHORT
 
 
 def dual_chain_time_ms(dev, c=CH, chain=40, reps=10, decaying=False):
@@ -262,42 +278,32 @@ def dual_chain_time_ms(dev, c=CH, chain=40, reps=10, decaying=False):
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     parts = ((0, BATCH // 2), (BATCH // 2, BATCH))
 
-    def body():
+    def body(n):
         cur = torch.cuda.current_stream()
         for st in streams:
             st.wait_stream(cur)
-        src = x0
-        for i in range(chain):
+        for i in range(n):
+            src = x0 if i % chain == 0 else bufs[(i - 1) & 1]
             for k, st in enumerate(streams):
                 with torch.cuda.stream(st):
                     K.conv3x3(src, wpk, c, bias=b, relu=True, out=bufs[i & 1], images=parts[k],
                               strips=2 if k else True, plain_stores=True)   # (plain stores: what the step's forward chain uses)
-            src = bufs[i & 1]
         for st in streams:
             cur.wait_stream(st)
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        body()
+        body(2)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-        body()
-    for _ in range(3):
-        graph.replay()
-    torch.cuda.synchronize()
-    best = []
-    for _ in range(3):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(reps):
-            graph.replay()
-        e.record()
-        torch.cuda.synchronize()
-        best.append(s.elapsed_time(e) / (reps * chain))
-    return sorted(best)[1], rms
+    times = {}
+    for n in (CHAIN_SHORT, CHAIN_LONG):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            body(n)
+        times[n] = replay_ms(graph, reps)
+    return (times[CHAIN_LONG] - times[CHAIN_SHORT]) / (CHAIN_LONG - CHAIN_SHORT), rms, times[CHAIN_SHORT] / CHAIN_SHORT
 
 
 def time_dominant_kernel(dev, iters=50):
@@ -353,13 +359,13 @@ def roofline_block(dev, c=CH, full=True, dual=False):
     res = dual_chain_time_ms(dev, c) if dual else chain_time_ms(dev, c)
     if res is None:
         return None
-    graph_ms, rms = res
+    graph_ms, rms, ms40 = res
     # priced on the in-graph time per layer (what the step pays, boundaries included)
     flop = conv_flop(c)
     achieved = flop / (graph_ms * 1e-3) / 1e12
     alg_bytes = 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c)
     blk = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_ms": graph_ms,
+           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_ms": graph_ms, "avg_ms_chain40": ms40,
            "inputs": "layer 0 reads N(0,1)*20 activations; weights rescaled so the RMS stays there down the 40-layer chain "
                      "(last layer's output RMS %.1f)" % rms}
     if c == CH:
@@ -368,8 +374,9 @@ def roofline_block(dev, c=CH, full=True, dual=False):
         if full or dual:
             old_ms = (dual_chain_time_ms(dev, c, decaying=True) if dual else chain_time_ms(dev, c, decaying=True))[0]
             blk["avg_ms_decaying_inputs"] = old_ms
-            blk["avg_ms_decaying_inputs_is"] = ("round 2's microbenchmark operands (ones in, weights x 0.05: all-zero activations "
-                                                "from the first replay on), for comparison")
+            blk["avg_ms_decaying_inputs_is"] = ("the same slope with round 2's microbenchmark operands (ones in, weights x 0.05: the "
+                                                "activations shrink ~30x per layer, most layers multiply zeros / denormals), for "
+                                                "comparison: the chip clocks higher on them")
     if dual:
         alone = strip_launch_alone_ms(dev, c)
         if alone is not None:
@@ -384,16 +391,18 @@ def roofline_block(dev, c=CH, full=True, dual=False):
             "launches_per_layer": 2, "flop_per_launch": flop // 2, "flop_per_layer": flop,
             "traffic_is": "HBM-side bytes per LAYER (two launches)",
             "algorithmic_bytes_per_layer": alg_bytes,
-            "timing": "HIP event pair around 10 replays of a captured graph of two 40-launch half-batch chains on two "
-                      "streams; avg_ms = replay time / 40 = time per full-batch layer (median of 3).  Under rocprofv3 "
-                      "the two chains do not overlap (the profiler makes the multi-stream graph launch host-bound): "
-                      "its per-launch durations are those of a launch running alone"})
+            "timing": "HIP event pairs around 10 replays of captured graphs of two half-batch chains on two streams, 40 and "
+                      "160 layers long (median of 3 each); avg_ms = (t160 - t40) / 120 = what one more full-batch layer costs "
+                      "in the steady state; avg_ms_chain40 = t40 / 40 (round 2's figure: includes the replay's fixed ~55 us).  "
+                      "The un-profiled in-kernel stamp profile profiles/r03_dual_chain_overlap.txt shows the same steady "
+                      "state; under rocprofv3 the two chains do not overlap (the profiler makes the multi-stream graph "
+                      "launch host-bound): its per-launch durations are those of a launch running alone"})
     else:
         blk.update({
             "kernel": "conv3x3_mfma_kernel<%d, true, 1> (fused conv3x3+bias+ReLU), 16x%dx48x48 fp32" % (c, c),
             "flop_per_launch": flop,
-            "timing": "HIP event pair around 10 replays of a captured chain of 40 dependent launches, per launch "
-                      "(median of 3)",
+            "timing": "HIP event pairs around 10 replays of captured chains of 40 and 160 dependent launches (median of 3 "
+                      "each); avg_ms = (t160 - t40) / 120, avg_ms_chain40 = t40 / 40",
             "algorithmic_bytes_per_launch": alg_bytes})
     if full:
         k_mean_ms, k_min_ms, pair_ms = time_dominant_kernel(dev)

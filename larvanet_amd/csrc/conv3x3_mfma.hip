@@ -217,16 +217,22 @@ struct ConvCfg {
 // Epilogue operands through LDS (strip tiles, round 3).  The mask / residual operands of a tile -- COUT channels x
 // ROWS rows x 16 pixels, 15 KiB at 48 channels x 5 rows -- used to be per-lane global loads in the MFMA waves'
 // prologue: older than the first chunk's pieces, so the K loop could not start before they had come in from HBM,
-// and held in up to 32 VGPRs through the whole loop.  Now the loader wave streams them by LDS-DMA into the ring
-// stages the last two chunks leave free (where it used to re-stream the last chunk as filler), and the epilogue
-// reads them from LDS after one more barrier.  Layout: [channel][row][16] floats, channels CHS = ROWS * 16 + 4
-// floats apart (the 16 lanes of a ds_read_b128 group read 16 different channels).
+// and held in up to 32 VGPRs through the whole loop.  Now the loader wave streams them by LDS-DMA and the epilogue
+// reads them from LDS.  Where to: the FIRST operand (mask / res0) into a tile of its own behind the three ring stages
+// (16 KiB: two workgroups still fit a CU's 160 KiB), issued right behind chunk 2's pieces, so it has the whole K loop
+// to arrive; the SECOND operand of the two-residual epilogue into the ring stage the last-but-one chunk's turn would
+// otherwise fill with filler.  (First version of this round: both operands into the freed stages during the last
+// two chunks -- issued 1-2 us before the epilogue they were still in flight when the K loop ended: +0.9 us per
+// launch alone, step 1.72 against 1.66 ms.)  Layout: [channel][row][16] floats, channels CHS = ROWS * 16 + 4 floats
+// apart (the 16 lanes of a ds_read_b128 group read 16 different channels).
 template <int COUT, typename G>
 struct AuxTile {
   static constexpr int CHS = G::ROWS * 16 + 4;
   static constexpr int SLOTS = COUT * CHS / 4;                 // 16-byte slots
   static constexpr int PIECES = (SLOTS + 63) / 64;
+  static constexpr int FLOATS = PIECES * 256;                  // whole pieces
   static_assert(G::COLS == 16, "epilogue operands in LDS: strip tiles only");
+  static_assert(2 * ConvCfg<COUT, G>::PIECES + PIECES <= 63, "vmcnt counts 63 operations at most");
   static_assert(PIECES <= ConvCfg<COUT, G>::PIECES, "an operand tile must fit the pieces of one ring stage");
 };
 
@@ -371,25 +377,23 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
   int stage = 0;
   for (int chunk = 0; chunk <= last; ++chunk) {
     // everything but the youngest chunk's pieces has landed: for chunk >= 2 that is chunk `chunk`
-    // itself (chunks 0 and 1 come from the MFMA waves, which wait for them on their side)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PIECES) : "memory");
+    // itself (chunks 0 and 1 come from the MFMA waves, which wait for them on their side).  With an early
+    // operand tile in flight behind chunk 2's pieces (issued in turn 0, see below) turns 1 and 2 leave AUXP more
+    // operations outstanding: the counter retires in order, so "chunk 2 has landed" is then <= PIECES + AUXP.
+    if (NAUXL > 0 && (chunk == 1 || chunk == 2))
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PIECES + (NAUXL > 0 ? AUXP : 0)) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PIECES) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
     const unsigned dst = lds_addr_of(smem + nstage * C::STAGE_FLOATS);
-    if (NAUXL > 0 && chunk + 2 > last) {
-      // past the end of K: the stage chunk - 1 has vacated takes operand (chunk + 1 - last) of the epilogue --
-      // res0 / mask while the last-but-one chunk multiplies, res1 during the last one.  Exactly PIECES
-      // operations like every other turn (the counted waits stay the same): the surplus pieces are all-zero
-      // writes, which fetch nothing.
-      const int which = chunk + 1 - last;
-      const bool have = which < NAUXL;   // (one operand only: the last turn writes nothing but zeros)
-      i32x4 rs = arsrc[0];
-      if constexpr (NAUXL > 1) {
-        if (which == 1) rs = arsrc[1];
-      }
+    if (NAUXL > 1 && chunk == last - 1) {
+      // the first past-the-end turn: the stage chunk - 1 has vacated takes the epilogue's SECOND operand (two
+      // chunks of K before it is read).  Exactly PIECES operations like every other turn (the counted waits stay
+      // the same): the surplus pieces are all-zero writes, which fetch nothing.
 #pragma unroll
       for (int p = 0; p < C::PIECES; ++p)
-        lds_dma16_buf(rs, (p < AUXP && have) ? aoff[p < AUXP ? p : 0] : kDmaZero, 0, dst + 1024u * (unsigned)p);
+        lds_dma16_buf(arsrc[NAUXL > 1 ? 1 : 0], p < AUXP ? aoff[p < AUXP ? p : 0] : kDmaZero, 0, dst + 1024u * (unsigned)p);
     } else {
       // past the end the last chunk is streamed again into a stage nobody reads: every wait stays
       // the same counted vmcnt(PIECES)
@@ -398,13 +402,20 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
       for (int p = 0; p < C::PIECES; ++p)
         lds_dma16_buf(p < C::IN_PIECES ? cs.img : cs.wgt, pl.voff[p], 0, dst + 1024u * (unsigned)p);
     }
+    if (NAUXL > 0 && chunk == 0) {
+      // the epilogue's FIRST operand, into its own tile behind the ring, behind chunk 2's pieces in the queue
+      const unsigned adst = lds_addr_of(smem + 3 * C::STAGE_FLOATS);
+#pragma unroll
+      for (int p = 0; p < AUXP; ++p) lds_dma16_buf(arsrc[0], aoff[p], 0, adst + 1024u * (unsigned)p);
+    }
     stage = stage == 2 ? 0 : stage + 1;
   }
-  // no LDS-DMA may be in flight when the workgroup's LDS is released -- and with operands in LDS the MFMA waves
-  // wait at one more barrier for them to have landed
+  // no LDS-DMA may be in flight when the workgroup's LDS is released -- and where the operands may still be in
+  // flight when the K loop ends (a second operand; or fewer than four chunks: the first operand is only known to
+  // have landed at turn 3's wait) the MFMA waves wait at one more barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (NAUXL > 0) {
-    asm volatile("s_barrier" ::: "memory");
+    if (NAUXL > 1 || a.n_chunks < 4) asm volatile("s_barrier" ::: "memory");
   }
 }
 
@@ -639,7 +650,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
                            ? 1 : ((EPI == kEpiRes2 || EPI == kEpiShuffleL1) ? 2 : 0);
   f32x4 aux[(NAUX > 0 && !AUXLDS) ? NAUX : 1][(NAUX > 0 && !AUXLDS) ? NCT : 1][(NAUX > 0 && !AUXLDS) ? NPG : 1];
   auto load_aux = [&]() {
-    if constexpr (AUXLDS) return;   // (the loader wave streams them into LDS during the last chunks)
+    if constexpr (!AUXLDS)   // (else the loader wave streams them into LDS)
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -748,14 +759,14 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     // no LDS-DMA may be in flight when the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (AUXLDS) {
-      // the epilogue's operands: streamed by the loader wave into the two stages behind the last chunk's --
-      // stage `stage` (res0 / mask, issued two chunks ago) and the one after it (res1, one chunk ago) -- and
-      // complete once the loader has passed this barrier too
-      asm volatile("s_barrier" ::: "memory");
+      // the epilogue's operands, streamed by the loader wave: the first into the tile behind the ring (landed by
+      // the barrier of chunk 3; with fewer chunks, or with a second operand -- in stage `stage`, issued two chunks
+      // ago --, complete once the loader has passed one more barrier)
+      if (NAUX > 1 || a.n_chunks < 4) asm volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       using T = AuxTile<COUT, G>;
-      const float* t0 = smem + stage * C::STAGE_FLOATS;
-      const float* t1 = smem + (stage == 2 ? 0 : stage + 1) * C::STAGE_FLOATS;
+      const float* t0 = smem + 3 * C::STAGE_FLOATS;
+      const float* t1 = smem + stage * C::STAGE_FLOATS;
 #pragma unroll
       for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -1049,10 +1060,13 @@ __global__ __launch_bounds__(320, 2) void conv3x3_mfma_strip_kernel(ConvArgs a) 
   if (e >> 31) strip_roles<COUT, EPI, GeoS5>(a, smem, wave, n, y0, x0, tid);
   else strip_roles<COUT, EPI, GeoS4>(a, smem, wave, n, y0, x0, tid);
 }
-template <int COUT>
-constexpr size_t kStripLdsBytes =
-    ConvCfg<COUT, GeoS5>::LDS_BYTES_DMA > ConvCfg<COUT, GeoS4>::LDS_BYTES_DMA ? ConvCfg<COUT, GeoS5>::LDS_BYTES_DMA
-                                                                              : ConvCfg<COUT, GeoS4>::LDS_BYTES_DMA;
+template <int COUT, typename G, int EPI>
+constexpr size_t kStripLdsOf = ConvCfg<COUT, G>::LDS_BYTES_DMA +
+    ((LARVA_AUX_LDS && (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2)) ? AuxTile<COUT, G>::FLOATS * sizeof(float) : 0);
+template <int COUT, int EPI = kEpiRelu>
+constexpr size_t kStripLdsBytes = kStripLdsOf<COUT, GeoS5, EPI> > kStripLdsOf<COUT, GeoS4, EPI> ? kStripLdsOf<COUT, GeoS5, EPI>
+                                                                                                : kStripLdsOf<COUT, GeoS4, EPI>;
+static_assert(2 * kStripLdsBytes<48, kEpiRes2> <= 160 * 1024, "two strip workgroups per CU");
 
 // Several INDEPENDENT convolutions of one shape and one epilogue in one launch (blockIdx.y = job).
 // A single conv launch at the training shape is one workgroup per CU and spends half of its time
@@ -1271,17 +1285,18 @@ static hipError_t launch_batch(const ConvBatch& b, int njobs, int epi, hipStream
 template <int COUT, int EPI>
 static hipError_t launch_strip_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
   static bool attr_set = false;
+  constexpr size_t lds = kStripLdsBytes<COUT, EPI>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_strip_kernel<COUT, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStripLdsBytes<COUT>);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if (tm)
-    hipExtLaunchKernelGGL((conv3x3_mfma_strip_kernel<COUT, EPI>), dim3(a.nwg), dim3(320), kStripLdsBytes<COUT>, stream,
+    hipExtLaunchKernelGGL((conv3x3_mfma_strip_kernel<COUT, EPI>), dim3(a.nwg), dim3(320), lds, stream,
                           tm->start, tm->stop, 0, a);
   else
-    hipLaunchKernelGGL((conv3x3_mfma_strip_kernel<COUT, EPI>), dim3(a.nwg), dim3(320), kStripLdsBytes<COUT>, stream, a);
+    hipLaunchKernelGGL((conv3x3_mfma_strip_kernel<COUT, EPI>), dim3(a.nwg), dim3(320), lds, stream, a);
   return hipGetLastError();
 }
 

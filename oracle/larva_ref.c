@@ -173,14 +173,15 @@ void ref_l1_grad(const float* a, const float* b, float g, long long n, float* ga
 
 /* One optim.AdamW step (models/LarvaNet.py:86-88,114; defaults betas=(.9,.999), eps=1e-8,
  * weight_decay=0.01): decoupled decay, then the bias-corrected Adam update. step is 1-based. */
-void ref_adamw(float* p, const float* g, float* m, float* v, long long n, int step, float lr,
-               float beta1, float beta2, float eps, float wd) {
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+void ref_adamw(float* p, const float* g, float* m, float* v, long long n, int step, double lr,
+               double beta1, double beta2, double eps, double wd) {
+  /* (hyper-parameters are doubles, as torch.optim.AdamW's Python floats are) */
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
   for (long long i = 0; i < n; ++i) {
-    double pi = (double)p[i] * (1.0 - (double)lr * wd);
-    const double mi = (double)beta1 * m[i] + (1.0 - (double)beta1) * g[i];
-    const double vi = (double)beta2 * v[i] + (1.0 - (double)beta2) * (double)g[i] * g[i];
-    pi -= ((double)lr / bc1) * mi / (sqrt(vi) / sqrt(bc2) + (double)eps);
+    double pi = (double)p[i] * (1.0 - lr * wd);
+    const double mi = beta1 * m[i] + (1.0 - beta1) * g[i];
+    const double vi = beta2 * v[i] + (1.0 - beta2) * (double)g[i] * g[i];
+    pi -= (lr / bc1) * mi / (sqrt(vi) / sqrt(bc2) + eps);
     p[i] = (float)pi;
     m[i] = (float)mi;
     v[i] = (float)vi;

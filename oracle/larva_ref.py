@@ -41,7 +41,7 @@ def lib():
         L.ref_l1_mean.argtypes = [_f, _f, ll]
         L.ref_l1_mean.restype = d
         L.ref_l1_grad.argtypes = [_f, _f, fl, ll, _f]
-        L.ref_adamw.argtypes = [_f, _f, _f, _f, ll, i, fl, fl, fl, fl, fl]
+        L.ref_adamw.argtypes = [_f, _f, _f, _f, ll, i, d, d, d, d, d]
         L.ref_image_to_uint8.argtypes = [_f, _b, ll]
         L.ref_image_psnr.argtypes = [_b, i, i, i, _b, i, i]
         L.ref_image_psnr.restype = d

@@ -118,6 +118,12 @@ def main():
       "(the stamped build pays for its stamps: compare with the bench line of the same box)" % event_us)
     span = tt[:, :, 3].max() - tt[:, :, 0].min()
     w("stamps: first kernel entry -> last store drained %.1f us = %.2f us per full-batch layer" % (span, span / chain))
+    starts = [min(tt[2 * i, :, 0].min(), tt[2 * i + 1, :, 0].min()) for i in range(chain)]
+    steady = (starts[chain - 1] - starts[8]) / (chain - 1 - 8)
+    w("stamps, steady state: layer 8's first entry -> layer %d's first entry = %.2f us per full-batch layer  <- what bench.py's "
+      "roofline.avg_ms (slope between a 160- and a 40-layer chain) measures; the replay's fixed cost (graph launch gap, the second "
+      "chain starting %.1f us after the first, the first layers' cold operands) is %.1f us per replay by the event pair"
+      % (chain - 1, steady, tt[1, :, 0].min() - tt[0, :, 0].min(), event_us * chain - steady * chain))
     w("")
     lay = [(tt[s, :, 0].min(), tt[s, :, 3].max()) for s in range(nslots)]   # launch = [first WG entry, last WG drained]
     w("per layer: launch interval of chain 0 / chain 1 (us after the first entry), time BOTH chains have a launch resident, "
@@ -167,9 +173,37 @@ def main():
           % (100 * pair_kinds["chain0+chain1"] / two, 100 * pair_kinds["same chain"] / two))
     wg_per_cu = np.array([(cu_key == k_).sum() for k_ in keys]) / float(nslots)
     w("  workgroups per CU per launch: min %.2f  median %.2f  max %.2f" % (wg_per_cu.min(), np.median(wg_per_cu), wg_per_cu.max()))
-    # do workgroup i of both chains' launches land on the same CU?
+    # do workgroup i of both chains' launches land on the same CU?  and which tile heights meet on a CU?
     same = np.mean([np.mean(cu_key[2 * i] == cu_key[2 * i + 1]) for i in range(chain)])
     w("  workgroup index i of chain 0's and chain 1's launch of a layer sit on the same CU in %.0f %% of the cases" % (100 * same))
+    tabs = [K.strip_tile_table(48, 48, dev, ph)[0].cpu().numpy().astype(np.int64) for ph in (0, 1)]
+    per_img = len(tabs[0])
+
+    def rows_of(block, ph):   # tile height of workgroup `block` of a launch with table phase ph (xcd_remap as in the kernel)
+        nwg = WG
+        q, r, xcd = nwg >> 3, nwg & 7, block & 7
+        base = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+        tile = base + (block >> 3)
+        return 5 if (tabs[ph][tile % per_img] >> 31) & 1 else 4
+
+    heights = np.array([[rows_of(g_, s_ & 1) for g_ in range(WG)] for s_ in range(nslots)])
+    pairs = {"5+4": 0.0, "5+5": 0.0, "4+4": 0.0}
+    for key in keys:
+        sel = [(s_, g_) for s_, g_ in np.argwhere(cu_key == key)]
+        ev = sorted([(tt[s_, g_, 0], 1, heights[s_, g_]) for s_, g_ in sel] + [(tt[s_, g_, 3], -1, heights[s_, g_]) for s_, g_ in sel])
+        live, last = [], ev[0][0]
+        for when, d, h in ev:
+            if len(live) == 2:
+                pairs["%d+%d" % (max(live), min(live))] += when - last
+            last = when
+            if d > 0:
+                live.append(h)
+            else:
+                live.remove(h)
+    tp = sum(pairs.values())
+    if tp > 0:
+        w("  tile heights of the two workgroups that share a CU (share of the 2-workgroup time): 5 + 4 rows %.0f %%, 5 + 5 %.0f %%, "
+          "4 + 4 %.0f %%" % (100 * pairs["5+4"] / tp, 100 * pairs["5+5"] / tp, 100 * pairs["4+4"] / tp))
     text = "\n".join(out)
     print(text)
     if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):
