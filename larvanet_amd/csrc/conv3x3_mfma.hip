@@ -48,7 +48,12 @@
 #define LARVA_PIXEL_MAJOR 1   // 0: channel-major accumulators in every epilogue (A/B timing)
 #endif
 #ifndef LARVA_AUX_LDS
-#define LARVA_AUX_LDS 1   // 0: the strip kernel's mask / residual operands as per-lane global loads in the prologue (A/B timing)
+// 1: the strip kernel's mask / residual operands reach the epilogue through LDS (streamed by the loader wave, see
+// AuxTile) instead of per-lane global loads in the prologue.  Built, bit-exact, measured twice in round 3 and LEFT OFF:
+// same-box step 1.72 ms (both operands into the ring stages the last two chunks free) / 1.78 ms (first operand early
+// into a tile of its own) against 1.66 ms with the register path; a launch alone 11.0-11.5 us against 10.0-10.9
+// (tools/ab_aux_lds.sh).
+#define LARVA_AUX_LDS 0
 #endif
 #ifndef LARVA_OPERAND_DEPTH
 #define LARVA_OPERAND_DEPTH 2   // k-steps between an operand's LDS read and the MFMAs that use it (A/B: 1)
@@ -873,7 +878,14 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         for (int p = 0; p < NPG; ++p) {
           const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
           const int y = y0 + prow, xb = x0 + pcol * 16 + lq * 4;
-          const size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * a.pitch + xb;
+          size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * a.pitch + xb;
+          if constexpr ((LARVA_DIAG & 1024) != 0 && G::COLS == 16) {
+            // timing-only ablation (results land in the wrong places): the tile's COUT x ROWS x 16 floats as ONE
+            // contiguous run per workgroup -- a workgroup-contiguous ("blocked") activation layout's store side,
+            // with every load left as it is: what would DESIGN 9.0 buy in the two-chain regime?  tools/ab_blocked_stores.sh
+            idx = (((size_t)n * (a.pitch / 16) + x0 / 16) * a.H + y0) * 16 * COUT +
+                  (size_t)(((ct0 + c) * 16 + lr) * G::ROWS + prow) * 16 + lq * 4;
+          }
           f32x4 v = acc[c][p] + bias[c];
           if (y < a.H && xb < a.pitch) {
 #pragma unroll
