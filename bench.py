@@ -350,13 +350,14 @@ def strip_launch_alone_ms(dev, c, iters=50):
         return None
 
 
-def roofline_block(dev, c=CH, full=True, dual=False):
+def roofline_block(dev, c=CH, full=True, dual=False, quick=False):
     """fp32-MFMA roofline of the fused conv3x3+ReLU layer at 16 x c x 48 x 48.  dual=False: one
     chain of whole-batch launches (3 x 48 tiles, conv3x3_mfma_kernel).  dual=True: the layer as the
     training step runs it since round 2 -- two concurrent half-batch launches of
     conv3x3_mfma_strip_kernel; `avg_ms` is then the time per FULL-BATCH layer (= per pair of
     launches), `flop_per_launch` one launch's half."""
-    res = dual_chain_time_ms(dev, c) if dual else chain_time_ms(dev, c)
+    reps = 2 if quick else 10   # quick: a short run for rocprofv3 --pmc passes (every dispatch is serialised there)
+    res = dual_chain_time_ms(dev, c, reps=reps) if dual else chain_time_ms(dev, c, reps=reps)
     if res is None:
         return None
     graph_ms, rms, ms40 = res
@@ -371,19 +372,19 @@ def roofline_block(dev, c=CH, full=True, dual=False):
     if c == CH:
         blk["traffic"], src = conv_traffic(dual)
         blk["traffic_source"] = TRAFFIC_NOTE % src
-        if full or dual:
+        if (full or dual) and not quick:
             old_ms = (dual_chain_time_ms(dev, c, decaying=True) if dual else chain_time_ms(dev, c, decaying=True))[0]
             blk["avg_ms_decaying_inputs"] = old_ms
             blk["avg_ms_decaying_inputs_is"] = ("the same slope with round 2's microbenchmark operands (ones in, weights x 0.05: the "
                                                 "activations shrink ~30x per layer, most layers multiply zeros / denormals), for "
                                                 "comparison: the chip clocks higher on them")
     if dual:
-        alone = strip_launch_alone_ms(dev, c)
+        alone = None if quick else strip_launch_alone_ms(dev, c)
         if alone is not None:
             blk["launch_alone_ms"] = alone[0]
             blk["launch_alone_is"] = ("mean duration of ONE half-batch strip launch running alone, kernel-attached HIP events over "
                                       "50 launches (min %.5f): the figure rocprofv3 --stats reports per dispatch of this kernel "
-                                      "(profiles/r02_c_bench_final_kernel_stats.csv), NOT half of avg_ms -- two such launches "
+                                      "(profiles/r03_bench_kernel_stats.csv), NOT half of avg_ms -- two such launches "
                                       "overlap in the step" % alone[1])
         blk.update({
             "kernel": "conv3x3_mfma_strip_kernel<%d, 1> (fused conv3x3+bias+ReLU, 5x16 / 4x16 pixel tiles), two concurrent " % c +
@@ -404,7 +405,7 @@ def roofline_block(dev, c=CH, full=True, dual=False):
             "timing": "HIP event pairs around 10 replays of captured chains of 40 and 160 dependent launches (median of 3 "
                       "each); avg_ms = (t160 - t40) / 120, avg_ms_chain40 = t40 / 40",
             "algorithmic_bytes_per_launch": alg_bytes})
-    if full:
+    if full and not quick:
         k_mean_ms, k_min_ms, pair_ms = time_dominant_kernel(dev)
         blk.update({"isolated_kernel_attached_ms": k_mean_ms, "isolated_min_ms": k_min_ms,
                     "event_pair_ms_incl_launch_gap": pair_ms})
@@ -696,6 +697,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only time the dominant kernel (short run for rocprofv3 --pmc passes)")
+    ap.add_argument("--wgrad-only", action="store_true",
+                    help="only the flat weight-gradient launch + reduction (short run for rocprofv3 --pmc passes)")
     ap.add_argument("--sync-loss", action="store_true", help="(the default since round 3; kept for old command lines)")
     ap.add_argument("--async-loss", action="store_true",
                     help="headline loop without the reference's per-step loss.item() and with the batch already in the "
@@ -728,7 +731,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device")
     dev = torch.device("cuda", torch.cuda.current_device())
     if a.roofline_only:
-        emit({"roofline": roofline_block(dev), "roofline_dual": roofline_block(dev, full=False, dual=True)})
+        emit({"roofline": roofline_block(dev, quick=True), "roofline_dual": roofline_block(dev, full=False, dual=True, quick=True)})
+        return
+    if a.wgrad_only:
+        emit({"roofline_wgrad_isolated": wgrad_block(dev, iters=3)})
         return
 
     import importlib

@@ -24,8 +24,10 @@ const char* larva_error_string(int code);
  * nn.Conv2d weights stay in PyTorch layout [cout][cin][3][3] (models/LarvaNet.py:210,212,227,
  * 256,258; models/LarvaNetV2.py:318).  The conv kernel consumes a packed image of 8-channel K
  * chunks, [cin/8][9][8][stride(cout)]; the input-gradient pass consumes the tap-mirrored,
- * channel-transposed image [cout/8][9][8][stride(cin)]; stride(c) = c if c % 32 == 16 else
- * c + 16 floats (LDS bank layout).  cin and cout are multiples of 8.
+ * channel-transposed image [cout/8][9][8][stride(cin)]; stride(c) = c if c % 32 is 0 or 16, else c + 16 floats
+ * (LDS bank layout: the 16-lane halves of a read hit rows k and k + 1).  Where c % 32 == 0 (32 and 64 channels;
+ * ABI version 3: these rows used to be padded by 16 floats) the rows are unpadded and every odd row (k odd) is stored
+ * with column c ^ 16 -- an opaque kernel layout: only larva_pack_weights* writes it.  cin and cout are multiples of 8.
  * larva_packed_weight_floats(cout, cin) = (cin/8) * 9 * 8 * stride(cout).
  * `w_cin_total`/`w_cin_off` select a channel slice [w_cin_off, w_cin_off+cin) of a wider weight;
  * channels >= w_cin_total pack as 0 (the 3-channel head conv is packed for a 16-channel, i.e.

@@ -237,7 +237,6 @@ struct AuxTile {
   static constexpr int PIECES = (SLOTS + 63) / 64;
   static constexpr int FLOATS = PIECES * 256;                  // whole pieces
   static_assert(G::COLS == 16, "epilogue operands in LDS: strip tiles only");
-  static_assert(2 * ConvCfg<COUT, G>::PIECES + PIECES <= 63, "vmcnt counts 63 operations at most");
   static_assert(PIECES <= ConvCfg<COUT, G>::PIECES, "an operand tile must fit the pieces of one ring stage");
 };
 
@@ -361,6 +360,7 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
   make_loader_plan<COUT, G>(a, lane, y0, x0, pl);
   // NAUXL > 0: this lane's source offsets of the epilogue operands' tile (AuxTile; the same for every operand)
   constexpr int AUXP = NAUXL > 0 ? (COUT * (G::ROWS * 16 + 4) / 4 + 63) / 64 : 1;
+  static_assert(NAUXL == 0 || 2 * C::PIECES + AUXP <= 63, "vmcnt counts 63 operations at most");
   unsigned aoff[AUXP];
   i32x4 arsrc[NAUXL > 0 ? NAUXL : 1];
   if constexpr (NAUXL > 0) {
@@ -491,7 +491,7 @@ __device__ __forceinline__ void reg_store(float* stage, int tid, const RegStagin
 // ---------------------------------------------------------------------------------------------
 // Operands of k-step `step` (= tap*2 + kk) of one chunk.
 template <int COUT, typename G, int NCT, int PG0, int NPG>
-__device__ __forceinline__ void read_operands(const float* a_base, const float* b_base, int step,
+__device__ __forceinline__ void read_operands(const float* const (&a_base)[NCT], const float* b_base, int step,
                                               float (&av)[NCT], float (&bv)[NPG]) {
   using C = ConvCfg<COUT, G>;
   if constexpr ((LARVA_DIAG & 128) != 0) {   // timing ablation: operands from registers, no LDS reads
@@ -504,7 +504,7 @@ __device__ __forceinline__ void read_operands(const float* a_base, const float* 
   const int tap = step / (kCh / 4), kk = step % (kCh / 4);
   const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-  for (int c = 0; c < NCT; ++c) av[c] = a_base[(tap * kCh + kk * 4) * C::CS + c * 16];
+  for (int c = 0; c < NCT; ++c) av[c] = a_base[c][(tap * kCh + kk * 4) * C::CS];
 #pragma unroll
   for (int p = 0; p < NPG; ++p) {
     const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
@@ -538,7 +538,14 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
                                            unsigned nxt_stage) {
   using C = ConvCfg<COUT, G>;
   const int lr = lane & 15, lq = lane >> 4;
-  const float* a_base = stage + C::IN_FLOATS + lq * C::CS + lr + ct0 * 16;
+  // Weight rows: lane (lr, lq) reads row (tap, k = 4 kk + lq), channel 16 (ct0 + c) + lr.  At 32 / 64 output channels
+  // the rows are unpadded and odd rows (lq odd) are stored with their 16-channel groups swapped in pairs (column
+  // c ^ 16, cout_swizzled): the group index becomes (ct0 + c) ^ (lq & 1) -- a per-lane base per output-channel
+  // group, the k-step offsets stay immediates.  (48 channels: plain rows, the bases differ by constants.)
+  const float* a_base[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+    a_base[c] = stage + C::IN_FLOATS + lq * C::CS + lr + (cout_swizzled(COUT) ? (((ct0 + c) ^ (lq & 1)) * 16) : (ct0 + c) * 16);
   const float* b_base = stage + lq * C::PS + lr + 3;
   constexpr int kEvery = C::STEPS / C::NPW > 0 ? C::STEPS / C::NPW : 1;
 #if LARVA_SHADOW
@@ -1028,10 +1035,10 @@ __global__ __launch_bounds__(VEC ? ConvCfg<COUT>::THREADS_DMA : 256, VEC ? 2 : 1
 template <int COUT, int EPI, typename G>
 __device__ __forceinline__ void strip_roles(const ConvArgs& a, float* smem, int wave, int n, int y0, int x0, int tid) {
   static_assert(ConvCfg<COUT, G>::LOADER, "the strip kernel is launched with a loader wave");
-  static_assert(COUT == 48 || COUT == 32, "strip tiles: 48 or 32 output channels");
+  static_assert(COUT == 48 || COUT == 32 || COUT == 64, "strip tiles: 32, 48 or 64 output channels");
   // mask / residual operands come through LDS (AuxTile): needs the two past-the-end turns of the loader, i.e.
   // n_chunks >= 2, which the host checks
-  constexpr bool AL = LARVA_AUX_LDS && LARVA_PIXEL_MAJOR && LARVA_AUX_EARLY && !(LARVA_DIAG & 6) &&
+  constexpr bool AL = LARVA_AUX_LDS && LARVA_PIXEL_MAJOR && LARVA_AUX_EARLY && !(LARVA_DIAG & 6) && COUT != 64 &&
                       (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2);
   if (wave == 4) {
     if constexpr (!AL) run_loader<COUT, G>(a, smem, tid & 63, n, y0, x0);
@@ -1040,7 +1047,10 @@ __device__ __forceinline__ void strip_roles(const ConvArgs& a, float* smem, int 
     else run_loader<COUT, G, 2>(a, smem, tid & 63, n, y0, x0, a.res0, a.res1);
     return;
   }
-  if constexpr (COUT == 48) {
+  if constexpr (COUT == 64) {
+    // ROWS pixel groups x 4 cout groups = 20 / 16 units: every wave one cout group x all pixel groups (5,5,5,5 / 4,4,4,4)
+    run_role<COUT, G, true, EPI, 1, 0, G::ROWS, false>(a, smem, wave, wave, n, y0, x0, tid);
+  } else if constexpr (COUT == 48) {
     // ROWS pixel groups x 3 cout groups: waves 0..2 own one cout group x the first ROWS-1 pixel groups, wave 3
     // all three cout groups of the last pixel group (15 units -> 4,4,4,3; 12 -> 3,3,3,3)
     if (wave < 3) run_role<COUT, G, true, EPI, 1, 0, G::ROWS - 1, AL>(a, smem, wave, wave, n, y0, x0, tid);
@@ -1074,11 +1084,12 @@ __global__ __launch_bounds__(320, 2) void conv3x3_mfma_strip_kernel(ConvArgs a) 
 }
 template <int COUT, typename G, int EPI>
 constexpr size_t kStripLdsOf = ConvCfg<COUT, G>::LDS_BYTES_DMA +
-    ((LARVA_AUX_LDS && (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2)) ? AuxTile<COUT, G>::FLOATS * sizeof(float) : 0);
+    ((LARVA_AUX_LDS && COUT != 64 && (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2)) ? AuxTile<COUT, G>::FLOATS * sizeof(float) : 0);
 template <int COUT, int EPI = kEpiRelu>
 constexpr size_t kStripLdsBytes = kStripLdsOf<COUT, GeoS5, EPI> > kStripLdsOf<COUT, GeoS4, EPI> ? kStripLdsOf<COUT, GeoS5, EPI>
                                                                                                 : kStripLdsOf<COUT, GeoS4, EPI>;
-static_assert(2 * kStripLdsBytes<48, kEpiRes2> <= 160 * 1024, "two strip workgroups per CU");
+static_assert(2 * kStripLdsBytes<48, kEpiRes2> <= 160 * 1024 && 2 * kStripLdsBytes<64, kEpiRes2> <= 160 * 1024,
+              "two strip workgroups per CU");
 
 // Several INDEPENDENT convolutions of one shape and one epilogue in one launch (blockIdx.y = job).
 // A single conv launch at the training shape is one workgroup per CU and spends half of its time
@@ -1163,9 +1174,11 @@ __device__ __forceinline__ void pack_block(const PackJob& j, int slot, float* __
     }
     __syncthreads();
     const int wcols = min(kPackTileCols, cs - c0);
+    const bool swz = cout_swizzled(cols);   // unpadded rows, odd rows (k odd) with column ^ 16 (larva_common.h)
     for (int idx = tid; idx < 72 * wcols; idx += 256) {
       const int r = idx / wcols, c = idx - r * wcols;
-      out[r * cs + c0 + c] = c < ncol ? tile[r * kPackLd + c] : 0.f;
+      const int col = swz ? ((c0 + c) ^ ((r & 1) << 4)) : c0 + c;
+      out[r * cs + col] = c < ncol ? tile[r * kPackLd + c] : 0.f;
     }
     __syncthreads();
   }
@@ -1630,7 +1643,7 @@ int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap) {
 // larva_conv3x3_fwd_pitched on strip tiles: `tile_tab` = DEVICE copy of larva_strip_tile_table(H,
 // pitch) with `tiles_per_image` entries.  plain_stores: mode-0 output written with plain instead of
 // non-temporal stores (faster when the next launch reads it at once, see the kernel's epilogue).
-// cout = 48 or 32 and the 16-byte staging path only (pitch % 4 == 0, 16-byte aligned tensors), otherwise
+// cout = 32, 48 or 64 and the 16-byte staging path only (pitch % 4 == 0, 16-byte aligned tensors), otherwise
 // hipErrorNotSupported.  Results are bit-identical to
 // larva_conv3x3_fwd_pitched: every output's K loop runs in the same order, only the assignment of
 // pixels to workgroups differs.
@@ -1639,7 +1652,7 @@ static int strips_dispatch(const float* const* src, int n_src, int cin_per_src, 
                            const float* base, float* out, int N, int cout, int H, int W, int pitch,
                            int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
                            void* stream, const LaunchTiming* tm) {
-  if (cout != 48 && cout != 32) return (int)hipErrorNotSupported;
+  if (cout != 48 && cout != 32 && cout != 64) return (int)hipErrorNotSupported;
   if (!tile_tab || tiles_per_image < 1) return (int)hipErrorInvalidValue;
   ConvArgs a;
   bool aligned;
@@ -1662,6 +1675,7 @@ static int strips_dispatch(const float* const* src, int n_src, int cin_per_src, 
   a.nwg = N * tiles_per_image;
 #if !LARVA_DIAG_ONLY48
   if (cout == 32) return (int)launch_strip<32>(a, epi, (hipStream_t)stream, tm);
+  if (cout == 64) return (int)launch_strip<64>(a, epi, (hipStream_t)stream, tm);
 #endif
   return (int)launch_strip<48>(a, epi, (hipStream_t)stream, tm);
 }

@@ -25,10 +25,14 @@ constexpr int kMaxSrc = 8;                                 // channel-concatenat
 constexpr int kRS = 56;
 
 __host__ __device__ constexpr int cout_stride(int cout) {
-  // Row stride (floats) of one [k][cout] weight row in LDS: must be == 16 (mod 32) so the two
-  // 16-lane halves of a 32-lane ds_read_b32 group land on disjoint banks.
-  return (cout % 32 == 16) ? cout : cout + 16;
+  // Row stride (floats) of one [k][cout] weight row in LDS.  The two 16-lane halves of a 32-lane ds_read_b32 group
+  // read rows k and k + 1: they must land on disjoint banks.  cout == 16 (mod 32): the stride itself does it.
+  // cout == 0 (mod 32) -- 32 and 64 channels: the row is stored UNPADDED and odd rows are swizzled instead (column
+  // c ^ 16, see cout_swizzled): until round 3 these rows were padded by 16 floats, 13.5 instead of 9 KiB of weights per
+  // K chunk at 32 channels and 22.5 instead of 18 at 64 -- what kept two strip workgroups of 64 channels off one CU.
+  return (cout % 32 == 16 || cout % 32 == 0) ? cout : cout + 16;
 }
+__host__ __device__ constexpr bool cout_swizzled(int cout) { return cout % 32 == 0; }
 
 // XCD-aware, bijective block remap (8 XCDs, blocks dealt round-robin): gives every XCD a
 // contiguous run of tiles so that vertically adjacent tiles (which share halo rows) and the

@@ -189,7 +189,7 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
             at(_opt(base, "base", hr), (cout // 16) * hr_img),
             at(out.data_ptr(), (cout // 16) * hr_img if shuffle else cout * lr_img),
             hi - lo, cout, H, W, P, 1 if relu else 0, 1 if shuffle else 0)
-    if strips and cout in (48, 32):
+    if strips and cout in (48, 32, 64):
         tab = strip_tile_table(H, P, out.device, phase=1 if strips == 2 else 0)
         if tab is not None:
             code = lib.larva_conv3x3_fwd_strips(*args, tab[0].data_ptr(), tab[1], 1 if plain_stores else 0, _stream())

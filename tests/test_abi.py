@@ -31,10 +31,10 @@ def test_library_exports_every_declared_symbol():
     assert sorted(hip_lib.SIGNATURES) == declared  # binding table and header agree
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.larva_abi_version() == 2
+    assert lib.larva_abi_version() == 3
     # pure host-side size helpers need no device
-    def stride(c):   # cout_stride() of csrc/larva_common.h: == 16 (mod 32) floats
-        return c if c % 32 == 16 else c + 16
+    def stride(c):   # cout_stride() of csrc/larva_common.h: c itself where c % 32 is 16 (or 0: swizzled rows), else c + 16
+        return c if c % 32 in (0, 16) else c + 16
 
     for cout, cin in ((48, 48), (64, 64), (32, 32), (48, 16), (48, 192), (48, 8)):
         # [cin/8] chunks x 9 taps x 8 channels x stride(cout) -- the layout include/larva_hip.h documents

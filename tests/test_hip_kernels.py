@@ -921,7 +921,7 @@ def test_adamw_host_scalars_match_torch_and_unaligned_views(hip_device):
                                                                (outs[0][2], st["exp_avg_sq"]))]
     print("AdamW vs torch CPU after 5 steps, fraction of bit-identical elements (param, exp_avg, exp_avg_sq):", same)
     assert same[1] == 1.0 and same[2] == 1.0 and same[0] > 0.97, same
-    assert float((outs[0][0].cpu() - ref.detach()).abs().max()) < 1e-8
+    assert float((outs[0][0].cpu() - ref.detach()).abs().max()) < 3e-8   # (<= 2 ulp of a 0.1-sized weight)
 
 
 def test_timed_launches_compute_what_the_plain_launches_compute(hip_device):
@@ -984,13 +984,16 @@ def test_strip_tiles_seeded_shape_fuzz(hip_device):
 
 
 @pytest.mark.parametrize("kind", ["relu", "res2", "mask", "plain"])
-def test_strip_tiles_at_32_channels(hip_device, kind):
-    """Strip tiles at 32 output channels (waves 3/3/2/2 and 2/2/2/2) == the 3 x 48 tiles bit for bit, and the
-    C oracle (BASELINE's "32ch" configuration has no reference counterpart: SURVEY 8a N1)."""
+@pytest.mark.parametrize("C", [32, 64])
+def test_strip_tiles_at_32_and_64_channels(hip_device, kind, C):
+    """Strip tiles at 32 output channels (waves 3/3/2/2 and 2/2/2/2) and at 64 (5/5/5/5 and 4/4/4/4; round 3: the weight
+    rows of these widths are staged unpadded with odd rows swizzled, which is what lets two 64-channel strip workgroups
+    share a CU) == the 3 x 48 tiles bit for bit, and the C oracle (BASELINE's "32ch" / "64ch" configurations have no
+    reference counterpart: SURVEY 8a N1)."""
     from larvanet_amd import kernels as K
     from oracle import larva_ref as R
-    rng = np.random.default_rng(32)
-    N, C, H, W = 3, 32, 13, 20
+    rng = np.random.default_rng(C)
+    N, H, W = 3, 13, 20
     x = _rand(rng, (N, C, H, W), 20.0)
     w = _rand(rng, (C, C, 3, 3), 0.05)
     b = _rand(rng, (C,), 1.0)
@@ -1012,7 +1015,7 @@ def test_strip_tiles_at_32_channels(hip_device, kind):
     K.conv3x3(_dev(x, hip_device), fwd, C, out=out, images=(1, 3), strips=2, **kw)
     torch.cuda.synchronize()
     assert torch.equal(out[1:], wide[1:]) and bool((out[0] == -1.0).all())
-    _report("c32 strips[%s]" % kind, wide.cpu().numpy(), ref, 2e-5)
+    _report("c%d strips[%s]" % (C, kind), wide.cpu().numpy(), ref, 2e-5)
 
 
 @pytest.fixture(scope="module")

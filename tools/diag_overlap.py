@@ -102,6 +102,8 @@ def main():
         torch.cuda.synchronize()
         runs.append(s.elapsed_time(e) / (10 * chain) * 1e3)
     event_us = sorted(runs)[1]
+    # the same build with the stamps switched off at run time (no slot armed): bench.py's figures in this process
+    slope_ms, _, ms40 = bench.dual_chain_time_ms(dev, c)
     t = stamps.cpu().numpy().reshape(nslots, WG, SLOT_WORDS)
     hw = t[:, :, 4].astype(np.uint64)
     tt = t[:, :, :4].astype(np.float64) * 0.01      # us
@@ -116,12 +118,15 @@ def main():
     w("activations N(0,1)*20 kept at that scale (RMS after the last layer %.1f); build -DLARVA_DIAG=544" % rms)
     w("HIP event pair around 10 replays (median of 3): %.2f us per full-batch layer  <- what bench.py's roofline.avg_ms measures "
       "(the stamped build pays for its stamps: compare with the bench line of the same box)" % event_us)
+    w("same process, stamps not armed: bench.py's roofline.avg_ms = (t160 - t40) / 120 = %.2f us per full-batch layer; t40 / 40 = %.2f us"
+      % (slope_ms * 1e3, ms40 * 1e3))
     span = tt[:, :, 3].max() - tt[:, :, 0].min()
     w("stamps: first kernel entry -> last store drained %.1f us = %.2f us per full-batch layer" % (span, span / chain))
     starts = [min(tt[2 * i, :, 0].min(), tt[2 * i + 1, :, 0].min()) for i in range(chain)]
     steady = (starts[chain - 1] - starts[8]) / (chain - 1 - 8)
     w("stamps, steady state: layer 8's first entry -> layer %d's first entry = %.2f us per full-batch layer  <- what bench.py's "
-      "roofline.avg_ms (slope between a 160- and a 40-layer chain) measures; the replay's fixed cost (graph launch gap, the second "
+      "roofline.avg_ms (slope between a 160- and a 40-layer chain) measures, plus what the armed stamps cost (the event figure above "
+      "against t40 / 40: per layer); the replay's fixed cost (graph launch gap, the second "
       "chain starting %.1f us after the first, the first layers' cold operands) is %.1f us per replay by the event pair"
       % (chain - 1, steady, tt[1, :, 0].min() - tt[0, :, 0].min(), event_us * chain - steady * chain))
     w("")

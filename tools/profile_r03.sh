@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round-3 profiles (GPU box): kernel inventory of the step, then PMC passes -- one counter set per pass, as the guide
+# prescribes -- over the dominant conv kernels (`bench.py --roofline-only`) and the weight-gradient launch pair
+# (`bench.py --wgrad-only`).  Summaries land in gpurun_out/r03_prof/ (copy the ones to keep into profiles/).
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03_prof
+mkdir -p $O
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/step.log 2>&1 || { echo step trace failed; tail -5 $O/step.log; exit 1; }
+cp $O/step/*/*kernel_stats.csv $O/bench_kernel_stats.csv
+(cd $R && python tools/step_timeline.py gpurun_out/r03_prof/step > gpurun_out/r03_prof/bench_timeline_summary.txt 2>&1)
+echo "step trace done"
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/conv$i -- python3 $R/bench.py --roofline-only > $O/conv$i.log 2>&1 || { echo conv pass $i failed; tail -5 $O/conv$i.log; exit 1; }
+  echo "conv pass $i done"
+done
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/wgrad$i -- python3 $R/bench.py --wgrad-only > $O/wgrad$i.log 2>&1 || { echo wgrad pass $i failed; tail -5 $O/wgrad$i.log; exit 1; }
+  echo "wgrad pass $i done"
+done
+cd $R
+python tools/pmc_summary.py gpurun_out/r03_prof/pmc_conv.csv fetch=$O/conv1 write=$O/conv2 mfma=$O/conv3 lds=$O/conv4
+python tools/pmc_summary.py gpurun_out/r03_prof/pmc_wgrad.csv fetch=$O/wgrad1 write=$O/wgrad2 mfma=$O/wgrad3
+# the raw traces are large: keep the summaries only
+rm -rf $O/step $O/conv1 $O/conv2 $O/conv3 $O/conv4 $O/wgrad1 $O/wgrad2 $O/wgrad3
+ls -la $O
