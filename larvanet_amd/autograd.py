@@ -799,28 +799,38 @@ class LegFn(torch.autograd.Function):
         out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base, logical_w=_lw())
         ctx.save_for_backward(fea, h)
         ctx.pcs = pcs
-        ctx.wshape = tuple(w1.shape)
+        ctx.wshape, ctx.wshape2 = tuple(w1.shape), tuple(w2.shape)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         fea, h = ctx.saved_tensors
         pcs = ctx.pcs
-        c = ctx.wshape[0]
+        c, c2 = ctx.wshape[0], ctx.wshape2[0]
         (_, bw1), = pcs[0].get()
         (_, bw2), = pcs[1].get()
         dyl = K.pixel_unshuffle4(dout.contiguous())
         dh = K.conv3x3(dyl, bw2, c, mask=h)
         dfea = K.conv3x3(dh, bw1, c)
-        (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0]),
-                                         (dyl, h, ctx.wshape, 0, c) + _targets(pcs[1])], c, c,
-                                        inplace=all(_targets(pc)[0] is not None for pc in pcs))
+        ((dw1, db1),), ((dw2, db2),) = _leg_wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0])],
+                                                    [(dyl, h, ctx.wshape2, 0, c) + _targets(pcs[1])], c, c2)
         if _targets(pcs[0])[0] is not None:
             dw1 = db1 = None
         if _targets(pcs[1])[0] is not None:
             dw2 = db2 = None
         # base comes from a parameter-free interpolation of the network input: no gradient
         return dfea, None, None, dw1, db1, dw2, db2
+
+
+def _leg_wgrad(first, second, c, c2):
+    """Weight gradients of legs' first (c -> c) and last (c -> c2) convs, jobs as for _wgrad -> (results of `first`,
+    results of `second`).  One call when the two shapes agree (c2 == c: the reference's 48-channel network), else one
+    per shape (--num_filters 32 / 64: the last conv keeps 48 = 3 * 4**2 outputs)."""
+    inplace = all(j[5] is not None for j in list(first) + list(second))
+    if c2 == c:
+        res = _wgrad([j for pair in zip(first, second) for j in pair], c, c, inplace=inplace)
+        return res[0::2], res[1::2]
+    return _wgrad(list(first), c, c, inplace=inplace), _wgrad(list(second), c2, c, inplace=inplace)
 
 
 class ExitFn(torch.autograd.Function):
@@ -856,7 +866,7 @@ class ExitFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(fea, h, out, truth)
         ctx.pcs = pcs
-        ctx.wshape = tuple(w1.shape)
+        ctx.wshape, ctx.wshape2 = tuple(w1.shape), tuple(w2.shape)
         ctx.mark_non_differentiable(out)
         ctx.set_materialize_grads(False)  # no 7 MB zero gradient for the non-differentiable image output
         return out, term
@@ -879,9 +889,8 @@ class ExitFn(torch.autograd.Function):
             dyl = K.l1_bwd_unshuffle4(out, truth, g0, ctx.gscale)
         dh = K.conv3x3(dyl, bw2, c, mask=h)
         dfea = K.conv3x3(dh, bw1, c)
-        (dw1, db1), (dw2, db2) = _wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0]),
-                                         (dyl, h, ctx.wshape, 0, c) + _targets(pcs[1])], c, c,
-                                        inplace=all(_targets(pc)[0] is not None for pc in pcs))
+        ((dw1, db1),), ((dw2, db2),) = _leg_wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0])],
+                                                    [(dyl, h, ctx.wshape2, 0, c) + _targets(pcs[1])], c, ctx.wshape2[0])
         if _targets(pcs[0])[0] is not None:
             dw1 = db1 = None
         if _targets(pcs[1])[0] is not None:
@@ -959,7 +968,7 @@ class ExitsFn(torch.autograd.Function):
                     third.append(out)
         ctx.save_for_backward(truth, *feas, *hs, *third)
         ctx.legs, ctx.M = legs, M
-        ctx.wshape = tuple(params[0].shape)
+        ctx.wshape, ctx.wshape2 = tuple(params[0].shape), tuple(params[2].shape)
         ctx.mark_non_differentiable(outs[-1])
         ctx.set_materialize_grads(False)
         return (outs[-1],) + tuple(parts)
@@ -982,7 +991,7 @@ class ExitsFn(torch.autograd.Function):
                                           for i in live], c))) if live else {}
         dfeas = [None] * M
         grads = [None] * (4 * M)
-        jobs = []
+        jobs1, jobs2 = [], []
         for i in live:
             pc1, pc2 = legs[i]
             if JointInputGrad.can_park(pc1):
@@ -990,13 +999,13 @@ class ExitsFn(torch.autograd.Function):
             else:
                 # (the last exit: its input gradient is the first link of the backward layer chain)
                 dfeas[i] = DualChain.conv(dhs[i], pc1.get()[0][1], c)
-            jobs += [(dhs[i], feas[i], ctx.wshape, 0, c) + _targets(pc1), (dyls[i], hs[i], ctx.wshape, 0, c) + _targets(pc2)]
+            jobs1.append((dhs[i], feas[i], ctx.wshape, 0, c) + _targets(pc1))
+            jobs2.append((dyls[i], hs[i], ctx.wshape2, 0, c) + _targets(pc2))
         DualChain.end_of_node(True)
-        inplace = all(_targets(pc)[0] is not None for i in live for pc in legs[i])
-        for k, (dw, db) in enumerate(_wgrad(jobs, c, c, inplace=inplace) if jobs else []):
-            i, which = live[k // 2], k % 2
-            if _targets(legs[i][which])[0] is None:
-                grads[4 * i + 2 * which], grads[4 * i + 2 * which + 1] = dw, db
+        for which, res in enumerate(_leg_wgrad(jobs1, jobs2, c, ctx.wshape2[0]) if jobs1 else ()):
+            for i, (dw, db) in zip(live, res):
+                if _targets(legs[i][which])[0] is None:
+                    grads[4 * i + 2 * which], grads[4 * i + 2 * which + 1] = dw, db
         return (None, None, None, None) + tuple(dfeas) + tuple(grads)
 
 
