@@ -258,6 +258,9 @@ class LarvaNet(BaseModel):
         self.early_loss = {"0": False, "split": "split"}.get(os.environ.get("LARVA_EARLY_LOSS", "poll"), "poll")
         self.use_hip_graph = os.environ.get("LARVA_HIP_GRAPH", "1") != "0"
         self.hip_graph_fell_back = None   # reason, if a capture failed and the step went eager
+        # a failed capture raises instead of continuing ~2.4x slower with a printed warning: the drivers
+        # (train_larva.py / validate.py / runtime.py) set it unless --allow_eager_fallback, bench.py exits on a fallback
+        self.strict_graph = os.environ.get("LARVA_HIP_GRAPH_STRICT", "0") != "0"
         # Exits on a side stream: measured neutral-to-negative on MI355X at batch 16 (same-box A/B:
         # 2.36 ms without, 2.36 / 2.45 ms with, depending on the wgrad variant) -- opt-in.
         self.use_side_streams = os.environ.get("LARVA_SIDE_STREAMS", "0") != "0"
@@ -577,7 +580,7 @@ class LarvaNet(BaseModel):
                 try:
                     self._capture_step(input_tensor, truth_tensor)
                 except Exception as e:  # capture is an optimisation: fall back to plain launches
-                    if os.environ.get("LARVA_HIP_GRAPH_STRICT", "0") != "0":
+                    if self.strict_graph:
                         raise
                     print("WARNING: hipGraph capture failed (%s: %s); continuing with eager launches"
                           % (type(e).__name__, e))
@@ -824,6 +827,8 @@ class LarvaNet(BaseModel):
                     out = self.model(static_x)
             return static_x, graph, out
         except Exception as e:   # an optimisation only
+            if self.strict_graph:
+                raise
             print("WARNING: hipGraph capture of the inference forward failed (%s: %s); running it eagerly"
                   % (type(e).__name__, e))
             torch.cuda.synchronize()

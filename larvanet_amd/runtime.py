@@ -20,6 +20,8 @@ def build_parser():
     p.add_argument("--scales", type=str, default="4")
     p.add_argument("--cuda_device", type=str, default=None)
     p.add_argument("--restore_path", type=str, default=None)
+    p.add_argument("--allow_eager_fallback", action="store_true",
+                   help="if a hipGraph capture fails, go on with one launch per kernel (~2.4x slower) instead of raising")
     p.add_argument("--repeats", type=int, default=1, help="timed forwards per image (after one warm-up)")
     return p
 
@@ -37,6 +39,8 @@ def main(argv=None):
     model = importlib.import_module("larvanet_amd.models." + args.model).create_model()
     _, remaining = model.parse_args(remaining)
     model.prepare(is_training=False, scales=scales)
+    if hasattr(model, "strict_graph") and not args.allow_eager_fallback:
+        model.strict_graph = True   # a failed hipGraph capture is an error here, not a silent 2.4x slowdown
     if remaining:
         print("WARNING: found unhandled arguments: %s" % remaining)
     if args.restore_path is not None:

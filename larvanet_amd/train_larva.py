@@ -63,6 +63,8 @@ def build_parser():
     p.add_argument("--restore_target", type=str)
     p.add_argument("--global_step", type=int, default=0)
     p.add_argument("--async_loss", action="store_true", help="do not read the loss back every step")
+    p.add_argument("--allow_eager_fallback", action="store_true",
+                   help="if a hipGraph capture fails, go on with one launch per kernel (~2.4x slower) instead of raising")
     p.add_argument("--save_train_state", action="store_true",
                    help="also save optimizer / scheduler / counters / RNG with every checkpoint")
     p.add_argument("--resume_state", type=str, help="train_state_step*.pth to continue from (with --restore_path)")
@@ -90,6 +92,8 @@ def main(argv=None):
     model_args, remaining = model.parse_args(remaining)
     model.volume_per_step = (args.input_patch_size ** 2) * args.batch_size * 3 * world
     model.prepare(is_training=True, scales=scales, global_step=args.global_step)
+    if hasattr(model, "strict_graph") and not args.allow_eager_fallback:
+        model.strict_graph = True   # a failed hipGraph capture is an error here, not a silent 2.4x slowdown
     model.sync_loss = not args.async_loss
     if remaining:
         print("WARNING: found unhandled arguments: %s" % remaining)

@@ -35,6 +35,8 @@ def build_parser():
     p.add_argument("--restore_global_step", type=int, default=0)
     p.add_argument("--save_path", type=str)
     p.add_argument("--chop_forward", action="store_true")
+    p.add_argument("--allow_eager_fallback", action="store_true",
+                   help="if a hipGraph capture fails, go on with one launch per kernel (~2.4x slower) instead of raising")
     p.add_argument("--chop_overlap_size", type=int, default=20)
     p.add_argument("--host_psnr", action="store_true",
                    help="score on the host like the reference (the HR image travels over PCIe) even when no image "
@@ -63,6 +65,8 @@ def main(argv=None):
     model = importlib.import_module("larvanet_amd.models." + args.model).create_model()
     _, remaining = model.parse_args(remaining)
     model.prepare(is_training=False, scales=scales, global_step=args.restore_global_step)
+    if hasattr(model, "strict_graph") and not args.allow_eager_fallback:
+        model.strict_graph = True   # a failed hipGraph capture is an error here, not a silent 2.4x slowdown
     if remaining:
         print("WARNING: found unhandled arguments: %s" % remaining)
     if args.restore_path is not None:
