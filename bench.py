@@ -65,9 +65,9 @@ FULL_IMAGE = (3, 339, 510)                               # DIV2K-val-like LR ima
 # itself); they are READ from the CSVs under profiles/ at run time -- a tile change that is not followed by new PMC
 # passes shows as a stale file name here, not as a silently wrong constant.  FETCH_SIZE is doubled per the guide's
 # gfx950 correction for 16-byte-per-lane streams; both counters are in KB.
-PMC_CONV_CSV = "profiles/r02_pmc_conv_strip_vs_wide.csv"
-PMC_WGRAD_CSV = "profiles/r02_pmc_wgrad_pipe_traffic.csv"
-PMC_REDUCE_CSV = "profiles/r02_pmc_reduce_traffic.csv"
+PMC_CONV_CSV = "profiles/r03_pmc_conv.csv"      # tools/profile_r03.sh: passes over `bench.py --roofline-only`
+PMC_WGRAD_CSV = "profiles/r03_pmc_wgrad.csv"    # passes over `bench.py --wgrad-only` (flat grid over 40 layers + reduction)
+PMC_WGRAD_LAYERS = 40
 
 
 def pmc_mean(path, kernel_substr, counter):
@@ -91,13 +91,14 @@ def hbm_traffic_bytes(path, kernel_substr):
 def conv_traffic(dual):
     """(bytes per LAYER, source) of the fused conv+ReLU layer: two half-batch strip launches, or one whole-batch launch."""
     if dual:
-        return 2 * hbm_traffic_bytes(PMC_CONV_CSV, "conv3x3_mfma_strip_kernel<1>"), PMC_CONV_CSV
+        return 2 * hbm_traffic_bytes(PMC_CONV_CSV, "conv3x3_mfma_strip_kernel<48, 1>"), PMC_CONV_CSV
     return hbm_traffic_bytes(PMC_CONV_CSV, "conv3x3_mfma_kernel<48, true, 1>"), PMC_CONV_CSV
 
 
 def wgrad_traffic_per_layer():
-    """Weight-gradient kernel (32-layer launch) + its reduction, per layer."""
-    return (hbm_traffic_bytes(PMC_WGRAD_CSV, "wgrad3x3_pipe_kernel") + hbm_traffic_bytes(PMC_REDUCE_CSV, "wgrad_reduce_kernel")) / 32.0
+    """Weight-gradient kernel (the flat grid over 40 layers) + its reduction, per layer."""
+    return (hbm_traffic_bytes(PMC_WGRAD_CSV, "wgrad3x3_pipe_flat_kernel<48, 48>") +
+            hbm_traffic_bytes(PMC_WGRAD_CSV, "wgrad_reduce_kernel")) / float(PMC_WGRAD_LAYERS)
 
 
 TRAFFIC_NOTE = ("read at run time from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
@@ -464,7 +465,7 @@ def wgrad_block(dev, c=CH, jobs=40, iters=10):
            "timing": "HIP event pair around %d replays of a captured graph of the launch pair, back to back (median of 3)" % iters}
     if c == CH:
         blk["traffic"] = wgrad_traffic_per_layer() * nlayers
-        blk["traffic_source"] = TRAFFIC_NOTE % (PMC_WGRAD_CSV + " + " + PMC_REDUCE_CSV)
+        blk["traffic_source"] = TRAFFIC_NOTE % PMC_WGRAD_CSV
         blk["traffic_is"] = ("HBM-side bytes of the launch pair = per-layer figure x layers (dy + x read once, partial images "
                              "written and read once)")
     return blk
