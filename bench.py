@@ -430,8 +430,8 @@ def wgrad_block(dev, c=CH, jobs=40, iters=10):
 
     def pair():
         res = K.conv3x3_wgrad_partial_flat(js, c, c, 256)
-        if res is None:   # (the flat grid does not apply: the per-layer launch)
-            K.conv3x3_wgrad(js[:32], c, c, 8)
+        if res is None:   # (the flat grid does not apply: the per-layer launch, one or two workgroups per CU in total)
+            K.conv3x3_wgrad(js[:32], c, c, 8 * K.wgrad_cu_share(c, c))
             return False
         K.wgrad_reduce([dict(j, partial=p, splits=s, cout=c, cin=c) for j, p, s in zip(js, *res)])
         return True
@@ -457,7 +457,7 @@ def wgrad_block(dev, c=CH, jobs=40, iters=10):
     ms = sorted(runs)[1]
     achieved = conv_flop(c) * nlayers / (ms * 1e-3) / 1e12
     kernel = ("wgrad3x3_pipe_flat_kernel<%d, %d> (one grid of 256 workgroups over %d layers) + wgrad_reduce_kernel" % (c, c, nlayers)
-              if flat else "wgrad3x3 kernel for (%d, %d) + wgrad_reduce_kernel, 32 layers x 8 workgroups" % (c, c))
+              if flat else "wgrad3x3 kernel for (%d, %d) + wgrad_reduce_kernel, 32 layers x %d workgroups" % (c, c, 8 * K.wgrad_cu_share(c, c)))
     blk = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "kernel": kernel + ", 16x%dx48x48 fp32" % c, "layers": nlayers,
            "ms_per_launch_pair": ms, "ms_per_layer": ms / nlayers, "flop_per_layer": conv_flop(c), "traffic": None,
@@ -871,6 +871,40 @@ def main():
             del m2
         finally:
             os.environ.pop("LARVA_FORCE_SPLIT", None)
+
+    if extras:
+        # BASELINE configs 2 / 5 name 32- and 64-channel bodies, which the reference cannot express:
+        # the same M4B4 network built with --num_filters (every leg's last conv kept at 48 outputs), same batch,
+        # same loop semantics.  Extras: the headline stays the reference's 48-channel network.
+        line["other_widths"] = {}
+        for nf in (32, 64):
+            mw = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
+            mw.parse_args(list(FLAGS) + ["--num_filters=%d" % nf])
+            torch.manual_seed(0)
+            mw.volume_per_step = PATCH * PATCH * BATCH * 3
+            mw.prepare(is_training=True, scales=[SCALE])
+            mw.sync_loss = ref_semantics
+            for _ in range(max(a.warmup, 1)):
+                mw.train_step_larva(args, val, x_fresh, truth_fresh)
+            secs_w, _ = timed_rounds(mw, args, val, x_fresh, truth_fresh, a.steps, min(rounds, 3), False)
+            ms_w = float(np.median([s / a.steps * 1e3 for s in secs_w]))
+            with torch.no_grad():
+                for _ in range(5):
+                    mw.fwd_runtime(x_fresh)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    mw.fwd_runtime(x_fresh)
+                torch.cuda.synchronize()
+                inf_w = (time.perf_counter() - t0) / 20 * 1e3
+            cc = (2 * sum(BLOCKS) + len(BLOCKS)) * conv_flop(nf) + len(BLOCKS) * 2 * 9 * nf * 48 * BATCH * PATCH * PATCH
+            flop_w = 3 * cc + 2 * (2 * 9 * 3 * nf * BATCH * PATCH * PATCH)
+            line["other_widths"]["num_filters_%d" % nf] = {
+                "train_ms_per_step": ms_w, "value": HR_PIX_PER_BATCH / (ms_w * 1e-3) / 1e6, "unit": "HR Mpixels/s",
+                "flop_per_step": flop_w, "frac_of_peak": flop_w / (ms_w * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                "infer_ms_per_batch": inf_w, "hip_graph_fell_back": mw.hip_graph_fell_back,
+                "what": "LarvaNet x4 M4B4 with --num_filters=%d (build-side extension, no reference counterpart)" % nf}
+            del mw
 
     # inference forward (extra information)
     with torch.no_grad():

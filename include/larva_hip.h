@@ -155,6 +155,9 @@ int larva_conv3x3_fwd_strips_timed(const float* const* src, int n_src, int cin_p
  * [cin_off[i], cin_off[i]+cin_valid[i])) and db[i] ([cout], may be NULL).
  * (cout, cin) in {(48,48), (48,16), (32,32), (64,64)}.  Deterministic (no atomics). */
 long long larva_wgrad_partial_floats(int cout, int cin, int splits);
+/* Workgroups of the (cout, cin) weight-gradient kernel that share a CU (1 or 2: the small shapes -- (32,32), the (C,16)
+ * heads -- fit twice and hide each other's staging phases): launch 256 * this many workgroups in total to fill the chip. */
+int larva_wgrad_cu_share(int cout, int cin);
 int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* const* partial,
                         float* const* dw, float* const* db, const int* cin_off,
                         const int* cin_valid, const int* w_cin_total, int njobs, int splits,

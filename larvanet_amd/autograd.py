@@ -415,8 +415,10 @@ def _targets(pc):
     return None, None
 
 
-def _splits(njobs):
-    return max(1, _WGRAD_WORKGROUPS // njobs)
+def _splits(njobs, cout=48, cin=48):
+    """Workgroups per layer of a weight-gradient launch over `njobs` layers: one workgroup per CU in total, two where
+    two of that shape's workgroups fit a CU (kernels.wgrad_cu_share)."""
+    return max(1, _WGRAD_WORKGROUPS * K.wgrad_cu_share(cout, cin) // njobs)
 
 
 class DeferredWgrad:
@@ -499,7 +501,7 @@ class DeferredWgrad:
                 if extra is not None:
                     reduce_jobs.append(dict(extra, partial=res[0][-1], splits=res[1][-1], cout=48, cin=16))
                 continue
-            parts, used = K.conv3x3_wgrad_partial(chunk, cout, cin, _splits(len(chunk)))
+            parts, used = K.conv3x3_wgrad_partial(chunk, cout, cin, _splits(len(chunk), cout, cin))
             reduce_jobs += [dict(j, partial=p, splits=used, cout=cout, cin=cin) for j, p in zip(chunk, parts)]
         for i in range(0, len(reduce_jobs), 64):
             last = i + 64 >= len(reduce_jobs)
@@ -651,7 +653,7 @@ def _wgrad(jobs, cout, cin, inplace=False):
             batch = []
         for i in range(0, len(batch), 16):
             chunk = batch[i:i + 16]
-            parts = K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk)))
+            parts = K.conv3x3_wgrad(chunk, cout, cin, _splits(len(chunk), cout, cin))
             if side is not None:
                 SideStreams.keep(*parts)
     return out

@@ -740,8 +740,15 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_flat_kernel(WgradBatch b
   }
 }
 
+// Workgroups per CU of the register-staged kernel.  Its tile loop is "stage (global loads -> LDS, two barriers), then
+// the MFMA block": alone on a CU the matrix pipe idles during every staging phase (58-60 % of peak).  The small shapes
+// -- (32,32), the (C,16) heads -- need 54 / 46 KB of LDS and ~130 registers, so TWO workgroups fit a CU and run out of
+// phase (the caller then launches twice as many splits, larva_wgrad_cu_share); the larger shapes do not fit twice.
+template <int COUT, int CIN>
+constexpr int kWgradPerCu = (COUT * CIN <= 32 * 32 && 2 * WgCfg<COUT, CIN>::LDS_BYTES <= 160 * 1024) ? 2 : 1;
+
 template <int COUT, int CIN, bool VEC>
-__global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(WgradBatch b) {
+__global__ __launch_bounds__(256, (kWgradPerCu<COUT, CIN>)) void wgrad3x3_kernel(WgradBatch b) {
   using C = WgCfg<COUT, CIN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WgradJob& j = b.job[blockIdx.y];
@@ -1055,6 +1062,17 @@ int larva_conv3x3_wgrad_partial_flat_head(const float* const* dy, const float* c
   if (!head_dy || !head_x16 || !head_partial || !head_splits_out) return (int)hipErrorInvalidValue;
   return wgrad_flat_impl(dy, x, partial, njobs, head_dy, head_x16, head_partial, nwg, N, 48, 48, H, W, splits_out,
                          head_splits_out, stream);
+}
+
+// How many workgroups of the (cout, cin) weight-gradient kernel share a CU (1 or 2): a caller that wants the chip
+// full launches 256 * this many workgroups in total.
+int larva_wgrad_cu_share(int cout, int cin) {
+  if (cout == 48 && cin == 48) return 1;   // (the pipelined kernel: 159 KB of LDS)
+  if (cout == 32 && cin == 32) return kWgradPerCu<32, 32>;
+  if (cout == 48 && cin == 16) return kWgradPerCu<48, 16>;
+  if (cout == 32 && cin == 16) return kWgradPerCu<32, 16>;
+  if (cout == 64 && cin == 16) return kWgradPerCu<64, 16>;
+  return 1;
 }
 
 // Floats of partial-image workspace one job needs for `splits` workgroups.

@@ -111,6 +111,7 @@ SIGNATURES = {
     "larva_sum_scalars": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_void_p]),
     "larva_pixel_unshuffle4": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_wgrad_cu_share": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "larva_adamw_step_host": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
                                              ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                              ctypes.c_double, ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p]),

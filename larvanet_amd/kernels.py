@@ -367,6 +367,11 @@ def max_wgrad_jobs():
     return 64
 
 
+def wgrad_cu_share(cout, cin):
+    """Workgroups of the (cout, cin) weight-gradient kernel that fit one CU together (1 or 2)."""
+    return int(hip_lib.load().larva_wgrad_cu_share(int(cout), int(cin)))
+
+
 def conv3x3_wgrad(jobs, cout, cin, splits):
     """jobs: list (<= max_wgrad_jobs()) of dicts {dy, x, dw, db (or None), cin_off, cin_valid}; dw/db are
     overwritten.  All jobs share (N, cout, cin, H, W)."""
