@@ -335,7 +335,12 @@ struct WgPipe {
   static constexpr int LAG = 6;
 #endif
   static constexpr int MIN_GAPS = C::CT * (C::NB / 4);          // MFMAs per k-step of the lightest wave
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NSLOT + LAG <= 36 && MIN_GAPS >= 17;
+  // The k-step's fillers -- CT + NBW operand reads, two address steps, the global load, the LDS write -- are laid
+  // out one per MFMA gap where the lightest wave has >= 17 MFMAs per k-step ((48,48): 21); with fewer (round 3:
+  // (32,32), 8-10 MFMAs) they are dealt evenly over the gaps there are, up to two per gap (gap_of in pipe_gap_asm) --
+  // an MFMA's shadow holds ~24 issue cycles, a filler costs 4-16.
+  static constexpr bool SPREAD = MIN_GAPS >= 17;
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NSLOT + LAG <= 36 && MIN_GAPS >= 8;
 };
 
 // Per-thread, tile-invariant description of staging slot I: element offset of its 16 bytes
@@ -506,34 +511,58 @@ __device__ __forceinline__ void mfma_tied(f32x4& acc, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
+// Filler event E of a k-step -> the MFMA gap it is issued in.  Events in program order: E < G0 = CT + NBW: the
+// operand reads of the next k-step; G0: address step a; G0 + 1: address step b; G0 + 2: the global load of staging
+// slot KS; G0 + 3: the LDS write of slot KS - LAG.  SPREAD (>= 17 gaps on every wave): one event per gap with the
+// load / write staggered over the waves, as measured best for (48,48); else dealt evenly over the NG gaps.
+template <int G0, int NG, bool SPREAD, int WV>
+__host__ __device__ constexpr int gap_of(int e) {
+  if (SPREAD) return e < G0 + 2 ? e : (e == G0 + 2 ? G0 + 2 + (WV & 1) : G0 + 4 + WV);
+  return e * NG / (G0 + 4);
+}
+
+template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS, int M, int E>
+__device__ __forceinline__ void pipe_gap_events(PipeCtx<COUT, CIN, NBW>& x, int& gy, int& gx, uint64_t& addr) {
+  using C = WgCfg<COUT, CIN>;
+  using P = WgPipe<COUT, CIN>;
+  constexpr int G0 = C::CT + NBW;
+  constexpr int NG = C::CT * NBW + (BIAS ? C::CT : 0);
+  if constexpr (E < G0 + 4) {
+    if constexpr (gap_of<G0, NG, P::SPREAD, WV>(E) == M) {
+      if constexpr (E < G0) {
+        if constexpr (KS + 1 < 36) {
+          constexpr int ks = KS + 1, row = ks / 12, col = 4 * (ks % 12);
+          if constexpr (E < C::CT) {
+            x.av[ks & 1][E] = x.a_base[E * 16 * C::PSD + row * kTileCols + col];
+          } else {
+            constexpr int bi = B0 + (E - C::CT), cit = bi / 9, tap = bi % 9, ky = tap / 3, kx = tap % 3;
+            x.bv[ks & 1][E - C::CT] = x.b_base[cit * 16 * C::PSX + (row + ky) * kRS + col + kx];
+          }
+        }
+      } else if constexpr (E == G0 + 3) {
+        constexpr bool kWrites = KS >= P::LAG && KS - P::LAG < P::NSLOT;
+        if constexpr (kWrites) pipe_lds_write<COUT, CIN, KS - P::LAG>(x.g, x.nxt, x.stage[KS - P::LAG]);
+      } else if constexpr (KS < P::NSLOT) {
+        if constexpr (E == G0) pipe_addr_a<COUT, CIN, KS>(x.g, x.next, gy, gx);
+        if constexpr (E == G0 + 1) addr = pipe_addr_b<COUT, CIN, KS>(x.g, x.next, x.b, gy, gx);
+        if constexpr (E == G0 + 2) x.stage[KS] = *reinterpret_cast<const f32x4*>(addr);
+      }
+    }
+    pipe_gap_events<COUT, CIN, B0, NBW, BIAS, WV, KS, M, E + 1>(x, gy, gx, addr);
+  }
+}
+
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS, int M>
 __device__ __forceinline__ void pipe_gap_asm(PipeCtx<COUT, CIN, NBW>& x, int& gy, int& gx, uint64_t& addr) {
   using C = WgCfg<COUT, CIN>;
-  using P = WgPipe<COUT, CIN>;
   constexpr int NMAIN = C::CT * NBW;
   if constexpr (M < NMAIN) {
     mfma_tied(x.acc[M / NBW][M % NBW], x.av[KS & 1][M / NBW], x.bv[KS & 1][M % NBW]);
   } else {
     mfma_tied(x.bacc[M - NMAIN], x.av[KS & 1][M - NMAIN], x.one);
   }
-  // fillers: operand reads of the next k-step in the first gaps, then the staging slot
-  constexpr int G0 = C::CT + NBW;
-  if constexpr (KS + 1 < 36 && M < G0) {
-    constexpr int ks = KS + 1, row = ks / 12, col = 4 * (ks % 12);
-    if constexpr (M < C::CT) {
-      x.av[ks & 1][M] = x.a_base[M * 16 * C::PSD + row * kTileCols + col];
-    } else {
-      constexpr int bi = B0 + (M - C::CT), cit = bi / 9, tap = bi % 9, ky = tap / 3, kx = tap % 3;
-      x.bv[ks & 1][M - C::CT] = x.b_base[cit * 16 * C::PSX + (row + ky) * kRS + col + kx];
-    }
-  }
-  if constexpr (KS < P::NSLOT) {
-    if constexpr (M == G0) pipe_addr_a<COUT, CIN, KS>(x.g, x.next, gy, gx);
-    if constexpr (M == G0 + 1) addr = pipe_addr_b<COUT, CIN, KS>(x.g, x.next, x.b, gy, gx);
-    if constexpr (M == G0 + 2 + (WV & 1)) x.stage[KS] = *reinterpret_cast<const f32x4*>(addr);
-  }
-  constexpr bool kWrites = KS >= P::LAG && KS - P::LAG < P::NSLOT;
-  if constexpr (kWrites && M == G0 + 4 + WV) pipe_lds_write<COUT, CIN, KS - P::LAG>(x.g, x.nxt, x.stage[KS - P::LAG]);
+  // this gap's fillers (gap_of): operand reads of the next k-step, then the staging slot's address, load, LDS write
+  pipe_gap_events<COUT, CIN, B0, NBW, BIAS, WV, KS, M, 0>(x, gy, gx, addr);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -988,8 +1017,9 @@ static int wgrad_flat_impl(const float* const* dy, const float* const* x, float*
                            int cin, int H, int W, int* splits_out, int* head_splits_out, void* stream) {
   if (njobs < 1 || njobs > kMaxJobs || nwg < 1 || nwg > 32767 || N <= 0 || H <= 0 || W <= 0 || !splits_out)
     return (int)hipErrorInvalidValue;
-  if (cout != 48 || cin != 48 || W % 4 || !wgrad_use_pipe()) return (int)hipErrorNotSupported;
+  if (!((cout == 48 && cin == 48) || (cout == 32 && cin == 32)) || W % 4 || !wgrad_use_pipe()) return (int)hipErrorNotSupported;
   const bool head = head_dy || head_x16 || head_partial;
+  if (head && cout != 48) return (int)hipErrorNotSupported;   // (the head's tail role is priced for the 48-channel grid)
   if (head && (!head_dy || !head_x16 || !head_partial || !head_splits_out)) return (int)hipErrorInvalidValue;
   WgradBatch b{};
   for (int i = 0; i < njobs; ++i) {
@@ -1030,6 +1060,7 @@ static int wgrad_flat_impl(const float* const* dy, const float* const* x, float*
     *head_splits_out = nwg - w;
     if (*head_splits_out > larva_wgrad_flat_head_splits(njobs, nwg, (int)total)) return (int)hipErrorInvalidValue;
   }
+  if (cout == 32) return (int)launch_wgrad_flat<32, 32>(b, nwg, (hipStream_t)stream);
   return (int)launch_wgrad_flat<48, 48>(b, nwg, (hipStream_t)stream);
 }
 
@@ -1068,7 +1099,7 @@ int larva_conv3x3_wgrad_partial_flat_head(const float* const* dy, const float* c
 // full launches 256 * this many workgroups in total.
 int larva_wgrad_cu_share(int cout, int cin) {
   if (cout == 48 && cin == 48) return 1;   // (the pipelined kernel: 159 KB of LDS)
-  if (cout == 32 && cin == 32) return kWgradPerCu<32, 32>;
+  if (cout == 32 && cin == 32) return (WgPipe<32, 32>::FITS && wgrad_use_pipe()) ? 1 : kWgradPerCu<32, 32>;
   if (cout == 48 && cin == 16) return kWgradPerCu<48, 16>;
   if (cout == 32 && cin == 16) return kWgradPerCu<32, 16>;
   if (cout == 64 && cin == 16) return kWgradPerCu<64, 16>;

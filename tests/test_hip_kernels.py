@@ -770,9 +770,13 @@ def test_step_prologue_equals_its_three_launches(hip_device):
     assert torch.equal(x16[:, :3], x) and not bool(x16[:, 3:].any())
 
 
-@pytest.mark.parametrize("njobs,nwg,N,H,W", [(5, 7, 2, 9, 48), (3, 64, 1, 6, 48), (6, 4, 2, 7, 52), (1, 3, 2, 9, 48),
-                                              (40, 256, 4, 12, 48)])
-def test_flat_wgrad_grid_over_all_layers(hip_device, njobs, nwg, N, H, W):
+@pytest.mark.parametrize("njobs,nwg,N,H,W,C", [(5, 7, 2, 9, 48, 48), (3, 64, 1, 6, 48, 48), (6, 4, 2, 7, 52, 48), (1, 3, 2, 9, 48, 48),
+                                                (40, 256, 4, 12, 48, 48),
+                                                # round 3: the pipelined kernel at (32,32) -- 8-10 MFMAs per k-step, the
+                                                # k-step's fillers dealt two to a gap -- per layer and as the flat grid
+                                                (5, 7, 2, 9, 48, 32), (6, 4, 2, 7, 52, 32), (40, 256, 4, 12, 48, 32),
+                                                (8, 256, 16, 48, 48, 32)])
+def test_flat_wgrad_grid_over_all_layers(hip_device, njobs, nwg, N, H, W, C):
     """larva_conv3x3_wgrad_partial_flat: one grid over the tiles of all layers (a workgroup's share may
     cross layer boundaries, more workgroups than tiles, several layers per workgroup) + the fixed-order
     reduction, against the C oracle / torch per layer; and run to run the same bits."""
@@ -780,26 +784,26 @@ def test_flat_wgrad_grid_over_all_layers(hip_device, njobs, nwg, N, H, W):
     gen = torch.Generator().manual_seed(njobs * 100 + nwg)
     jobs = []
     for _ in range(njobs):
-        dy = (torch.randn(N, 48, H, W, generator=gen) * 1e-3).to(hip_device)
-        x = (torch.randn(N, 48, H, W, generator=gen) * 20).to(hip_device)
-        jobs.append({"dy": dy, "x": x, "dw": torch.full((48, 48, 3, 3), float("nan"), device=hip_device),
-                     "db": torch.full((48,), float("nan"), device=hip_device)})
-    res = K.conv3x3_wgrad_partial_flat(jobs, 48, 48, nwg)
+        dy = (torch.randn(N, C, H, W, generator=gen) * 1e-3).to(hip_device)
+        x = (torch.randn(N, C, H, W, generator=gen) * 20).to(hip_device)
+        jobs.append({"dy": dy, "x": x, "dw": torch.full((C, C, 3, 3), float("nan"), device=hip_device),
+                     "db": torch.full((C,), float("nan"), device=hip_device)})
+    res = K.conv3x3_wgrad_partial_flat(jobs, C, C, nwg)
     assert res is not None
     parts, splits = res
     tiles = N * ((H + 2) // 3) * ((W + 47) // 48)
     assert all(1 <= s <= min(nwg, tiles) + 1 for s in splits)
-    K.wgrad_reduce([dict(j, partial=p, splits=s, cout=48, cin=48) for j, p, s in zip(jobs, parts, splits)])
+    K.wgrad_reduce([dict(j, partial=p, splits=s, cout=C, cin=C) for j, p, s in zip(jobs, parts, splits)])
     torch.cuda.synchronize()
     for j in jobs:
-        dw_ref = torch.nn.grad.conv2d_weight(j["x"].double().cpu(), (48, 48, 3, 3), j["dy"].double().cpu(), padding=1)
+        dw_ref = torch.nn.grad.conv2d_weight(j["x"].double().cpu(), (C, C, 3, 3), j["dy"].double().cpu(), padding=1)
         db_ref = j["dy"].double().cpu().sum((0, 2, 3))
         dw, db = j["dw"].cpu().double(), j["db"].cpu().double()
         assert float((dw - dw_ref).abs().max()) <= 3e-5 * float(dw_ref.abs().max())
         assert float((db - db_ref).abs().max()) <= 3e-5 * float(db_ref.abs().max()) + 1e-9
     first = [j["dw"].clone() for j in jobs]
-    res2 = K.conv3x3_wgrad_partial_flat(jobs, 48, 48, nwg)
-    K.wgrad_reduce([dict(j, partial=p, splits=s, cout=48, cin=48) for j, p, s in zip(jobs, *res2)])
+    res2 = K.conv3x3_wgrad_partial_flat(jobs, C, C, nwg)
+    K.wgrad_reduce([dict(j, partial=p, splits=s, cout=C, cin=C) for j, p, s in zip(jobs, *res2)])
     torch.cuda.synchronize()
     assert all(torch.equal(a, j["dw"]) for a, j in zip(first, jobs))
 
