@@ -561,8 +561,31 @@ __device__ __forceinline__ void pipe_gap_asm(PipeCtx<COUT, CIN, NBW>& x, int& gy
   } else {
     mfma_tied(x.bacc[M - NMAIN], x.av[KS & 1][M - NMAIN], x.one);
   }
-  // this gap's fillers (gap_of): operand reads of the next k-step, then the staging slot's address, load, LDS write
-  pipe_gap_events<COUT, CIN, B0, NBW, BIAS, WV, KS, M, 0>(x, gy, gx, addr);
+  // this gap's fillers: operand reads of the next k-step, then the staging slot's address, load, LDS write
+  using P = WgPipe<COUT, CIN>;
+  if constexpr (P::SPREAD) {
+    // one filler per gap, spelled out (the (48,48) layout as measured in round 1; same-box it is 0.7 % faster than the
+    // same assignment produced by the generic walk below)
+    constexpr int G0 = C::CT + NBW;
+    if constexpr (KS + 1 < 36 && M < G0) {
+      constexpr int ks = KS + 1, row = ks / 12, col = 4 * (ks % 12);
+      if constexpr (M < C::CT) {
+        x.av[ks & 1][M] = x.a_base[M * 16 * C::PSD + row * kTileCols + col];
+      } else {
+        constexpr int bi = B0 + (M - C::CT), cit = bi / 9, tap = bi % 9, ky = tap / 3, kx = tap % 3;
+        x.bv[ks & 1][M - C::CT] = x.b_base[cit * 16 * C::PSX + (row + ky) * kRS + col + kx];
+      }
+    }
+    if constexpr (KS < P::NSLOT) {
+      if constexpr (M == G0) pipe_addr_a<COUT, CIN, KS>(x.g, x.next, gy, gx);
+      if constexpr (M == G0 + 1) addr = pipe_addr_b<COUT, CIN, KS>(x.g, x.next, x.b, gy, gx);
+      if constexpr (M == G0 + 2 + (WV & 1)) x.stage[KS] = *reinterpret_cast<const f32x4*>(addr);
+    }
+    constexpr bool kWrites = KS >= P::LAG && KS - P::LAG < P::NSLOT;
+    if constexpr (kWrites && M == G0 + 4 + WV) pipe_lds_write<COUT, CIN, KS - P::LAG>(x.g, x.nxt, x.stage[KS - P::LAG]);
+  } else {
+    pipe_gap_events<COUT, CIN, B0, NBW, BIAS, WV, KS, M, 0>(x, gy, gx, addr);
+  }
   __builtin_amdgcn_sched_barrier(0);
 }
 
