@@ -55,6 +55,11 @@
 // (tools/ab_aux_lds.sh).
 #define LARVA_AUX_LDS 0
 #endif
+#ifndef LARVA_PRIO_BOOST
+// 1: a strip workgroup runs its prologue (until its first K chunk has landed) and its epilogue at wave priority 3 and
+// only its K loop at 1: with two workgroups per CU, the one that is not multiplying is the one its chain waits for.
+#define LARVA_PRIO_BOOST 0
+#endif
 #ifndef LARVA_OPERAND_DEPTH
 #define LARVA_OPERAND_DEPTH 2   // k-steps between an operand's LDS read and the MFMAs that use it (A/B: 1)
 #endif
@@ -75,15 +80,17 @@ __device__ unsigned long long* g_stamps = nullptr;
 #if LARVA_DIAG & 512
 // bit 9 (512, with bit 5): per-LAUNCH stamp areas for a whole graph of launches (tools/diag_overlap.py: which
 // workgroups of the two half-batch chains are resident together?).  Every launch built while a slot counter is
-// armed (larva_diag_arm_slots) takes the next area of kDiagWgPerSlot x 8 stamps: [0] kernel entry, [1] chunk 0
-// landed, [2] K loop done, [3] stores drained (100 MHz wall clock), [4] HW_ID | XCC_ID << 32 of wave 0.
+// armed (larva_diag_arm_slots) takes the next area of kDiagWgPerSlot x 16 stamps: [0] kernel entry, [1] chunk 0
+// landed, [2] K loop done, [3] stores drained (100 MHz wall clock), [4] HW_ID | XCC_ID << 32 of wave 0, and the
+// prologue's steps: [5] arguments + tile decode done, [6] chunk 0's weight pieces issued, [7] bias / epilogue operands
+// requested, [8] chunk 0's input pieces issued, [9] chunk 1 issued.
 constexpr int kDiagWgPerSlot = 256;
 __device__ int g_slot_of_launch = 0;   // (unused on the device: the slot travels in ConvArgs)
 __device__ __forceinline__ void stamp_slot(int slot, int k) {
   if (!g_stamps || threadIdx.x != 0 || slot < 0 || blockIdx.x >= kDiagWgPerSlot) return;
-  const int idx = k == 0 ? 0 : k == 2 ? 1 : k == 3 ? 2 : k == 5 ? 3 : -1;
+  const int idx = k == 0 ? 0 : k == 2 ? 1 : k == 3 ? 2 : k == 5 ? 3 : k == 6 ? 5 : k == 7 ? 6 : k == 14 ? 7 : k == 15 ? 8 : k == 1 ? 9 : -1;
   if (idx < 0) return;
-  unsigned long long* p = g_stamps + ((size_t)slot * kDiagWgPerSlot + blockIdx.x) * 8;
+  unsigned long long* p = g_stamps + ((size_t)slot * kDiagWgPerSlot + blockIdx.x) * 16;
   p[idx] = __builtin_amdgcn_s_memrealtime();
   if (k == 0) {
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
@@ -754,6 +761,9 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         wait_and_barrier<(LARVA_DIAG & 2) ? 0 : C::NPW>();
       }
       if (chunk == 0) stamp(2);
+      if constexpr (LARVA_PRIO_BOOST && G::COLS == 16) {
+        if (chunk == 0) __builtin_amdgcn_s_setprio(1);
+      }
       stamp(8 + (chunk < 7 ? chunk : 7));
       const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
       if constexpr (!(LARVA_DIAG & 1)) {
@@ -770,6 +780,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     }
     // no LDS-DMA may be in flight when the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (LARVA_PRIO_BOOST && G::COLS == 16) __builtin_amdgcn_s_setprio(3);
     if constexpr (AUXLDS) {
       // the epilogue's operands, streamed by the loader wave: the first into the tile behind the ring (landed by
       // the barrier of chunk 3; with fewer chunks, or with a second operand -- in stage `stage`, issued two chunks
@@ -1078,7 +1089,7 @@ __global__ __launch_bounds__(320, 2) void conv3x3_mfma_strip_kernel(ConvArgs a) 
   const int y0 = (int)(e & 0xfffu), x0 = (int)((e >> 12) & 0xfffu);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  __builtin_amdgcn_s_setprio(1);
+  __builtin_amdgcn_s_setprio(LARVA_PRIO_BOOST ? 3 : 1);
   if (e >> 31) strip_roles<COUT, EPI, GeoS5>(a, smem, wave, n, y0, x0, tid);
   else strip_roles<COUT, EPI, GeoS4>(a, smem, wave, n, y0, x0, tid);
 }

@@ -17,7 +17,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tools", "_diag", "liblarva_overlap.so")
-WG, SLOT_WORDS = 256, 8
+WG, SLOT_WORDS = 256, 16
 
 
 def build():
@@ -144,6 +144,20 @@ def main():
         kl = np.median(np.concatenate([tt[2 * i + k, :, 2] - tt[2 * i + k, :, 1] for k in (0, 1)]))
         if i < 6 or i >= chain - 3 or i % 8 == 0:
             w("%5d %8.1f -%8.1f  %8.1f -%8.1f  %9.2f %9.2f %9.2f" % (i, a0[0], a0[1], a1[0], a1[1], ov, life, kl))
+    steady = slice(16, nslots)
+    pro = np.median(tt[steady, :, 1] - tt[steady, :, 0])
+    kl = np.median(tt[steady, :, 2] - tt[steady, :, 1])
+    epi = np.median(tt[steady, :, 3] - tt[steady, :, 2])
+    skew_in = np.median([tt[s_, :, 0].max() - tt[s_, :, 0].min() for s_ in range(16, nslots)])
+    skew_out = np.median([tt[s_, :, 3].max() - tt[s_, :, 3].min() for s_ in range(16, nslots)])
+    gap = np.median([tt[s_ + 2, :, 0].min() - tt[s_, :, 3].max() for s_ in range(16, nslots - 2)])
+    w("a workgroup's life (medians, layers 8+): entry -> first chunk landed %.2f us, K loop %.2f us, K loop done -> stores drained "
+      "%.2f us; per launch: first to last workgroup entry %.2f us, first to last drain %.2f us; last drain of a launch -> first "
+      "entry of the chain's next launch %.2f us" % (pro, kl, epi, skew_in, skew_out, gap))
+    raw = t[16:, :, :].astype(np.float64) * 0.01
+    ph = [np.median(raw[:, :, b_] - raw[:, :, a_]) for a_, b_ in ((0, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 1))]
+    w("the prologue, step by step (medians): arguments + tile decode %.2f us, chunk 0's weight pieces issued +%.2f, bias requested "
+      "+%.2f, input plan + chunk 0's input pieces +%.2f, chunk 1's pieces +%.2f, first chunk landed (wait + barrier) +%.2f" % tuple(ph))
     busy0 = union_len([lay[2 * i] for i in range(chain)])
     busy1 = union_len([lay[2 * i + 1] for i in range(chain)])
     w("chain 0 has a launch resident %.1f us, chain 1 %.1f us, both at once %.1f us of the %.1f us span (%.0f %%)"
