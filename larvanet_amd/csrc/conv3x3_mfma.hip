@@ -88,7 +88,9 @@ constexpr int kDiagWgPerSlot = 256;
 __device__ int g_slot_of_launch = 0;   // (unused on the device: the slot travels in ConvArgs)
 __device__ __forceinline__ void stamp_slot(int slot, int k) {
   if (!g_stamps || threadIdx.x != 0 || slot < 0 || blockIdx.x >= kDiagWgPerSlot) return;
-  const int idx = k == 0 ? 0 : k == 2 ? 1 : k == 3 ? 2 : k == 5 ? 3 : k == 6 ? 5 : k == 7 ? 6 : k == 14 ? 7 : k == 15 ? 8 : k == 1 ? 9 : -1;
+  // (bit 11, 2048: also the prologue's steps -- five more stamps per workgroup cost ~1 us of its life)
+  const int idx = k == 0 ? 0 : k == 2 ? 1 : k == 3 ? 2 : k == 5 ? 3
+                  : !(LARVA_DIAG & 2048) ? -1 : k == 6 ? 5 : k == 7 ? 6 : k == 14 ? 7 : k == 15 ? 8 : k == 1 ? 9 : -1;
   if (idx < 0) return;
   unsigned long long* p = g_stamps + ((size_t)slot * kDiagWgPerSlot + blockIdx.x) * 16;
   p[idx] = __builtin_amdgcn_s_memrealtime();

@@ -16,14 +16,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "tools", "_diag", "liblarva_overlap.so")
+STEPS = "--prologue-steps" in sys.argv     # the heavier build that also stamps the prologue's steps
+LIB = os.path.join(ROOT, "tools", "_diag", "liblarva_overlap%s.so" % ("_steps" if STEPS else ""))
 WG, SLOT_WORDS = 256, 16
 
 
 def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     csrc = os.path.join(ROOT, "larvanet_amd", "csrc")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLARVA_DIAG=544", "-I" + csrc,
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLARVA_DIAG=%d" % (544 + (2048 if STEPS else 0)), "-I" + csrc,
            os.path.join(csrc, "conv3x3_mfma.hip"), os.path.join(csrc, "wgrad3x3_mfma.hip"),
            os.path.join(csrc, "larva_pointwise.hip"), "-o", LIB]
     subprocess.check_call(cmd)
@@ -115,7 +116,7 @@ def main():
     w = out.append
     w("two half-batch chains of %d conv3x3+ReLU strip launches (8x48x48x48 each, 256 workgroups), one captured graph, "
       "un-profiled replay; in-kernel 100 MHz stamps of the LAST of 33 replays" % chain)
-    w("activations N(0,1)*20 kept at that scale (RMS after the last layer %.1f); build -DLARVA_DIAG=544" % rms)
+    w("activations N(0,1)*20 kept at that scale (RMS after the last layer %.1f); build -DLARVA_DIAG=%d" % (rms, 544 + (2048 if STEPS else 0)))
     w("HIP event pair around 10 replays (median of 3): %.2f us per full-batch layer  <- what bench.py's roofline.avg_ms measures "
       "(the stamped build pays for its stamps: compare with the bench line of the same box)" % event_us)
     w("same process, stamps not armed: bench.py's roofline.avg_ms = (t160 - t40) / 120 = %.2f us per full-batch layer; t40 / 40 = %.2f us"
@@ -154,10 +155,12 @@ def main():
     w("a workgroup's life (medians, layers 8+): entry -> first chunk landed %.2f us, K loop %.2f us, K loop done -> stores drained "
       "%.2f us; per launch: first to last workgroup entry %.2f us, first to last drain %.2f us; last drain of a launch -> first "
       "entry of the chain's next launch %.2f us" % (pro, kl, epi, skew_in, skew_out, gap))
-    raw = t[16:, :, :].astype(np.float64) * 0.01
-    ph = [np.median(raw[:, :, b_] - raw[:, :, a_]) for a_, b_ in ((0, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 1))]
-    w("the prologue, step by step (medians): arguments + tile decode %.2f us, chunk 0's weight pieces issued +%.2f, bias requested "
-      "+%.2f, input plan + chunk 0's input pieces +%.2f, chunk 1's pieces +%.2f, first chunk landed (wait + barrier) +%.2f" % tuple(ph))
+    if STEPS:
+        raw = t[16:, :, :].astype(np.float64) * 0.01
+        ph = [np.median(raw[:, :, b_] - raw[:, :, a_]) for a_, b_ in ((0, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 1))]
+        w("the prologue, step by step (medians; this build's five extra stamps per workgroup cost ~1 us of its life): arguments + "
+          "tile decode %.2f us, chunk 0's weight pieces issued +%.2f, bias requested +%.2f, input plan + chunk 0's input pieces "
+          "+%.2f, chunk 1's pieces +%.2f, first chunk landed (wait + barrier) +%.2f" % tuple(ph))
     busy0 = union_len([lay[2 * i] for i in range(chain)])
     busy1 = union_len([lay[2 * i + 1] for i in range(chain)])
     w("chain 0 has a launch resident %.1f us, chain 1 %.1f us, both at once %.1f us of the %.1f us span (%.0f %%)"
@@ -225,8 +228,9 @@ def main():
           "4 + 4 %.0f %%" % (100 * pairs["5+4"] / tp, 100 * pairs["5+5"] / tp, 100 * pairs["4+4"] / tp))
     text = "\n".join(out)
     print(text)
-    if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):
-        with open(sys.argv[1], "w") as f:
+    outs = [a_ for a_ in sys.argv[1:] if not a_.startswith("--")]
+    if outs:
+        with open(outs[0], "w") as f:
             f.write(text + "\n")
 
 
