@@ -660,9 +660,12 @@ def timed_rounds(model, args, val, x, truth, steps, rounds, dist_on):
     per_rank = None
     if dist_on:
         t = torch.tensor(secs, dtype=torch.float64, device=model.device)
-        every = [torch.empty_like(t) for _ in range(td.get_world_size())]
-        td.all_gather(every, t)
-        per_rank = [[float(v) for v in r.cpu()] for r in every]   # each rank's own wall time of every round
+        # each rank's own wall time of every round: a sum all-reduce of a [world, rounds] table with one row filled
+        # (all-reduce is the one collective every backend has for device tensors; gloo has no device all-gather)
+        table = torch.zeros(td.get_world_size(), len(secs), dtype=torch.float64, device=model.device)
+        table[td.get_rank()] = t
+        td.all_reduce(table, op=td.ReduceOp.SUM)
+        per_rank = [[float(v) for v in r] for r in table.cpu()]
         td.all_reduce(t, op=td.ReduceOp.MAX)
         secs = [float(v) for v in t.cpu()]
     timed_rounds.per_rank = per_rank
