@@ -333,3 +333,30 @@ def test_edsr_restatement_train_steps_f15(golden):
     np.testing.assert_allclose(up[:, ::3, ::3], g["up_sample"], rtol=0, atol=1e-3)
     full = E.init_state_dict()
     assert sorted(full) == list(g["default_keys"]) and sum(v.numel() for v in full.values()) == int(g["default_params"])
+
+
+def test_edsr_cpu_driver_loop_config0(tmp_path, capsys):
+    """BASELINE configs[0] end to end on the CPU: the reference's train.py loop (train.py:83-105) over the EDSR
+    restatement and the synthetic loader -- flag chaining, arguments.json, the log / save cadence, `model_%d.pth`
+    names (models/edsr.py:60-62), the step-decayed learning rate, and a loss that goes down."""
+    from oracle import train_edsr_cpu as D
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model, losses = D.main(["--train_path", str(tmp_path), "--max_steps=6", "--log_freq=2", "--save_freq=3", "--batch_size=2",
+                            "--input_patch_size=12", "--synthetic_images=2", "--synthetic_lr_size=16", "--threads=4",
+                            "--edsr_conv_features=16", "--edsr_res_blocks=2", "--edsr_learning_rate=1e-3",
+                            "--edsr_learning_rate_decay_steps=4", "--bogus_flag=1"])
+    out = capsys.readouterr().out
+    assert model.global_step == 6 and len(losses) == 6
+    assert "WARNING: found unhandled arguments: ['--bogus_flag=1']" in out
+    assert out.count("step ") == 3 + 2 and "step 6, lr 0.000500" in out and "step 4, lr 0.001000" in out
+    import json as _json
+    import os as _os
+    saved = sorted(n for n in _os.listdir(str(tmp_path)) if n.endswith(".pth"))
+    assert saved == ["model_3.pth", "model_6.pth"]
+    a = _json.load(open(_os.path.join(str(tmp_path), "arguments.json")))
+    assert a["batch_size"] == 2 and a["edsr_res_blocks"] == 2 and a["max_steps"] == 6
+    ck = torch.load(_os.path.join(str(tmp_path), "model_6.pth"))
+    assert sorted(ck) == sorted(model.state_dict()) and losses[-1] < losses[0]
+    up = model.upscale([np.zeros((3, 8, 9), np.float32)], 4)
+    assert up.shape == (1, 3, 32, 36)
