@@ -123,6 +123,24 @@ def trajectory_batches(nb=4, seed0=1300):
     return pool
 
 
+def synthetic_task(steps=200):
+    """F16's data, from the repo's own dataset-free loader (larvanet_amd/dataloaders/synthetic_loader.py: pure numpy,
+    seeded): `steps` training batches of 4 x 3 x 16 x 16 -> 4 x 3 x 64 x 64 and a 3-image validation loader."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    S = importlib.import_module("larvanet_amd.dataloaders.synthetic_loader")
+    tr = S.create_loader()
+    tr.parse_args(["--synthetic_images=6", "--synthetic_lr_size=40", "--data_seed=3"])
+    tr.prepare([4])
+    batches = []
+    for _ in range(steps):
+        x, t = tr.get_patch_batch(4, 4, 16)
+        batches.append((torch.from_numpy(np.stack(x)), torch.from_numpy(np.stack(t))))
+    val = S.create_loader()
+    val.parse_args(["--synthetic_images=3", "--synthetic_lr_size=32", "--data_seed=9"])
+    val.prepare([4])
+    return batches, val
+
+
 F13_ARGV = ["--num_modules=2", "--num_blocks=2,2", "--lr=2e-3", "--val_volume=1.2e9"]
 F13_STEPS = 72
 F13_VOLUME_PER_STEP = 400000000   # 3 steps per validation; file names run through vol1G, vol2G, vol4G ...
@@ -204,6 +222,45 @@ def main_r3(only):
                  global_step=np.array(model.global_step),
                  ulp_tube_loss=np.maximum.accumulate(env_loss), ulp_tube_psnr=np.maximum.accumulate(env_psnr),
                  ulp_tube_weights_mean=np.array(env_w), ulp_tube_same_lrs=np.array(lrs_same))
+
+    if "f16" in only:
+        # A short REALISTIC training run (the stand-in north_star's "PSNR within 0.02 dB of reference" can have without
+        # DIV2K): the reference's own train_step_larva for 200 steps at its default learning rate on a learnable task --
+        # the repo's dataset-free synthetic loader (smooth images, LR = box-filtered HR), 200 different batches of
+        # 4 x 3 x 16 x 16 patches, validation on 3 synthetic images at step 1 and every 25 steps -- plus how far the
+        # reference moves when its initial weights move by one ulp (two perturbed runs).
+        def f16_run(perturb_seed=None):
+            model = make_ref_model("LarvaNet", ["--num_modules=2", "--num_blocks=2,2", "--val_volume=25"], seed=0)
+            if perturb_seed is not None:
+                gen = torch.Generator().manual_seed(perturb_seed)
+                with torch.no_grad():
+                    for p_ in model.model.parameters():
+                        p_.mul_(1 + 1e-7 * torch.randn(p_.shape, generator=gen))
+            attach_training(model)
+            model.volume_per_step = 1
+            batches, val = synthetic_task()
+            tmp = tempfile.mkdtemp()
+            args = types.SimpleNamespace(train_path=tmp)
+            losses, lrs, psnrs = [], [], []
+            for step in range(200):
+                x, t = batches[step]
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    losses.append(model.train_step_larva(args, val, x, t, None))
+                lrs.append(model.get_lr())
+                psnrs += [float(line.split("psnr=")[1].split(",")[0]) for line in buf.getvalue().splitlines() if "psnr=" in line]
+            f13_cleanup(tmp)
+            return losses, lrs, psnrs
+
+        losses, lrs, psnrs = f16_run()
+        tube_l, tube_p = np.zeros(200), np.zeros(len(psnrs))
+        for seed in (21, 22):
+            l2, _, p2 = f16_run(seed)
+            tube_l = np.maximum(tube_l, np.abs(np.array(l2) / np.array(losses) - 1))
+            tube_p = np.maximum(tube_p, np.abs(np.array(p2) - np.array(psnrs)))
+        np.savez(os.path.join(OUT, "f16_realistic_training.npz"), losses=np.array(losses, np.float64), lrs=np.array(lrs, np.float64),
+                 psnrs=np.array(psnrs, np.float64), ulp_tube_loss=np.maximum.accumulate(tube_l),
+                 ulp_tube_psnr=np.maximum.accumulate(tube_p))
 
     if "f15" in only:
         # BASELINE configs[0]: the reference's EDSR through train.py's loop (train.py:83-105: get_next_train_scale,
@@ -294,7 +351,7 @@ def main():
         main_r2(sys.argv[2:] or ["f11", "f12"])
         return
     if len(sys.argv) > 1 and sys.argv[1] == "r3":
-        main_r3(sys.argv[2:] or ["f13", "f14", "f15"])
+        main_r3(sys.argv[2:] or ["f13", "f14", "f15", "f16"])
         return
 
     # ---------------- F1/F2: M2B2 weights, staged outputs on a 2x3x12x12 input ----------------

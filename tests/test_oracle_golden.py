@@ -360,3 +360,35 @@ def test_edsr_cpu_driver_loop_config0(tmp_path, capsys):
     assert sorted(ck) == sorted(model.state_dict()) and losses[-1] < losses[0]
     up = model.upscale([np.zeros((3, 8, 9), np.float32)], 4)
     assert up.shape == (1, 3, 32, 36)
+
+
+def _synthetic_task(steps=200):
+    """F16's data (tests/golden/make_golden.py synthetic_task): the repo's seeded, dataset-free loader."""
+    from larvanet_amd.dataloaders import synthetic_loader as S
+    tr = S.create_loader()
+    tr.parse_args(["--synthetic_images=6", "--synthetic_lr_size=40", "--data_seed=3"])
+    tr.prepare([4])
+    batches = []
+    for _ in range(steps):
+        x, t = tr.get_patch_batch(4, 4, 16)
+        batches.append((torch.from_numpy(np.stack(x)), torch.from_numpy(np.stack(t))))
+    val = S.create_loader()
+    val.parse_args(["--synthetic_images=3", "--synthetic_lr_size=32", "--data_seed=9"])
+    val.prepare([4])
+    return batches, val
+
+
+def test_torch_restatement_realistic_training_f16(golden):
+    """F16: 200 steps of the reference's train_step_larva at its default learning rate on a learnable task (smooth
+    synthetic images, LR = box-filtered HR), 9 validations: the oracle's PSNR trajectory within 0.005 dB of the
+    reference's (the reference re-run one ulp away: 0.0018 dB), losses within 1e-3."""
+    g = golden("f16_realistic_training.npz")
+    torch.set_num_threads(4)
+    batches, val = _synthetic_task()
+    pairs = [val.get_image_pair(i, 4)[:2] for i in range(val.get_num_images())]
+    sd = T.init_state_dict([2, 2], seed=0)
+    rec = T.train_trajectory(sd, batches, 200, [2, 2], pairs, 1, 25, lr=4e-4)
+    assert len(rec["psnrs"]) == len(g["psnrs"]) == 9 and rec["lrs"] == list(g["lrs"])
+    np.testing.assert_allclose(rec["psnrs"], g["psnrs"], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(rec["losses"], g["losses"], rtol=1e-3)
+    assert g["psnrs"][-1] > g["psnrs"][0] + 0.03    # (the task is learnable: the reference's PSNR goes up)
