@@ -85,13 +85,9 @@ struct WgCfg {
   static constexpr int CT = COUT / 16;
   static constexpr int NB = (CIN / 16) * 9;  // B operands: (ci group, tap)
   static constexpr int NBW = (NB + 3) / 4;   // per wave (last waves may own one fewer)
-  // Channel strides == 2*odd (mod 32): 16 channels x 2 adjacent pixels hit 32 distinct banks.  Where two tile buffers
-  // with 16-byte aligned strides still fit the LDS (the shapes below 48 x 48; round 3) the strides are 148 / 284 instead
-  // -- 20 and 28 (mod 32): the 64 lanes of an operand read still spread two to a bank -- and a staging slot is ONE
-  // ds_write_b128 instead of two ds_write_b64 (~64 issue cycles each in a k-step that has ~24 to spare per MFMA).
-  static constexpr bool ALIGN16 = COUT * CIN < 48 * 48 && 2 * (COUT * 148 + CIN * 284 + 8) * 4 <= 160 * 1024;
-  static constexpr int PSD = ALIGN16 ? 148 : 146;   // dy: 3 rows x 48
-  static constexpr int PSX = ALIGN16 ? 284 : 278;   // x : 5 rows x kRS (tail of the last row unused)
+  // Channel strides == 2*odd (mod 32): 16 channels x 2 adjacent pixels hit 32 distinct banks.
+  static constexpr int PSD = 146;            // dy: 3 rows x 48
+  static constexpr int PSX = 278;            // x : 5 rows x kRS (tail of the last row unused)
   static constexpr int DY_FLOATS = COUT * PSD;
   static constexpr int X_FLOATS = CIN * PSX + 8;
   static constexpr size_t LDS_BYTES = (DY_FLOATS + X_FLOATS) * sizeof(float);
@@ -173,16 +169,11 @@ __device__ __forceinline__ void wg_load(const WgradBatch& b, const WgradJob& j, 
   st.ok_x = ok_x;
 }
 
-template <bool ALIGN16 = false>
 __device__ __forceinline__ void lds_store4(float* p, f32x4 v) {
-  if constexpr (ALIGN16) {
-    *reinterpret_cast<f32x4*>(p) = v;
-  } else {
-    // Channel bases are only 8-byte aligned (odd strides/2), so two 8-byte stores.
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
-    *reinterpret_cast<f32x2*>(p + 2) = f32x2{v[2], v[3]};
-  }
+  // Channel bases are only 8-byte aligned (odd strides/2), so two 8-byte stores.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
+  *reinterpret_cast<f32x2*>(p + 2) = f32x2{v[2], v[3]};
 }
 
 template <int COUT, int CIN, bool VEC>
@@ -200,7 +191,7 @@ __device__ __forceinline__ void wg_store(float* s_dy, float* s_x, int tid,
       const int q = rem - r * 12;
       f32x4 v = st.dy[i];
       if constexpr (VEC) v = ((st.ok_dy >> i) & 1u) ? v : zero;
-      lds_store4<C::ALIGN16>(s_dy + co * C::PSD + r * kTileCols + 4 * q, v);
+      lds_store4(s_dy + co * C::PSD + r * kTileCols + 4 * q, v);
     }
   }
 #pragma unroll
@@ -213,7 +204,7 @@ __device__ __forceinline__ void wg_store(float* s_dy, float* s_x, int tid,
       const int q = rem - r * 14;
       f32x4 v = st.x[i];
       if constexpr (VEC) v = ((st.ok_x >> i) & 1u) ? v : zero;
-      lds_store4<C::ALIGN16>(s_x + ci * C::PSX + r * kRS + 4 * q, v);
+      lds_store4(s_x + ci * C::PSX + r * kRS + 4 * q, v);
     }
   }
 }
@@ -429,9 +420,9 @@ __device__ __forceinline__ void pipe_lds_write(const PipeGeom<COUT, CIN>& g, flo
   constexpr int slots = (I < C::DY_ITERS) ? C::DY_SLOTS : C::X_SLOTS;
   constexpr int i = (I < C::DY_ITERS) ? I : I - C::DY_ITERS;
   if constexpr (i * 256 + 255 < slots) {
-    lds_store4<C::ALIGN16>(buf + (g.pos[I] & 0xffff), v);
+    lds_store4(buf + (g.pos[I] & 0xffff), v);
   } else {  // only some threads own a slot in the last round
-    if (!(g.pos[I] >> 30)) lds_store4<C::ALIGN16>(buf + (g.pos[I] & 0xffff), v);
+    if (!(g.pos[I] >> 30)) lds_store4(buf + (g.pos[I] & 0xffff), v);
   }
 }
 
