@@ -60,6 +60,15 @@
 // only its K loop at 1: with two workgroups per CU, the one that is not multiplying is the one its chain waits for.
 #define LARVA_PRIO_BOOST 0
 #endif
+#ifndef LARVA_RING_STAGES
+// Stages of the LDS-DMA ring (loader-wave path).  3 (the product): chunks c + 1 and c + 2 in flight while chunk c
+// multiplies, two workgroups per CU.  2 (experiment, with -DLARVA_WG_PER_CU=3): one chunk in flight, 40 instead of 60 KiB
+// per strip workgroup, so that three workgroups share a CU and hide each other's waits by occupancy instead.
+#define LARVA_RING_STAGES 3
+#endif
+#ifndef LARVA_WG_PER_CU
+#define LARVA_WG_PER_CU 2
+#endif
 #ifndef LARVA_OPERAND_DEPTH
 #define LARVA_OPERAND_DEPTH 2   // k-steps between an operand's LDS read and the MFMAs that use it (A/B: 1)
 #endif
@@ -214,7 +223,10 @@ struct ConvCfg {
   static constexpr int NPW = (PIECES + 3) / 4;                              // pieces per wave per chunk
   static constexpr int STAGE_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr int STEPS = 9 * (kCh / 4);                               // 18 k-steps per chunk
-  static constexpr size_t LDS_BYTES_DMA = 3 * STAGE_FLOATS * sizeof(float);
+  static constexpr int NST = LARVA_RING_STAGES;                              // ring stages
+  static constexpr int AHEAD = NST - 1;                                      // chunks in flight beside the one multiplying
+  static_assert(NST == 2 || NST == 3, "ring of two or three stages");
+  static constexpr size_t LDS_BYTES_DMA = NST * STAGE_FLOATS * sizeof(float);
   // LDS-DMA path: a fifth wave issues the pieces of chunks >= 2 (see run_loader); it keeps two
   // chunks in flight, and vmcnt counts 63 operations at most.
   static constexpr bool LOADER = LARVA_LOADER_WAVE && 2 * PIECES <= 63;
@@ -394,12 +406,13 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
     // itself (chunks 0 and 1 come from the MFMA waves, which wait for them on their side).  With an early
     // operand tile in flight behind chunk 2's pieces (issued in turn 0, see below) turns 1 and 2 leave AUXP more
     // operations outstanding: the counter retires in order, so "chunk 2 has landed" is then <= PIECES + AUXP.
+    static_assert(NAUXL == 0 || C::NST == 3, "epilogue operands in LDS: the three-stage ring");
     if (NAUXL > 0 && (chunk == 1 || chunk == 2))
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PIECES + (NAUXL > 0 ? AUXP : 0)) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PIECES) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((C::AHEAD - 1) * C::PIECES) : "memory");
     __builtin_amdgcn_sched_barrier(0);
-    const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
+    const int nstage = (stage + C::AHEAD) % C::NST;   // the stage chunk - 1 has just vacated
     const unsigned dst = lds_addr_of(smem + nstage * C::STAGE_FLOATS);
     if (NAUXL > 1 && chunk == last - 1) {
       // the first past-the-end turn: the stage chunk - 1 has vacated takes the epilogue's SECOND operand (two
@@ -411,7 +424,7 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
     } else {
       // past the end the last chunk is streamed again into a stage nobody reads: every wait stays
       // the same counted vmcnt(PIECES)
-      const ChunkSrc cs = chunk_src<COUT, G>(a, min(chunk + 2, last), n);
+      const ChunkSrc cs = chunk_src<COUT, G>(a, min(chunk + C::AHEAD, last), n);
 #pragma unroll
       for (int p = 0; p < C::PIECES; ++p)
         lds_dma16_buf(p < C::IN_PIECES ? cs.img : cs.wgt, pl.voff[p], 0, dst + 1024u * (unsigned)p);
@@ -422,7 +435,7 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
 #pragma unroll
       for (int p = 0; p < AUXP; ++p) lds_dma16_buf(arsrc[0], aoff[p], 0, adst + 1024u * (unsigned)p);
     }
-    stage = stage == 2 ? 0 : stage + 1;
+    stage = stage == C::NST - 1 ? 0 : stage + 1;
   }
   // no LDS-DMA may be in flight when the workgroup's LDS is released -- and where the operands may still be in
   // flight when the K loop ends (a second operand; or fewer than four chunks: the first operand is only known to
@@ -742,9 +755,12 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       for (int i = 0; i < C::NPW; ++i)
         if (wave + 4 * i < C::IN_PIECES) dma_piece<COUT, G>(pl, i, wave, cs0, st0);
       stamp(15);
-      const ChunkSrc cs1 = chunk_src<COUT, G>(a, min(1, last), n);
+      if constexpr (C::NST == 3 || !C::LOADER) {   // (two stages: chunk 1 is the loader wave's first turn)
+        const ChunkSrc cs1 = chunk_src<COUT, G>(a, min(1, last), n);
 #pragma unroll
-      for (int i = 0; i < C::NPW; ++i) dma_piece<COUT, G>(pl, i, wave, cs1, st1);
+        for (int i = 0; i < C::NPW; ++i) dma_piece<COUT, G>(pl, i, wave, cs1, st1);
+      }
+      (void)st1;
     }
     stamp(1);
     int stage = 0;
@@ -756,7 +772,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         // pieces in flight, every later one finds nothing outstanding
         if constexpr ((LARVA_DIAG & 256) != 0) {
           // timing ablation (with bit 1: nothing is staged): no barrier between the chunks
-        } else if (chunk == 0) wait_and_barrier<(LARVA_DIAG & 2) ? 0 : C::NPW>();
+        } else if (chunk == 0) wait_and_barrier<((LARVA_DIAG & 2) || C::NST == 2) ? 0 : C::NPW>();
         else wait_and_barrier<0>();
       } else {
         // (the NPW youngest operations belong to chunk+1)
@@ -767,7 +783,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         if (chunk == 0) __builtin_amdgcn_s_setprio(1);
       }
       stamp(8 + (chunk < 7 ? chunk : 7));
-      const int nstage = stage >= 1 ? stage - 1 : 2;  // (stage + 2) % 3
+      const int nstage = (stage + C::AHEAD) % C::NST;
       if constexpr (!(LARVA_DIAG & 1)) {
         if constexpr (!(LARVA_DIAG & 2) && !C::LOADER) {
           const ChunkSrc nxt = chunk_src<COUT, G>(a, min(chunk + 2, last), n);
@@ -778,7 +794,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
                                                  0u);
         }
       }
-      stage = stage == 2 ? 0 : stage + 1;
+      stage = stage == C::NST - 1 ? 0 : stage + 1;
     }
     // no LDS-DMA may be in flight when the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1036,7 +1052,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
 }
 
 template <int COUT, bool VEC, int EPI>
-__global__ __launch_bounds__(VEC ? ConvCfg<COUT>::THREADS_DMA : 256, VEC ? 2 : 1) void conv3x3_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(VEC ? ConvCfg<COUT>::THREADS_DMA : 256, VEC ? LARVA_WG_PER_CU : 1) void conv3x3_mfma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   conv_tile<COUT, VEC, EPI>(a, smem);
 }
@@ -1081,7 +1097,7 @@ __device__ __forceinline__ void strip_roles(const ConvArgs& a, float* smem, int 
 }
 
 template <int COUT, int EPI>
-__global__ __launch_bounds__(320, 2) void conv3x3_mfma_strip_kernel(ConvArgs a) {
+__global__ __launch_bounds__(320, LARVA_WG_PER_CU) void conv3x3_mfma_strip_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   stamp(0);
   fetch_args(a);
@@ -1101,8 +1117,8 @@ constexpr size_t kStripLdsOf = ConvCfg<COUT, G>::LDS_BYTES_DMA +
 template <int COUT, int EPI = kEpiRelu>
 constexpr size_t kStripLdsBytes = kStripLdsOf<COUT, GeoS5, EPI> > kStripLdsOf<COUT, GeoS4, EPI> ? kStripLdsOf<COUT, GeoS5, EPI>
                                                                                                 : kStripLdsOf<COUT, GeoS4, EPI>;
-static_assert(2 * kStripLdsBytes<48, kEpiRes2> <= 160 * 1024 && 2 * kStripLdsBytes<64, kEpiRes2> <= 160 * 1024,
-              "two strip workgroups per CU");
+static_assert(LARVA_WG_PER_CU * kStripLdsBytes<48, kEpiRes2> <= 160 * 1024 && 2 * kStripLdsBytes<64, kEpiRes2> <= 160 * 1024,
+              "strip workgroups per CU");
 
 // Several INDEPENDENT convolutions of one shape and one epilogue in one launch (blockIdx.y = job).
 // A single conv launch at the training shape is one workgroup per CU and spends half of its time
@@ -1115,7 +1131,7 @@ struct ConvBatch {
 };
 
 template <int COUT, int EPI>
-__global__ __launch_bounds__(ConvCfg<COUT>::THREADS_DMA, 2) void conv3x3_mfma_batch_kernel(ConvBatch b) {
+__global__ __launch_bounds__(ConvCfg<COUT>::THREADS_DMA, LARVA_WG_PER_CU) void conv3x3_mfma_batch_kernel(ConvBatch b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   conv_tile<COUT, true, EPI>(b.job[blockIdx.y], smem);
 }
