@@ -60,6 +60,12 @@
 // only its K loop at 1: with two workgroups per CU, the one that is not multiplying is the one its chain waits for.
 #define LARVA_PRIO_BOOST 0
 #endif
+#ifndef LARVA_TABLE_SCALAR
+// 1: the strip kernel's tile-table entry through the constant address space = a scalar load (s_load_dword, tile origin in
+// SGPRs) instead of the vector global load the generic pointer gives.  Measured in round 3 and LEFT OFF: two chains
+// 14.9-15.4 against 14.2-14.6 us per layer, step 1.664-1.672 against 1.653-1.657 ms (same box, tools/ab_variant.sh).
+#define LARVA_TABLE_SCALAR 0
+#endif
 #ifndef LARVA_RING_STAGES
 // Stages of the LDS-DMA ring (loader-wave path).  3 (the product): chunks c + 1 and c + 2 in flight while chunk c
 // multiplies, two workgroups per CU.  2 (experiment, with -DLARVA_WG_PER_CU=3): one chunk in flight, 40 instead of 60 KiB
@@ -1103,7 +1109,12 @@ __global__ __launch_bounds__(320, LARVA_WG_PER_CU) void conv3x3_mfma_strip_kerne
   fetch_args(a);
   const int tile = xcd_remap(blockIdx.x, a.nwg);
   const int n = div_by_magic(tile, a.magic_tx);   // tiles_x = tiles per image
+#if LARVA_TABLE_SCALAR
+  const unsigned e = reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(
+      reinterpret_cast<uintptr_t>(a.tile_tab))[tile - n * a.tiles_x];
+#else
   const unsigned e = a.tile_tab[tile - n * a.tiles_x];
+#endif
   const int y0 = (int)(e & 0xfffu), x0 = (int)((e >> 12) & 0xfffu);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
