@@ -622,9 +622,9 @@ def full_image_block(dev):
     import torch
     out = {"lr_image": list(FULL_IMAGE), "hr_pixels": 16 * FULL_IMAGE[1] * FULL_IMAGE[2]}
     x = (torch.rand(1, *FULL_IMAGE, generator=torch.Generator().manual_seed(2)) * 255).to(dev)
-    for name in ("LarvaNet", "LarvaNetV2"):
+    for name, extra in (("LarvaNet", []), ("LarvaNetV2", []), ("LarvaNetV2", ["--num_filters=64"])):
         m = importlib.import_module("larvanet_amd.models." + name).create_model()
-        m.parse_args(list(FLAGS))
+        m.parse_args(list(FLAGS) + extra)
         torch.manual_seed(0)
         m.prepare(is_training=False, scales=[SCALE])
         with torch.no_grad():
@@ -639,7 +639,8 @@ def full_image_block(dev):
                 torch.cuda.synchronize()
                 runs.append((time.perf_counter() - t0) / reps * 1e3)
             ms = sorted(runs)[1]
-        out[name] = {"ms_per_image": ms, "value": out["hr_pixels"] / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s"}
+        key = name + ("_64ch" if extra else "")   # (BASELINE configs[4] reads "LarvaNetV2, 64ch body": the --num_filters extension)
+        out[key] = {"ms_per_image": ms, "value": out["hr_pixels"] / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s"}
         del m
     return out
 
