@@ -42,8 +42,16 @@ def make_summary_writer(path):
         return _NullSummary()
 
 
-def build_parser():
+def round_to_1(x):
+    """train_larvaV2.py:15-16: x rounded to one significant digit."""
+    from math import floor, log10
+    return round(x, -int(floor(log10(abs(x)))))
+
+
+def build_parser(v2=False):
     p = argparse.ArgumentParser()
+    if v2:
+        p.add_argument("--steps_per_epoch", type=float, help="Num of steps on 1 epoch.")
     p.add_argument("--dataloader", type=str, default="combined_loader")
     p.add_argument("--val_dataloader", type=str, default="div2k_val_loader")
     p.add_argument("--model", type=str, default="LarvaNet")
@@ -71,8 +79,9 @@ def build_parser():
     return p
 
 
-def main(argv=None):
-    args, remaining = build_parser().parse_known_args(argv)
+def main(argv=None, v2=False):
+    """v2: the reference's train_larvaV2.py variant of the same loop (see larvanet_amd/train_larvaV2.py)."""
+    args, remaining = build_parser(v2).parse_known_args(argv)
     if args.cuda_device is not None and "LOCAL_RANK" not in os.environ:
         os.environ["HIP_VISIBLE_DEVICES"] = args.cuda_device  # before the first device use
     rank, world = ldist.init_from_env()
@@ -90,7 +99,15 @@ def main(argv=None):
     print("prepare model - %s" % args.model)
     model = importlib.import_module("larvanet_amd.models." + args.model).create_model()
     model_args, remaining = model.parse_args(remaining)
-    model.volume_per_step = (args.input_patch_size ** 2) * args.batch_size * 3 * world
+    if v2:
+        # train_larvaV2.py:73-81: an "epoch" of 300 MiB of input values; volume_per_step is NOT set there, so the model's
+        # stays 0 and the volume-triggered validation / checkpoint of train_step_larva never fires after step 1
+        #  -- reproduced as is
+        if args.steps_per_epoch is None:
+            args.steps_per_epoch = round_to_1(300 * (1024 ** 2) / ((args.input_patch_size ** 2) * args.batch_size * 3))
+        model.steps_per_epoch = int(args.steps_per_epoch)
+    else:
+        model.volume_per_step = (args.input_patch_size ** 2) * args.batch_size * 3 * world
     model.prepare(is_training=True, scales=scales, global_step=args.global_step)
     if hasattr(model, "strict_graph") and not args.allow_eager_fallback:
         model.strict_graph = True   # a failed hipGraph capture is an error here, not a silent 2.4x slowdown
@@ -116,9 +133,13 @@ def main(argv=None):
         loader.start_training_queue_runner(batch_size=args.batch_size, input_patch_size=args.input_patch_size)
 
     print("begin training")
-    print(f"volume {model.volume_per_step/1e6:.2f}M for 1 step.")
-    print(f"needs {model_args.val_volume/model.volume_per_step:.0f}steps to validate "
-          f"for {model_args.val_volume/1e9:.1f}G volume.")
+    if v2:
+        print(f"{model.steps_per_epoch} steps equal to 1 epoch")
+    else:
+        print(f"volume {model.volume_per_step/1e6:.2f}M for 1 step.")
+        print(f"needs {model_args.val_volume/model.volume_per_step:.0f}steps to validate "
+              f"for {model_args.val_volume/1e9:.1f}G volume.")
+    log_until = model.steps_per_epoch * 2 if v2 else 1000   # (train_larvaV2.py:142 / train_larva.py:136)
     try:
         while model.global_step < args.max_steps:
             scale = model.get_next_train_scale()
@@ -150,7 +171,7 @@ def main(argv=None):
             t3 = time.time()
             if args.sleep_ratio > 0 and t3 > t0:
                 time.sleep(min(10.0, (t3 - t0) * args.sleep_ratio))
-            if rank == 0 and model.global_step < 1000 and model.global_step % args.log_freq == 0:
+            if rank == 0 and model.global_step < log_until and model.global_step % args.log_freq == 0:
                 print("step %d, lr %.10f, loss %.6f (%.3f sec/batch)" % (model.global_step, model.get_lr(),
                                                                         float(loss), t3 - t0))
                 print(f"dataload_time:{t1 - t0:.4f}s, np2ts_time:{t2 - t1:.4f}s, train_time: {t3 - t2:.4f}s")

@@ -46,3 +46,18 @@ def test_validate_scores_on_the_device_like_on_the_host(hip_device):
     assert [r[0] for r in a] == [r[0] for r in b] == [0, 1, 2]
     # (exact integer sum on the device, float32 mean on the host)
     assert all(abs(x[1] - y[1]) < 1e-4 for x, y in zip(a, b))
+
+
+def test_train_larva_v2_driver(hip_device, tmp_path, capsys):
+    """train_larvaV2.py's loop: steps_per_epoch on the model, validation at step 1 only (the reference never sets
+    volume_per_step in this driver), no checkpoint."""
+    from larvanet_amd import train_larvaV2
+    model = train_larvaV2.main([
+        "--model=LarvaNetV2", "--dataloader=synthetic_loader", "--val_dataloader=synthetic_loader",
+        "--train_path", str(tmp_path), "--max_steps=4", "--batch_size=2", "--input_patch_size=12",
+        "--num_modules=2", "--num_blocks=1,1", "--synthetic_images=2", "--synthetic_lr_size=16", "--steps_per_epoch=3",
+        "--val_volume=1"])
+    out = capsys.readouterr().out
+    assert model.global_step == 4 and model.steps_per_epoch == 3 and model.volume_per_step == 0
+    assert "3 steps equal to 1 epoch" in out and out.count("begin validation") == 1
+    assert not glob.glob(os.path.join(str(tmp_path), "model_step*"))

@@ -206,3 +206,14 @@ def test_train_driver_argument_chain_on_cpu(tmp_path, monkeypatch, capsys):
     saved = json.load(open(os.path.join(str(tmp_path), "arguments.json")))
     assert saved["model"] == "LarvaNet" and saved["num_blocks"] == "1" and saved["batch_size"] == 3 and saved["world_size"] == 1
     assert "WARNING: found unhandled arguments: ['--bogus_flag=7']" in capsys.readouterr().out
+
+
+def test_train_larva_v2_driver_flags():
+    """larvanet_amd/train_larvaV2.py: the reference's --steps_per_epoch (train_larvaV2.py:29,73-81) and its one-significant-
+    digit default epoch."""
+    from larvanet_amd import train_larva
+    args, rest = train_larva.build_parser(v2=True).parse_known_args(["--steps_per_epoch=500", "--model=LarvaNetV2", "--x=1"])
+    assert args.steps_per_epoch == 500 and rest == ["--x=1"]
+    assert not hasattr(train_larva.build_parser().parse_known_args([])[0], "steps_per_epoch")
+    assert train_larva.round_to_1(300 * 1024 ** 2 / (48 ** 2 * 16 * 3)) == 3000.0   # 2844.4 -> one significant digit
+    assert train_larva.round_to_1(0.0234) == 0.02
