@@ -645,6 +645,16 @@ def full_image_block(dev):
     return out
 
 
+def guarded(line, key, fn):
+    """An EXTRA of the JSON line: whatever goes wrong inside it (a Python exception -- a GPU fault ends the process
+    anyway) is recorded under its key instead of costing the run its headline, `roofline` and `cpu_baseline`."""
+    try:
+        line[key] = fn()
+    except Exception as e:   # noqa: BLE001 (deliberately broad: extras must not take the line down)
+        line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        sys.stderr.write("bench.py: extra %r failed: %s: %s\n" % (key, type(e).__name__, e))
+
+
 def timed_rounds(model, args, val, x, truth, steps, rounds, dist_on):
     """`rounds` x (barrier + sync, `steps` steps, barrier + sync) -> seconds per round, max over ranks."""
     import torch
@@ -844,44 +854,48 @@ def main():
     if extras and ref_semantics and bufs is not None:
         # round 2's headline, now an extra: no per-step loss.item() (the loss comes back as a device scalar) and the
         # batch already resident in the captured step's input buffers (what dataloaders/device_patch_loader does)
-        model.sync_loss = False
-        secs2, _ = timed_rounds(model, args, val, bufs[0], bufs[1], a.steps, min(rounds, 3), False)
-        model.sync_loss = True
-        ms2 = float(np.median([s / a.steps * 1e3 for s in secs2]))
-        line["value_async_resident"] = {"value": HR_PIX_PER_BATCH / (ms2 * 1e-3) / 1e6, "unit": "HR Mpixels/s", "ms_per_step": ms2,
-                                        "what": "--async_loss loop: loss returned as a device scalar, batch written straight into "
-                                                "the captured step's input buffers by a device-side producer"}
+        def async_resident():
+            model.sync_loss = False
+            try:
+                secs2, _ = timed_rounds(model, args, val, bufs[0], bufs[1], a.steps, min(rounds, 3), False)
+            finally:
+                model.sync_loss = True
+            ms2 = float(np.median([s / a.steps * 1e3 for s in secs2]))
+            return {"value": HR_PIX_PER_BATCH / (ms2 * 1e-3) / 1e6, "unit": "HR Mpixels/s", "ms_per_step": ms2,
+                    "what": "--async_loss loop: loss returned as a device scalar, batch written straight into "
+                            "the captured step's input buffers by a device-side producer"}
+        guarded(line, "value_async_resident", async_resident)
 
     if extras:
         # The weight-gradient schedule a data-parallel rank runs (two launch groups instead of one flat grid, see
         # DESIGN section 5) on this one GPU, without collectives: the cost of making the all-reduce overlappable.
-        os.environ["LARVA_FORCE_SPLIT"] = "1"
-        try:
-            m2 = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
-            m2.parse_args(list(FLAGS))
-            torch.manual_seed(0)
-            m2.volume_per_step = PATCH * PATCH * BATCH * 3
-            m2.prepare(is_training=True, scales=[SCALE])
-            m2.sync_loss = ref_semantics
-            for _ in range(max(a.warmup, 1)):
-                m2.train_step_larva(args, val, x_fresh, truth_fresh)
-            secs3, _ = timed_rounds(m2, args, val, x_fresh, truth_fresh, a.steps, min(rounds, 3), False)
-            ms3 = float(np.median([s / a.steps * 1e3 for s in secs3]))
-            line["dp_schedule_1gpu"] = {"ms_per_step": ms3, "value": HR_PIX_PER_BATCH / (ms3 * 1e-3) / 1e6, "unit": "HR Mpixels/s",
-                                        "late_graph": m2._graph_late is not None,
-                                        "what": "the same step with the data-parallel weight-gradient schedule (LARVA_FORCE_SPLIT=1: two "
-                                                "launch groups + two reductions, the second in a graph of its own), no collectives: what a "
-                                                "rank of an N-GPU run computes per step"}
-            del m2
-        finally:
-            os.environ.pop("LARVA_FORCE_SPLIT", None)
+        def dp_schedule():
+            os.environ["LARVA_FORCE_SPLIT"] = "1"
+            try:
+                m2 = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
+                m2.parse_args(list(FLAGS))
+                torch.manual_seed(0)
+                m2.volume_per_step = PATCH * PATCH * BATCH * 3
+                m2.prepare(is_training=True, scales=[SCALE])
+                m2.sync_loss = ref_semantics
+                for _ in range(max(a.warmup, 1)):
+                    m2.train_step_larva(args, val, x_fresh, truth_fresh)
+                secs3, _ = timed_rounds(m2, args, val, x_fresh, truth_fresh, a.steps, min(rounds, 3), False)
+                ms3 = float(np.median([s / a.steps * 1e3 for s in secs3]))
+                return {"ms_per_step": ms3, "value": HR_PIX_PER_BATCH / (ms3 * 1e-3) / 1e6, "unit": "HR Mpixels/s",
+                        "late_graph": m2._graph_late is not None,
+                        "what": "the same step with the data-parallel weight-gradient schedule (LARVA_FORCE_SPLIT=1: two "
+                                "launch groups + two reductions, the second in a graph of its own), no collectives: what a "
+                                "rank of an N-GPU run computes per step"}
+            finally:
+                os.environ.pop("LARVA_FORCE_SPLIT", None)
+        guarded(line, "dp_schedule_1gpu", dp_schedule)
 
     if extras:
         # BASELINE configs 2 / 5 name 32- and 64-channel bodies, which the reference cannot express:
         # the same M4B4 network built with --num_filters (every leg's last conv kept at 48 outputs), same batch,
         # same loop semantics.  Extras: the headline stays the reference's 48-channel network.
-        line["other_widths"] = {}
-        for nf in (32, 64):
+        def width(nf):
             mw = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
             mw.parse_args(list(FLAGS) + ["--num_filters=%d" % nf])
             torch.manual_seed(0)
@@ -903,12 +917,13 @@ def main():
                 inf_w = (time.perf_counter() - t0) / 20 * 1e3
             cc = (2 * sum(BLOCKS) + len(BLOCKS)) * conv_flop(nf) + len(BLOCKS) * 2 * 9 * nf * 48 * BATCH * PATCH * PATCH
             flop_w = 3 * cc + 2 * (2 * 9 * 3 * nf * BATCH * PATCH * PATCH)
-            line["other_widths"]["num_filters_%d" % nf] = {
-                "train_ms_per_step": ms_w, "value": HR_PIX_PER_BATCH / (ms_w * 1e-3) / 1e6, "unit": "HR Mpixels/s",
-                "flop_per_step": flop_w, "frac_of_peak": flop_w / (ms_w * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                "infer_ms_per_batch": inf_w, "hip_graph_fell_back": mw.hip_graph_fell_back,
-                "what": "LarvaNet x4 M4B4 with --num_filters=%d (build-side extension, no reference counterpart)" % nf}
-            del mw
+            return {"train_ms_per_step": ms_w, "value": HR_PIX_PER_BATCH / (ms_w * 1e-3) / 1e6, "unit": "HR Mpixels/s",
+                    "flop_per_step": flop_w, "frac_of_peak": flop_w / (ms_w * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    "infer_ms_per_batch": inf_w, "hip_graph_fell_back": mw.hip_graph_fell_back,
+                    "what": "LarvaNet x4 M4B4 with --num_filters=%d (build-side extension, no reference counterpart)" % nf}
+        line["other_widths"] = {}
+        for nf in (32, 64):
+            guarded(line["other_widths"], "num_filters_%d" % nf, lambda nf=nf: width(nf))
 
     # inference forward (extra information)
     with torch.no_grad():
@@ -935,27 +950,30 @@ def main():
         # priced, like `roofline`, on what the STEP pays: the captured forward+backward with and without its
         # weight-gradient launches; the back-to-back loop of the launch pair alone (clock pulled down by
         # sustained fp32-MFMA load, operands streamed cold from HBM every replay) stays beside it
-        ins = wgrad_in_step(model, x, truth)
-        line["roofline_wgrad"] = {
-            "bound": "mfma", "achieved": ins["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ins["frac"],
-            "kernel": "all weight-gradient launches of the step: " + iso["kernel"].replace(", 16x48x48x48 fp32", "") +
-                      " with the 3 -> 48 head's tiles as the tail of the grid, 16x48x48x48 fp32",
-            "ms_all_weight_gradients": ins["ms_all_weight_gradients"], "flop": ins["flop"], "layers": ins["layers"],
-            "traffic": iso.get("traffic"), "traffic_source": iso.get("traffic_source"),
-            "timing": ins["what"], "in_step": ins, "isolated_loop": iso}
+        def wgrad_in_the_step():
+            ins = wgrad_in_step(model, x, truth)
+            return {
+                "bound": "mfma", "achieved": ins["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ins["frac"],
+                "kernel": "all weight-gradient launches of the step: " + iso["kernel"].replace(", 16x48x48x48 fp32", "") +
+                          " with the 3 -> 48 head's tiles as the tail of the grid, 16x48x48x48 fp32",
+                "ms_all_weight_gradients": ins["ms_all_weight_gradients"], "flop": ins["flop"], "layers": ins["layers"],
+                "traffic": iso.get("traffic"), "traffic_source": iso.get("traffic_source"),
+                "timing": ins["what"], "in_step": ins, "isolated_loop": iso}
+        guarded(line, "roofline_wgrad", wgrad_in_the_step)
+        if "error" in line["roofline_wgrad"]:
+            line["roofline_wgrad"] = dict(iso, in_step_error=line["roofline_wgrad"]["error"])
     line["infer"] = {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
                      "unit": "HR Mpixels/s"}
     if extras:
-        c32 = roofline_block(dev, 32, full=False, dual=True)     # two half-batch strip chains, like the 48-channel layer
-        line["roofline_c32"] = c32 if c32 is not None else roofline_block(dev, 32, full=False)
-        line["roofline_c32_single_chain"] = roofline_block(dev, 32, full=False)
-        c64 = roofline_block(dev, 64, full=False, dual=True)
-        line["roofline_c64"] = c64 if c64 is not None else roofline_block(dev, 64, full=False)
-        line["roofline_c64_single_chain"] = roofline_block(dev, 64, full=False)
-        line["roofline_wgrad_c32"] = wgrad_block(dev, 32)
-        line["roofline_wgrad_c64"] = wgrad_block(dev, 64)
+        def two_chain(c):   # two half-batch strip chains, like the 48-channel layer; else one chain
+            blk = roofline_block(dev, c, full=False, dual=True)
+            return blk if blk is not None else roofline_block(dev, c, full=False)
+        for c in (32, 64):
+            guarded(line, "roofline_c%d" % c, lambda c=c: two_chain(c))
+            guarded(line, "roofline_c%d_single_chain" % c, lambda c=c: roofline_block(dev, c, full=False))
+            guarded(line, "roofline_wgrad_c%d" % c, lambda c=c: wgrad_block(dev, c))
         del model
-        line["infer_full_image"] = full_image_block(dev)
+        guarded(line, "infer_full_image", lambda: full_image_block(dev))
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     emit(line)
