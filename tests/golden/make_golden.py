@@ -123,17 +123,17 @@ def trajectory_batches(nb=4, seed0=1300):
     return pool
 
 
-def synthetic_task(steps=200):
-    """F16's data, from the repo's own dataset-free loader (larvanet_amd/dataloaders/synthetic_loader.py: pure numpy,
-    seeded): `steps` training batches of 4 x 3 x 16 x 16 -> 4 x 3 x 64 x 64 and a 3-image validation loader."""
+def synthetic_task(steps=200, batch=4, patch=16, lr_size=40):
+    """F16's / F17's data, from the repo's own dataset-free loader (larvanet_amd/dataloaders/synthetic_loader.py: pure
+    numpy, seeded): `steps` training batches of batch x 3 x patch x patch (x4 truth) and a 3-image validation loader."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
     S = importlib.import_module("larvanet_amd.dataloaders.synthetic_loader")
     tr = S.create_loader()
-    tr.parse_args(["--synthetic_images=6", "--synthetic_lr_size=40", "--data_seed=3"])
+    tr.parse_args(["--synthetic_images=6", "--synthetic_lr_size=%d" % lr_size, "--data_seed=3"])
     tr.prepare([4])
     batches = []
     for _ in range(steps):
-        x, t = tr.get_patch_batch(4, 4, 16)
+        x, t = tr.get_patch_batch(batch, 4, patch)
         batches.append((torch.from_numpy(np.stack(x)), torch.from_numpy(np.stack(t))))
     val = S.create_loader()
     val.parse_args(["--synthetic_images=3", "--synthetic_lr_size=32", "--data_seed=9"])
@@ -262,6 +262,38 @@ def main_r3(only):
                  psnrs=np.array(psnrs, np.float64), ulp_tube_loss=np.maximum.accumulate(tube_l),
                  ulp_tube_psnr=np.maximum.accumulate(tube_p))
 
+    if "f17" in only:
+        # F16's question at the HEADLINE configuration (M4B4, 16 x 3 x 48 x 48 per step: the launch geometry bench.py times):
+        # the reference's own train_step_larva for 60 steps on the learnable synthetic task, validation at step 1 and
+        # every 20 steps, and one re-run from initial weights one ulp away.
+        def f17_run(perturb_seed=None):
+            model = make_ref_model("LarvaNet", ["--num_modules=4", "--num_blocks=4,4,4,4", "--val_volume=20"], seed=0)
+            if perturb_seed is not None:
+                gen = torch.Generator().manual_seed(perturb_seed)
+                with torch.no_grad():
+                    for p_ in model.model.parameters():
+                        p_.mul_(1 + 1e-7 * torch.randn(p_.shape, generator=gen))
+            attach_training(model)
+            model.volume_per_step = 1
+            batches, val = synthetic_task(steps=60, batch=16, patch=48, lr_size=96)
+            tmp = tempfile.mkdtemp()
+            args = types.SimpleNamespace(train_path=tmp)
+            losses, psnrs = [], []
+            for step in range(60):
+                x, t = batches[step]
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    losses.append(model.train_step_larva(args, val, x, t, None))
+                psnrs += [float(line.split("psnr=")[1].split(",")[0]) for line in buf.getvalue().splitlines() if "psnr=" in line]
+            f13_cleanup(tmp)
+            return losses, psnrs
+
+        losses, psnrs = f17_run()
+        l2, p2 = f17_run(31)
+        np.savez(os.path.join(OUT, "f17_headline_training.npz"), losses=np.array(losses, np.float64), psnrs=np.array(psnrs, np.float64),
+                 ulp_tube_loss=np.maximum.accumulate(np.abs(np.array(l2) / np.array(losses) - 1)),
+                 ulp_tube_psnr=np.maximum.accumulate(np.abs(np.array(p2) - np.array(psnrs))))
+
     if "f15" in only:
         # BASELINE configs[0]: the reference's EDSR through train.py's loop (train.py:83-105: get_next_train_scale,
         # a batch of lists of CHW arrays, model.train_step(input_list, scale, truth_list, summary)), small width here
@@ -351,7 +383,7 @@ def main():
         main_r2(sys.argv[2:] or ["f11", "f12"])
         return
     if len(sys.argv) > 1 and sys.argv[1] == "r3":
-        main_r3(sys.argv[2:] or ["f13", "f14", "f15", "f16"])
+        main_r3(sys.argv[2:] or ["f13", "f14", "f15", "f16", "f17"])
         return
 
     # ---------------- F1/F2: M2B2 weights, staged outputs on a 2x3x12x12 input ----------------

@@ -281,6 +281,38 @@ def test_realistic_training_psnr_within_north_star_of_reference_f16(hip_device, 
     assert len([n for n in os.listdir(str(tmp_path)) if n.startswith("model_step")]) == 8
 
 
+def test_headline_size_training_psnr_within_north_star_of_reference_f17(hip_device, golden, tmp_path, capsys):
+    """F16's question at the HEADLINE configuration -- M4B4, 16 x 3 x 48 x 48 per step, i.e. the launch geometry bench.py
+    times (two half-batch strip chains of 256 workgroups, batched exits scored in their conv launch, the flat 40-layer
+    weight-gradient grid with the head as its tail, one-launch AdamW, the captured graph): F17 = the reference's own 60
+    steps on the learnable synthetic task, validation at step 1 and every 20 steps.  Bars: every validation within 0.02 dB
+    (north_star), every loss within 2e-3 relative; the reference re-run one ulp away moves 4.5e-3 dB / 1.3e-4."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_golden import _synthetic_task
+    g = golden("f17_headline_training.npz")
+    m = _model("LarvaNet", FLAGS + ["--val_volume=20"], training=True)
+    m.volume_per_step = 1
+    batches, val = _synthetic_task(steps=60, batch=16, patch=48, lr_size=96)
+    args = types.SimpleNamespace(train_path=str(tmp_path))
+    losses, psnrs = [], []
+    capsys.readouterr()
+    for x, t in batches:
+        losses.append(m.train_step_larva(args, val, x.to(hip_device), t.to(hip_device), None))
+        psnrs += [float(line.split("psnr=")[1].split(",")[0]) for line in capsys.readouterr().out.splitlines() if "psnr=" in line]
+    assert m.use_hip_graph and m.hip_graph_fell_back is None
+    psnr_dev = np.abs(np.array(psnrs) - g["psnrs"])
+    loss_dev = np.abs(np.array(losses) / g["losses"] - 1)
+    with capsys.disabled():
+        print("\nF17: PSNR %.4f -> %.4f dB (reference %.4f -> %.4f), max deviation %.2e dB (reference one ulp away: %.2e), "
+              "max relative loss deviation %.2e (reference: %.2e)" % (psnrs[0], psnrs[-1], g["psnrs"][0], g["psnrs"][-1],
+                                                                      psnr_dev.max(), g["ulp_tube_psnr"].max(), loss_dev.max(),
+                                                                      g["ulp_tube_loss"].max()))
+    assert len(psnrs) == 4 and psnr_dev.max() < 0.02, psnr_dev
+    assert loss_dev.max() < 2e-3, loss_dev.max()
+
+
 def test_headline_wgrad_launch_shape_32_layers_by_8_splits(hip_device):
     """The weight-gradient launch exactly as the step issues it (32 layers x 8 workgroups at
     16x48x48x48, pipelined kernel + fixed-order reduction) against torch's CPU conv2d_weight."""

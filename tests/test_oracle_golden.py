@@ -362,15 +362,15 @@ def test_edsr_cpu_driver_loop_config0(tmp_path, capsys):
     assert up.shape == (1, 3, 32, 36)
 
 
-def _synthetic_task(steps=200):
-    """F16's data (tests/golden/make_golden.py synthetic_task): the repo's seeded, dataset-free loader."""
+def _synthetic_task(steps=200, batch=4, patch=16, lr_size=40):
+    """F16's / F17's data (tests/golden/make_golden.py synthetic_task): the repo's seeded, dataset-free loader."""
     from larvanet_amd.dataloaders import synthetic_loader as S
     tr = S.create_loader()
-    tr.parse_args(["--synthetic_images=6", "--synthetic_lr_size=40", "--data_seed=3"])
+    tr.parse_args(["--synthetic_images=6", "--synthetic_lr_size=%d" % lr_size, "--data_seed=3"])
     tr.prepare([4])
     batches = []
     for _ in range(steps):
-        x, t = tr.get_patch_batch(4, 4, 16)
+        x, t = tr.get_patch_batch(batch, 4, patch)
         batches.append((torch.from_numpy(np.stack(x)), torch.from_numpy(np.stack(t))))
     val = S.create_loader()
     val.parse_args(["--synthetic_images=3", "--synthetic_lr_size=32", "--data_seed=9"])
@@ -392,3 +392,16 @@ def test_torch_restatement_realistic_training_f16(golden):
     np.testing.assert_allclose(rec["psnrs"], g["psnrs"], rtol=0, atol=5e-3)
     np.testing.assert_allclose(rec["losses"], g["losses"], rtol=1e-3)
     assert g["psnrs"][-1] > g["psnrs"][0] + 0.03    # (the task is learnable: the reference's PSNR goes up)
+
+
+def test_torch_restatement_headline_training_f17_first_steps(golden):
+    """F17 (the reference's 60-step run at the headline configuration): the oracle on the first 4 steps and the first
+    validation -- the whole run is the GPU test's job (tests/test_headline_parity.py); on the CPU it costs 25 s."""
+    g = golden("f17_headline_training.npz")
+    torch.set_num_threads(8)
+    batches, val = _synthetic_task(steps=4, batch=16, patch=48, lr_size=96)
+    pairs = [val.get_image_pair(i, 4)[:2] for i in range(val.get_num_images())]
+    sd = T.init_state_dict([4, 4, 4, 4], seed=0)
+    rec = T.train_trajectory(sd, batches, 4, [4, 4, 4, 4], pairs, 1, 20, lr=4e-4)
+    np.testing.assert_allclose(rec["losses"], g["losses"][:4], rtol=1e-4)
+    assert abs(rec["psnrs"][0] - g["psnrs"][0]) < 2e-3
