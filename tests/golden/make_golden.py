@@ -17,7 +17,10 @@ import numpy as np
 import torch
 
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))
+# LARVA_GOLDEN_OUT=<dir>: write the fixtures there instead of beside this script (to check that the committed ones
+# regenerate bit for bit:  LARVA_GOLDEN_OUT=/tmp/g python tests/golden/make_golden.py [r2|r3]  then compare the arrays)
+OUT = os.environ.get("LARVA_GOLDEN_OUT", HERE)
 
 
 def sha(t):
@@ -126,7 +129,7 @@ def trajectory_batches(nb=4, seed0=1300):
 def synthetic_task(steps=200, batch=4, patch=16, lr_size=40):
     """F16's / F17's data, from the repo's own dataset-free loader (larvanet_amd/dataloaders/synthetic_loader.py: pure
     numpy, seeded): `steps` training batches of batch x 3 x patch x patch (x4 truth) and a 3-image validation loader."""
-    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     S = importlib.import_module("larvanet_amd.dataloaders.synthetic_loader")
     tr = S.create_loader()
     tr.parse_args(["--synthetic_images=6", "--synthetic_lr_size=%d" % lr_size, "--data_seed=3"])
