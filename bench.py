@@ -109,6 +109,16 @@ def conv_flop(c):
     return 2 * 9 * c * c * BATCH * PATCH * PATCH         # 1.5288 GFLOP per 48->48 layer
 
 
+def infer_flop_per_lr_pixel(blocks, c, v2):
+    """algorithmic FLOP per LR pixel of the inference forward (2 * 9 * cin * cout per 3x3 conv): the head
+    3 -> c, every body's c -> c convs, and V1: the LAST leg (c -> c, c -> 48); V2: the merge conv (M * c -> c) and the
+    tail (c -> c, c -> 48).  c = 48, M4B4, V1: 1 412 640."""
+    f = 2 * 9 * 3 * c + 2 * sum(blocks) * 2 * 9 * c * c + 2 * 9 * c * c + 2 * 9 * c * 48
+    if v2:
+        f += len(blocks) * 2 * 9 * c * c
+    return f
+
+
 # ------------------------------------------------------------------------------------------------
 # self-launch: `python bench.py --gpus N` without a launcher
 # ------------------------------------------------------------------------------------------------
@@ -236,17 +246,18 @@ def replay_ms(graph, reps=10):
     return sorted(best)[1]
 
 
-# Layers per captured chain: the per-layer figure is the SLOPE between a long and a short chain, (t(160) - t(40)) / 120,
-# i.e. what one more layer costs in the steady state.  A replay has a fixed cost on top -- graph launch, the chains
-# ramping up (the stamp profile profiles/r03_dual_chain_overlap.txt: ~55 us per replay, 1.4 us per layer when spread over
-# 40) -- which belongs to the replay, not to the kernel; `avg_ms_chain40` keeps round 2's "replay / 40" figure.
+# Layers per captured chain.  The roofline fraction is priced on the SHORT chain (replay / 40: the chain length of the
+# training step, fixed cost of a replay included -- graph launch, the chains ramping up, the last drain: ~55 us per
+# replay in profiles/r03_dual_chain_overlap.txt).  The slope between the long and the short chain, (t(160) - t(40)) / 120
+# = what one more layer costs in the steady state, is reported beside it as `*_steady_state` (round 3 made it the
+# headline, which was a change of definition, not of kernel: VERDICT r3 / ADVICE r3).
 CHAIN_SHORT, CHAIN_LONG = 40, 160
 
 
 def chain_time_ms(dev, c, chain=CHAIN_SHORT, reps=10, decaying=False):
     """The fused conv3x3+ReLU kernel the way it runs inside the training step: captured chains of dependent launches
     (each reads the previous one's output), replayed back to back, timed by a HIP event pair on the launch stream.
-    Returns (ms per launch = slope between the 160- and the 40-launch chain, RMS of the last output, replay / 40)."""
+    Returns (slope between the 160- and the 40-launch chain in ms per launch, RMS of the last output, replay / 40)."""
     import torch
     from larvanet_amd import kernels as K
     x0, wpk, b, bufs, rms = chain_operands(dev, c, chain, decaying)
@@ -361,22 +372,31 @@ def roofline_block(dev, c=CH, full=True, dual=False, quick=False):
     res = dual_chain_time_ms(dev, c, reps=reps) if dual else chain_time_ms(dev, c, reps=reps)
     if res is None:
         return None
-    graph_ms, rms, ms40 = res
-    # priced on the in-graph time per layer (what the step pays, boundaries included)
+    slope_ms, rms, ms40 = res
+    # `frac` / `achieved` / `avg_ms` are priced on a captured chain as long as the step's own (40 links, replay / 40:
+    # graph launch, the chains' ramp and the last drain included) -- rounds 1-2's definition, comparable across rounds
+    # and what the step pays per layer.  The slope between a 160- and a 40-link chain (what one MORE layer costs once
+    # the chains are in their steady state) is reported beside it as *_steady_state and is never the headline.
     flop = conv_flop(c)
-    achieved = flop / (graph_ms * 1e-3) / 1e12
+    achieved = flop / (ms40 * 1e-3) / 1e12
+    steady = flop / (slope_ms * 1e-3) / 1e12
     alg_bytes = 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c)
     blk = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_ms": graph_ms, "avg_ms_chain40": ms40,
+           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_ms": ms40, "avg_ms_chain40": ms40,
+           "avg_ms_is": "replay of a captured %d-link chain / %d (the chain length the training step runs)" % (CHAIN_SHORT, CHAIN_SHORT),
+           "avg_ms_steady_state": slope_ms, "achieved_steady_state": steady,
+           "frac_steady_state": steady / FP32_MFMA_PEAK_TFLOPS,
+           "steady_state_is": "(t%d - t%d) / %d: the replay's fixed cost (graph launch, ramp, last drain) removed; "
+                              "NOT the headline fraction" % (CHAIN_LONG, CHAIN_SHORT, CHAIN_LONG - CHAIN_SHORT),
            "inputs": "layer 0 reads N(0,1)*20 activations; weights rescaled so the RMS stays there down the 40-layer chain "
                      "(last layer's output RMS %.1f)" % rms}
     if c == CH:
         blk["traffic"], src = conv_traffic(dual)
         blk["traffic_source"] = TRAFFIC_NOTE % src
         if (full or dual) and not quick:
-            old_ms = (dual_chain_time_ms(dev, c, decaying=True) if dual else chain_time_ms(dev, c, decaying=True))[0]
+            old_ms = (dual_chain_time_ms(dev, c, decaying=True) if dual else chain_time_ms(dev, c, decaying=True))[2]
             blk["avg_ms_decaying_inputs"] = old_ms
-            blk["avg_ms_decaying_inputs_is"] = ("the same slope with round 2's microbenchmark operands (ones in, weights x 0.05: the "
+            blk["avg_ms_decaying_inputs_is"] = ("the same replay / 40 with round 2's microbenchmark operands (ones in, weights x 0.05: the "
                                                 "activations shrink ~30x per layer, most layers multiply zeros / denormals), for "
                                                 "comparison: the chip clocks higher on them")
     if dual:
@@ -394,17 +414,17 @@ def roofline_block(dev, c=CH, full=True, dual=False, quick=False):
             "traffic_is": "HBM-side bytes per LAYER (two launches)",
             "algorithmic_bytes_per_layer": alg_bytes,
             "timing": "HIP event pairs around 10 replays of captured graphs of two half-batch chains on two streams, 40 and "
-                      "160 layers long (median of 3 each); avg_ms = (t160 - t40) / 120 = what one more full-batch layer costs "
-                      "in the steady state; avg_ms_chain40 = t40 / 40 (round 2's figure: includes the replay's fixed ~55 us).  "
-                      "The un-profiled in-kernel stamp profile profiles/r03_dual_chain_overlap.txt shows the same steady "
-                      "state; under rocprofv3 the two chains do not overlap (the profiler makes the multi-stream graph "
-                      "launch host-bound): its per-launch durations are those of a launch running alone"})
+                      "160 layers long (median of 3 each); avg_ms = t40 / 40 per full-batch layer (rounds 1-2's definition, includes "
+                      "the replay's fixed cost); avg_ms_steady_state = (t160 - t40) / 120.  The un-profiled in-kernel stamp "
+                      "profile profiles/r04_dual_chain_overlap.txt records both figures for the same 40-link graph; under "
+                      "rocprofv3 the two chains do not overlap (the profiler makes the multi-stream graph launch "
+                      "host-bound): its per-launch durations are those of a launch running alone"})
     else:
         blk.update({
             "kernel": "conv3x3_mfma_kernel<%d, true, 1> (fused conv3x3+bias+ReLU), 16x%dx48x48 fp32" % (c, c),
             "flop_per_launch": flop,
             "timing": "HIP event pairs around 10 replays of captured chains of 40 and 160 dependent launches (median of 3 "
-                      "each); avg_ms = (t160 - t40) / 120, avg_ms_chain40 = t40 / 40",
+                      "each); avg_ms = t40 / 40, avg_ms_steady_state = (t160 - t40) / 120",
             "algorithmic_bytes_per_launch": alg_bytes})
     if full and not quick:
         k_mean_ms, k_min_ms, pair_ms = time_dominant_kernel(dev)
@@ -640,19 +660,41 @@ def full_image_block(dev):
                 runs.append((time.perf_counter() - t0) / reps * 1e3)
             ms = sorted(runs)[1]
         key = name + ("_64ch" if extra else "")   # (BASELINE configs[4] reads "LarvaNetV2, 64ch body": the --num_filters extension)
-        out[key] = {"ms_per_image": ms, "value": out["hr_pixels"] / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s"}
+        flop = infer_flop_per_lr_pixel(BLOCKS, 64 if extra else CH, v2=name.endswith("V2")) * FULL_IMAGE[1] * FULL_IMAGE[2]
+        out[key] = {"ms_per_image": ms, "value": out["hr_pixels"] / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s", "flop": flop,
+                    "frac_of_peak": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         del m
     return out
 
 
+class GpuFault(Exception):
+    """The HIP context is poisoned (a fault inside an extra): no further GPU work, non-zero exit."""
+
+
 def guarded(line, key, fn):
-    """An EXTRA of the JSON line: whatever goes wrong inside it (a Python exception -- a GPU fault ends the process
-    anyway) is recorded under its key instead of costing the run its headline, `roofline` and `cpu_baseline`."""
+    """An EXTRA of the JSON line: a pure-Python failure inside it is recorded under its key instead of costing the run
+    its headline, `roofline` and `cpu_baseline`.  A failure that leaves the HIP context unusable (an illegal access or a
+    launch failure surfaces as a RuntimeError and is sticky) is NOT downgraded: the device is synchronised after every
+    failed extra, and if that raises too the line gets `gpu_fault`, the remaining GPU extras are skipped (GpuFault) and
+    the process exits non-zero after emitting what it has."""
+    if line.get("gpu_fault") or (guarded.fault is not None):
+        line[key] = {"skipped": "earlier GPU fault"}
+        return
     try:
         line[key] = fn()
     except Exception as e:   # noqa: BLE001 (deliberately broad: extras must not take the line down)
         line[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         sys.stderr.write("bench.py: extra %r failed: %s: %s\n" % (key, type(e).__name__, e))
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception as e2:   # noqa: BLE001
+            guarded.fault = "%s in extra %r, then synchronize: %s: %s" % (type(e).__name__, key, type(e2).__name__, e2)
+            sys.stderr.write("bench.py: the HIP context is unusable after extra %r: %s\n" % (key, guarded.fault))
+
+
+guarded.fault = None
 
 
 def timed_rounds(model, args, val, x, truth, steps, rounds, dist_on):
@@ -817,9 +859,8 @@ def main():
         "value": value, "unit": "HR Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "LarvaNet x4 train_step_larva, num_modules=4 num_blocks=4,4,4,4, 48 channels "
-                               "(BASELINE config 2 at the reference's only channel count), batch 16 x 3x48x48 "
-                               "-> 3x192x192 per GPU, fp32",
+        "config": {"workload": "48ch batch16 3x48x48->3x192x192 fp32 LarvaNet x4 train_step_larva M4 B4,4,4,4 per GPU "
+                               "(BASELINE config 2 at the reference's only channel count)",
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                    "inputs": ("fresh device tensors handed to train_step_larva every step (copied into the captured step's inputs)"
                               if ref_semantics or bufs is None else "resident in the captured step's input buffers"),
@@ -850,6 +891,28 @@ def main():
                     "what": "SURVEY 8(d): forward 40 C->C convs + head, backward dgrad + wgrad per C->C conv + the head's wgrad "
                             "(elementwise work excluded) over the timed ms_per_step of one rank"}
 
+    # the REQUIRED blocks first (inference forward, `roofline`, the isolated weight-gradient pair): a fault inside a later
+    # extra then cannot cost the line its roofline
+    with torch.no_grad():
+        for _ in range(5):
+            model.fwd_runtime(x)
+        runs = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                model.fwd_runtime(x)
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t0) / 20 * 1e3)
+        infer_ms = sorted(runs)[1]
+    single = roofline_block(dev)
+    dual = roofline_block(dev, full=False, dual=True) if model.dual_chain else None
+    # the dominant kernel as the step runs it: the pair of strip-tile launches when the layer chain
+    # runs as two half-batch chains, else the whole-batch launch
+    line["roofline"] = dual if dual is not None else single
+    line["roofline_single_chain"] = single
+    iso = wgrad_block(dev)
+    line["roofline_wgrad"] = iso
     extras = world == 1 and not a.no_extras
     if extras and ref_semantics and bufs is not None:
         # round 2's headline, now an extra: no per-step loss.item() (the loss comes back as a device scalar) and the
@@ -925,27 +988,6 @@ def main():
         for nf in (32, 64):
             guarded(line["other_widths"], "num_filters_%d" % nf, lambda nf=nf: width(nf))
 
-    # inference forward (extra information)
-    with torch.no_grad():
-        for _ in range(5):
-            model.fwd_runtime(x)
-        runs = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(20):
-                model.fwd_runtime(x)
-            torch.cuda.synchronize()
-            runs.append((time.perf_counter() - t0) / 20 * 1e3)
-        infer_ms = sorted(runs)[1]
-    single = roofline_block(dev)
-    dual = roofline_block(dev, full=False, dual=True) if model.dual_chain else None
-    # the dominant kernel as the step runs it: the pair of strip-tile launches when the layer chain
-    # runs as two half-batch chains, else the whole-batch launch
-    line["roofline"] = dual if dual is not None else single
-    line["roofline_single_chain"] = single
-    iso = wgrad_block(dev)
-    line["roofline_wgrad"] = iso
     if extras:
         # priced, like `roofline`, on what the STEP pays: the captured forward+backward with and without its
         # weight-gradient launches; the back-to-back loop of the launch pair alone (clock pulled down by
@@ -962,8 +1004,10 @@ def main():
         guarded(line, "roofline_wgrad", wgrad_in_the_step)
         if "error" in line["roofline_wgrad"]:
             line["roofline_wgrad"] = dict(iso, in_step_error=line["roofline_wgrad"]["error"])
+    infer_flop = infer_flop_per_lr_pixel(BLOCKS, CH, v2=False) * BATCH * PATCH * PATCH     # 52.08 GFLOP
     line["infer"] = {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
-                     "unit": "HR Mpixels/s"}
+                     "unit": "HR Mpixels/s", "flop": infer_flop,
+                     "frac_of_peak": infer_flop / (infer_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
     if extras:
         def two_chain(c):   # two half-batch strip chains, like the 48-channel layer; else one chain
             blk = roofline_block(dev, c, full=False, dual=True)
@@ -976,7 +1020,11 @@ def main():
         guarded(line, "infer_full_image", lambda: full_image_block(dev))
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
+    if guarded.fault is not None:
+        line["gpu_fault"] = guarded.fault
     emit(line)
+    if guarded.fault is not None:
+        os._exit(4)   # (the context is unusable: no orderly teardown of it)
     if world > 1:
         td.barrier()
         td.destroy_process_group()

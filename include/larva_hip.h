@@ -133,6 +133,33 @@ int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src
                              int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
                              void* stream);
 
+/* ReLU sign bits (round 4).  The reference's autograd keeps h = relu(conv1(x)) and multiplies the incoming gradient
+ * by [h > 0] (models/LarvaNet.py:211, 257: nn.ReLU inside ResidualBlock / recon_block).  The ReLU-backward launch
+ * used to read h (fp32, 7.08 MB at the training shape) as its `mask` operand only to test its sign; the conv + ReLU
+ * launch that produces h can write that sign once, 4 bits per lane:
+ *   maskbits [N][cout / 16][H][ceil(pitch / 16)][64] bytes, byte index within a (16 channels x 16 pixels) unit =
+ *   ((x % 16) / 4) * 16 + (c % 16), bit r = (h[n][c][y][x - x % 4 + r] > 0)    (larva_maskbits_bytes = its size)
+ * The *_mb entry points are their namesakes with two more operands: `maskbits_out` (relu = 1, mode 0, no other
+ * fusion: the launch also writes the bits of its output) and `maskbits` (relu = 0, mask = res0 = res1 = NULL: the
+ * ReLU-backward mask given as bits); both NULL = the namesake.  Same predicate, bit-identical results.  16-byte
+ * staging path only (hipErrorNotSupported otherwise: the caller then passes the fp32 mask). */
+long long larva_maskbits_bytes(int N, int cout, int H, int pitch);
+int larva_conv3x3_fwd_pitched_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                                 const float* bias, const float* res0, const float* res1, const float* mask,
+                                 const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                                 int relu, int mode, const unsigned char* maskbits, unsigned char* maskbits_out,
+                                 void* stream);
+int larva_conv3x3_fwd_batch_mb(int njobs, const float* const* src, int n_src, int cin_per_src,
+                               const float* const* wpk, const float* const* bias, const float* const* res0,
+                               const float* const* res1, const float* const* mask, const float* const* base,
+                               float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
+                               const unsigned char* const* maskbits, unsigned char* const* maskbits_out, void* stream);
+int larva_conv3x3_fwd_strips_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                                const float* bias, const float* res0, const float* res1, const float* mask,
+                                const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                                int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
+                                const unsigned char* maskbits, unsigned char* maskbits_out, void* stream);
+
 /* Measurement only: the same launch `iters` times with kernel-attached events
  * (hipExtLaunchKernelGGL); mean/min kernel duration in ms.  Synchronises the stream. */
 int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,

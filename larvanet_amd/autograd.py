@@ -52,6 +52,32 @@ def _lw():
     return PaddedWidth.current
 
 
+class MaskBits:
+    """ReLU backward from sign bits (round 4).  The reference's autograd keeps h = relu(conv(x)) and multiplies the
+    incoming gradient by [h > 0] (models/LarvaNet.py:211, 257); the ReLU-backward conv launch read the whole fp32 h
+    (7 MB per layer at the training shape, 15 KiB per strip tile held in 16-20 registers through the K loop) only for
+    its sign.  When a backward will follow, the conv + ReLU launch also writes the sign of what it stores -- one byte per
+    lane and (16 channels x 16 pixels) unit, 1/16 of h -- and the backward launch reads that instead
+    (include/larva_hip.h: larva_conv3x3_fwd_*_mb).  h itself is still kept: the next conv and the weight gradient read it.
+    LARVA_MASK_BITS=0: the fp32 mask operand (A/B timing; same results bit for bit, tested)."""
+
+    enabled = os.environ.get("LARVA_MASK_BITS", "1") != "0"
+
+    @classmethod
+    def new(cls, like, *operands):
+        """Sign-bit tensor for an activation shaped like `like`, or None where the launches cannot carry one."""
+        if not cls.enabled or PaddedWidth.current is not None or not K.maskbits_ok(like, *operands):
+            return None
+        return K.new_maskbits(like)
+
+    @staticmethod
+    def mask_kw(bits, h, *operands):
+        """Keyword of the ReLU-backward launch: the bits when they exist and the launch can read them, else h."""
+        if bits is not None and K.maskbits_ok(*operands):
+            return {"maskbits": bits}
+        return {"mask": h}
+
+
 class SideStreams:
     """Concurrency inside one training step.  A conv launch keeps the matrix pipes busy only
     about half of its duration (tile staging, the store burst and the launch floor are exposed),
@@ -166,7 +192,8 @@ class DualChain:
             cls._forked = True
         cls._keep.append(out)
         cls._keep.extend([srcs] if isinstance(srcs, torch.Tensor) else list(srcs))
-        cls._keep.extend(t for t in (wpk, kw.get("bias"), kw.get("mask"), kw.get("res0"), kw.get("res1")) if t is not None)
+        cls._keep.extend(t for t in (wpk, kw.get("bias"), kw.get("mask"), kw.get("res0"), kw.get("res1"), kw.get("maskbits"),
+                                     kw.get("maskbits_out")) if t is not None)
         half = n // 2
         for k, rng in enumerate(((0, half), (half, n))):
             with torch.cuda.stream(cls._stream(k)):
@@ -727,12 +754,15 @@ class BodyFn(torch.autograd.Function):
         nb = len(params) // 4
         keep = [x]
         fea = x
+        training = any(ctx.needs_input_grad)
+        bits = []
         for j in range(nb):
             w1, b1, w2, b2 = params[4 * j:4 * j + 4]
             (f1, _), = pcs[2 * j].get()
             (f2, _), = pcs[2 * j + 1].get()
             c = int(w1.shape[0])
-            h = DualChain.conv(fea, f1, c, forward=True, bias=b1.detach(), relu=True, logical_w=_lw())
+            bits.append(MaskBits.new(fea) if training else None)
+            h = DualChain.conv(fea, f1, c, forward=True, bias=b1.detach(), relu=True, logical_w=_lw(), maskbits_out=bits[-1])
             if j == nb - 1:
                 nxt = DualChain.conv(h, f2, c, forward=True, bias=b2.detach(), res0=fea, res1=x, logical_w=_lw())
             else:
@@ -742,7 +772,8 @@ class BodyFn(torch.autograd.Function):
                 keep.append(nxt)
             fea = nxt
         DualChain.end_of_node(False)
-        ctx.save_for_backward(*keep)
+        ctx.have_bits = all(b is not None for b in bits)
+        ctx.save_for_backward(*keep, *(bits if ctx.have_bits else []))
         ctx.pcs = pcs
         ctx.nb = nb
         ctx.wshape = tuple(params[0].shape)
@@ -750,8 +781,9 @@ class BodyFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        keep = ctx.saved_tensors
         nb, pcs = ctx.nb, ctx.pcs
+        keep = ctx.saved_tensors[:2 * nb]
+        bits = ctx.saved_tensors[2 * nb:] if ctx.have_bits else [None] * nb
         dy = dy.contiguous()
         c = ctx.wshape[0]
         # keep = [x, h0, fea1, h1, fea2, ..., h_{nb-1}]
@@ -763,7 +795,7 @@ class BodyFn(torch.autograd.Function):
             h_j = keep[2 * j + 1]
             (_, bw1), = pcs[2 * j].get()
             (_, bw2), = pcs[2 * j + 1].get()
-            dh = DualChain.conv(g, bw2, c, mask=h_j)
+            dh = DualChain.conv(g, bw2, c, **MaskBits.mask_kw(bits[j], h_j, g))
             jobs[2 * j + 1] = (g, h_j, ctx.wshape, 0, c) + _targets(pcs[2 * j + 1])
             jobs[2 * j] = (dh, fea_j, ctx.wshape, 0, c) + _targets(pcs[2 * j])
             if j > 0:
@@ -797,22 +829,25 @@ class LegFn(torch.autograd.Function):
         (f1, _), = pcs[0].get()
         (f2, _), = pcs[1].get()
         c = int(w1.shape[0])
-        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True, logical_w=_lw())
+        bits = MaskBits.new(fea) if any(ctx.needs_input_grad) else None
+        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True, logical_w=_lw(), maskbits_out=bits)
         out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base, logical_w=_lw())
-        ctx.save_for_backward(fea, h)
+        ctx.have_bits = bits is not None
+        ctx.save_for_backward(fea, h, *([bits] if bits is not None else []))
         ctx.pcs = pcs
         ctx.wshape, ctx.wshape2 = tuple(w1.shape), tuple(w2.shape)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        fea, h = ctx.saved_tensors
+        fea, h = ctx.saved_tensors[:2]
+        bits = ctx.saved_tensors[2] if ctx.have_bits else None
         pcs = ctx.pcs
         c, c2 = ctx.wshape[0], ctx.wshape2[0]
         (_, bw1), = pcs[0].get()
         (_, bw2), = pcs[1].get()
         dyl = K.pixel_unshuffle4(dout.contiguous())
-        dh = K.conv3x3(dyl, bw2, c, mask=h)
+        dh = K.conv3x3(dyl, bw2, c, **MaskBits.mask_kw(bits, h, dyl))
         dfea = K.conv3x3(dh, bw1, c)
         ((dw1, db1),), ((dw2, db2),) = _leg_wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0])],
                                                     [(dyl, h, ctx.wshape2, 0, c) + _targets(pcs[1])], c, c2)
@@ -847,7 +882,8 @@ class ExitFn(torch.autograd.Function):
         (f1, _), = pcs[0].get()
         (f2, _), = pcs[1].get()
         c = int(w1.shape[0])
-        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True)
+        bits = MaskBits.new(fea)
+        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True, maskbits_out=bits)
         out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base)
         dyl = None
         if divisor is None:
@@ -863,10 +899,12 @@ class ExitFn(torch.autograd.Function):
             else:
                 term, _ = K.l1_partial(out, truth)
         ctx.have_dyl = dyl is not None
+        ctx.have_bits = bits is not None
+        tail = [bits] if bits is not None else []
         if dyl is not None:
-            ctx.save_for_backward(fea, h, dyl)
+            ctx.save_for_backward(fea, h, dyl, *tail)
         else:
-            ctx.save_for_backward(fea, h, out, truth)
+            ctx.save_for_backward(fea, h, out, truth, *tail)
         ctx.pcs = pcs
         ctx.wshape, ctx.wshape2 = tuple(w1.shape), tuple(w2.shape)
         ctx.mark_non_differentiable(out)
@@ -875,10 +913,11 @@ class ExitFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _dout, gterm):
+        bits = ctx.saved_tensors[-1] if ctx.have_bits else None
         if ctx.have_dyl:
-            fea, h, dyl = ctx.saved_tensors
+            fea, h, dyl = ctx.saved_tensors[:3]
         else:
-            fea, h, out, truth = ctx.saved_tensors
+            fea, h, out, truth = ctx.saved_tensors[:4]
         pcs = ctx.pcs
         c = ctx.wshape[0]
         if gterm is None:
@@ -889,7 +928,7 @@ class ExitFn(torch.autograd.Function):
             # (a partial-sum term receives its scalar gradient broadcast to its shape: element 0)
             g0 = gterm.as_strided((), ()) if gterm.dim() else gterm.contiguous()
             dyl = K.l1_bwd_unshuffle4(out, truth, g0, ctx.gscale)
-        dh = K.conv3x3(dyl, bw2, c, mask=h)
+        dh = K.conv3x3(dyl, bw2, c, **MaskBits.mask_kw(bits, h, dyl))
         dfea = K.conv3x3(dh, bw1, c)
         ((dw1, db1),), ((dw2, db2),) = _leg_wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0])],
                                                     [(dyl, h, ctx.wshape2, 0, c) + _targets(pcs[1])], c, ctx.wshape2[0])
@@ -908,7 +947,8 @@ def _conv_group(jobs, cout, **kw):
         if len(chunk) == 1:
             j = chunk[0]
             outs.append(K.conv3x3(j["srcs"], j["wpk"], cout, bias=j.get("bias"), mask=j.get("mask"), base=j.get("base"),
-                                  res0=j.get("res0"), res1=j.get("res1"), **kw))
+                                  res0=j.get("res0"), res1=j.get("res1"), maskbits=j.get("maskbits"),
+                                  maskbits_out=j.get("maskbits_out"), **kw))
         else:
             outs += K.conv3x3_batch(chunk, cout, **kw)
     return outs
@@ -933,8 +973,11 @@ class ExitsFn(torch.autograd.Function):
         feas, params = args[:M], args[M:]   # params: (w1, b1, w2, b2) per exit
         c = int(params[0].shape[0])
         c2 = int(params[2].shape[0])
-        hs = _conv_group([{"srcs": feas[i], "wpk": legs[i][0].get()[0][0], "bias": params[4 * i + 1].detach()}
-                          for i in range(M)], c, relu=True)
+        bits = [MaskBits.new(feas[i]) for i in range(M)]
+        if any(b is None for b in bits):
+            bits = [None] * M   # (a batched launch carries the operand for every job or for none)
+        hs = _conv_group([{"srcs": feas[i], "wpk": legs[i][0].get()[0][0], "bias": params[4 * i + 1].detach(),
+                           "maskbits_out": bits[i]} for i in range(M)], c, relu=True)
         ctx.gscale = float(np.float32(1.0) / np.float32(divisor))
         ctx.have_dyl = StepScope.seed_grad is not None
         shuffle_jobs = [{"srcs": hs[i], "wpk": legs[i][1].get()[0][0], "bias": params[4 * i + 3].detach(), "base": base}
@@ -968,7 +1011,8 @@ class ExitsFn(torch.autograd.Function):
                     part, _ = K.l1_partial(out, truth)
                     parts.append(part)
                     third.append(out)
-        ctx.save_for_backward(truth, *feas, *hs, *third)
+        ctx.have_bits = bits[0] is not None
+        ctx.save_for_backward(truth, *feas, *hs, *third, *(bits if ctx.have_bits else []))
         ctx.legs, ctx.M = legs, M
         ctx.wshape, ctx.wshape2 = tuple(params[0].shape), tuple(params[2].shape)
         ctx.mark_non_differentiable(outs[-1])
@@ -980,6 +1024,7 @@ class ExitsFn(torch.autograd.Function):
         M, legs = ctx.M, ctx.legs
         saved = ctx.saved_tensors
         truth, feas, hs, third = saved[0], saved[1:1 + M], saved[1 + M:1 + 2 * M], saved[1 + 2 * M:1 + 3 * M]
+        bits = saved[1 + 3 * M:1 + 4 * M] if ctx.have_bits else [None] * M
         c = ctx.wshape[0]
         live = [i for i in range(M) if gterms[i] is not None]
         dyls = {}
@@ -989,7 +1034,9 @@ class ExitsFn(torch.autograd.Function):
             else:
                 g0 = gterms[i].as_strided((), ())  # the scalar gradient arrives broadcast to the term's shape
                 dyls[i] = K.l1_bwd_unshuffle4(third[i], truth, g0, ctx.gscale)
-        dhs = dict(zip(live, _conv_group([{"srcs": dyls[i], "wpk": legs[i][1].get()[0][1], "mask": hs[i]}
+        use_bits = ctx.have_bits and all(K.maskbits_ok(dyls[i]) for i in live)
+        dhs = dict(zip(live, _conv_group([dict({"srcs": dyls[i], "wpk": legs[i][1].get()[0][1]},
+                                               **({"maskbits": bits[i]} if use_bits else {"mask": hs[i]}))
                                           for i in live], c))) if live else {}
         dfeas = [None] * M
         grads = [None] * (4 * M)

@@ -181,6 +181,13 @@ struct ConvArgs {
   float* grad;                // [N][COUT][H][pitch]: sign(out - truth) * gval, pixel-unshuffled
   float* partial;             // [4 * nwg]: sum |out - truth| of every MFMA wave's share of its tile
   int plain_stores;           // strip kernel, mode-0 output: plain instead of non-temporal stores (see the epilogue)
+  // ReLU sign bits (round 4): the 16-byte-path conv+ReLU launch also writes, and the ReLU-backward launch (kEpiMaskBits)
+  // reads, ONE BYTE per lane and (16 channels x 16 pixels) unit instead of a 16-byte fp32 mask operand:
+  //   byte [n][c / 16][y][x / 16][lane],  lane = ((x % 16) / 4) * 16 + c % 16,  bit r = relu output of pixel x - x % 4 + r > 0
+  // (the pixel-major accumulator layout, see run_role) -- 1/16 of the fp32 tensor the reference's autograd keeps
+  // for `ReLU` backward (models/LarvaNet.py:211); the predicate is the same `h > 0`.
+  const unsigned char* maskbits;   // kEpiMaskBits
+  unsigned char* maskbits_out;     // kEpiRelu, or null
   float gval;                 // d loss / d out element = seed * (1/M) / numel
                               // (`out` may be null with this epilogue: the exit's image is not wanted)
   // ceil(2^40 / d) for d = tiles_x, tiles_y, cin_per_src / 8: the kernel's wave-uniform divisions
@@ -209,8 +216,14 @@ enum Epi : int {
   kEpiShuffleBase = 6,  // pixel-shuffle(4) store, + base
   kEpiShuffleL1 = 7,    // + base, then L1 against `truth`: partial sums of |out - truth| and the sign
                         // gradient in pixel-unshuffled layout from the registers (image store optional)
-  kEpiCount = 8
+  kEpiMaskBits = 8,     // kEpiMask with the mask given as sign bits (ConvArgs::maskbits); 16-byte path only
+  kEpiCount = 9
 };
+
+// bytes of one image's sign-bit tensor: [cout / 16][H][ceil(pitch / 16)][64]
+__host__ __device__ __forceinline__ size_t maskbits_image_bytes(int cout, int H, int pitch) {
+  return (size_t)(cout / 16) * (size_t)H * (size_t)((pitch + 15) / 16) * 64;
+}
 
 template <int COUT, typename G = GeoWide>
 struct ConvCfg {
@@ -689,8 +702,22 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiShuffleBase)
                            ? 1 : ((EPI == kEpiRes2 || EPI == kEpiShuffleL1) ? 2 : 0);
   f32x4 aux[(NAUX > 0 && !AUXLDS) ? NAUX : 1][(NAUX > 0 && !AUXLDS) ? NCT : 1][(NAUX > 0 && !AUXLDS) ? NPG : 1];
+  static_assert(EPI != kEpiMaskBits || kPixMajor, "sign-bit masks: pixel-major accumulators (16-byte path) only");
+  unsigned mbits[EPI == kEpiMaskBits ? NCT : 1][EPI == kEpiMaskBits ? NPG : 1];   // one byte per (c, p) unit
+  const int nxg = (a.pitch + 15) >> 4;   // 16-pixel groups per row of the sign-bit tensor
+  auto bits_at = [&](int c, int y, int xcol) {   // byte offset of this lane's nibble of unit (channel group ct0 + c, row y, column xcol)
+    return ((((size_t)n * C::CT + (ct0 + c)) * a.H + y) * nxg + (xcol >> 4)) * 64 + lane;
+  };
   auto load_aux = [&]() {
-    if constexpr (!AUXLDS)   // (else the loader wave streams them into LDS)
+    if constexpr (EPI == kEpiMaskBits) {
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int p = 0; p < NPG; ++p) {
+          const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
+          mbits[c][p] = a.maskbits[bits_at(c, min(y0 + prow, a.H - 1), min(x0 + pcol * 16, a.pitch - 1))];
+        }
+    } else if constexpr (!AUXLDS)   // (else the loader wave streams them into LDS)
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -723,7 +750,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   };
   auto load_early = [&]() {
     load_bias();
-    if constexpr (NAUX > 0 && LARVA_AUX_EARLY && !(LARVA_DIAG & 4)) load_aux();
+    if constexpr ((NAUX > 0 || EPI == kEpiMaskBits) && LARVA_AUX_EARLY && !(LARVA_DIAG & 4)) load_aux();
   };
   if constexpr (!VEC || (LARVA_DIAG & 2)) load_early();
 
@@ -856,7 +883,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     return;
   }
 
-  if constexpr (NAUX > 0 && !LARVA_AUX_EARLY && !AUXLDS) load_aux();
+  if constexpr ((NAUX > 0 || EPI == kEpiMaskBits) && !LARVA_AUX_EARLY && !AUXLDS) load_aux();
 
   // Epilogue.  Lane (lr, lq) holds, in acc[c][p][r], output channel (ct0+c)*16 + lq*4 + r of
   // pixel (y0 + pg/3, x0 + (pg%3)*16 + lr).
@@ -940,6 +967,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
                 if constexpr (EPI == kEpiRes2) o += auxl[1][c][p][r];
               } else {
                 if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
+                if constexpr (EPI == kEpiMaskBits) o = ((mbits[c][p] >> r) & 1u) ? o : 0.f;
                 if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
                 if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
               }
@@ -947,6 +975,12 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
             }
             if constexpr (kPlain) *reinterpret_cast<f32x4*>(a.out + idx) = v;
             else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
+            if constexpr (EPI == kEpiRelu) {
+              if (a.maskbits_out) {   // (wave-uniform) the sign bits of what was just stored: `h > 0` of the ReLU backward
+                const unsigned b = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+                a.maskbits_out[bits_at(c, y, x0 + pcol * 16)] = (unsigned char)b;
+              }
+            }
           }
         }
     };
@@ -1015,7 +1049,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
 __device__ __forceinline__ void fetch_args(const ConvArgs& a) {
   asm volatile("" ::"s"(a.src[0]), "s"(a.wpk), "s"(a.bias), "s"(a.out), "s"(a.cin_per_src), "s"(a.n_chunks), "s"(a.N),
                "s"(a.H), "s"(a.W), "s"(a.pitch), "s"(a.tiles_x), "s"(a.tiles_y), "s"(a.magic_tx), "s"(a.magic_ty),
-               "s"(a.magic_cps), "s"(a.nwg), "s"(a.tile_tab));
+               "s"(a.magic_cps), "s"(a.nwg), "s"(a.tile_tab), "s"(a.maskbits_out));
 }
 
 // VEC: 2 workgroups per CU (launch bound 2 waves/SIMD caps the registers at 256).
@@ -1301,6 +1335,9 @@ static hipError_t launch_conv_v(const ConvArgs& a, int epi, hipStream_t stream, 
     case kEpiPlain: return launch_conv_e<COUT, VEC, kEpiPlain>(a, stream, tm);
     case kEpiRelu: return launch_conv_e<COUT, VEC, kEpiRelu>(a, stream, tm);
     case kEpiMask: return launch_conv_e<COUT, VEC, kEpiMask>(a, stream, tm);
+    case kEpiMaskBits:
+      if constexpr (VEC && LARVA_PIXEL_MAJOR) return launch_conv_e<COUT, VEC, kEpiMaskBits>(a, stream, tm);
+      else return hipErrorNotSupported;
     case kEpiRes1: return launch_conv_e<COUT, VEC, kEpiRes1>(a, stream, tm);
     case kEpiRes2: return launch_conv_e<COUT, VEC, kEpiRes2>(a, stream, tm);
     case kEpiShuffle: return launch_conv_e<COUT, VEC, kEpiShuffle>(a, stream, tm);
@@ -1336,6 +1373,9 @@ static hipError_t launch_batch(const ConvBatch& b, int njobs, int epi, hipStream
     case kEpiPlain: return launch_batch_e<COUT, kEpiPlain>(b, njobs, stream);
     case kEpiRelu: return launch_batch_e<COUT, kEpiRelu>(b, njobs, stream);
     case kEpiMask: return launch_batch_e<COUT, kEpiMask>(b, njobs, stream);
+    case kEpiMaskBits:
+      if constexpr (LARVA_PIXEL_MAJOR) return launch_batch_e<COUT, kEpiMaskBits>(b, njobs, stream);
+      else return hipErrorNotSupported;
     case kEpiRes1: return launch_batch_e<COUT, kEpiRes1>(b, njobs, stream);
     case kEpiRes2: return launch_batch_e<COUT, kEpiRes2>(b, njobs, stream);
     case kEpiShuffle: return launch_batch_e<COUT, kEpiShuffle>(b, njobs, stream);
@@ -1371,6 +1411,9 @@ static hipError_t launch_strip(const ConvArgs& a, int epi, hipStream_t stream, c
     case kEpiPlain: return launch_strip_e<COUT, kEpiPlain>(a, stream, tm);
     case kEpiRelu: return launch_strip_e<COUT, kEpiRelu>(a, stream, tm);
     case kEpiMask: return launch_strip_e<COUT, kEpiMask>(a, stream, tm);
+    case kEpiMaskBits:
+      if constexpr (LARVA_PIXEL_MAJOR) return launch_strip_e<COUT, kEpiMaskBits>(a, stream, tm);
+      else return hipErrorNotSupported;
     case kEpiRes1: return launch_strip_e<COUT, kEpiRes1>(a, stream, tm);
     case kEpiRes2: return launch_strip_e<COUT, kEpiRes2>(a, stream, tm);
     case kEpiShuffle: return launch_strip_e<COUT, kEpiShuffle>(a, stream, tm);
@@ -1462,9 +1505,15 @@ int larva_diag_arm_slots(int first, int cap) {
 // (cout, n_src*cin_per_src).  Epilogue, in this order: relu -> mask -> +res0 -> +res1 -> store
 // (mode 0, [N][cout][H][W]) or pixel-shuffle(4) store with optional +base (mode 1,
 // [N][cout/16][4H][4W]).  Stream-ordered, never allocates or synchronises.
+struct MaskBitsArg {
+  const unsigned char* in = nullptr;   // ReLU-backward mask as sign bits (instead of `mask`)
+  unsigned char* out = nullptr;        // conv+ReLU: also write the sign bits of the output
+};
+
 static int conv_build(const float* const* src, int n_src, int cin_per_src, const float* wpk, const float* bias,
                       const float* res0, const float* res1, const float* mask, const float* base, float* out,
-                      int N, int H, int W, int pitch, int relu, int mode, ConvArgs& a, bool& aligned, int& epi) {
+                      int N, int H, int W, int pitch, int relu, int mode, ConvArgs& a, bool& aligned, int& epi,
+                      MaskBitsArg mb = MaskBitsArg{}) {
   if (pitch == 0) pitch = W;
   if (pitch < W) return (int)hipErrorInvalidValue;
   if (n_src < 1 || n_src > kMaxSrc || cin_per_src % kCh || cin_per_src <= 0 || N <= 0 || H <= 0 || W <= 0)
@@ -1487,6 +1536,13 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
                           reinterpret_cast<uintptr_t>(res1) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0);
   a.wpk = wpk; a.bias = bias; a.res0 = res0; a.res1 = res1; a.mask = mask; a.base = base;
   a.out = out;
+  a.maskbits = mb.in; a.maskbits_out = mb.out;
+  if (mb.in || mb.out) {
+    // sign bits exist on the 16-byte path with pixel-major accumulators only; a launch is either the producer
+    // (conv + ReLU, nothing else fused) or the consumer (ReLU-backward mask, nothing else fused)
+    if (!aligned || !LARVA_PIXEL_MAJOR) return (int)hipErrorNotSupported;
+    if (mode != 0 || mask || res0 || res1 || (mb.in && (relu || mb.out)) || (mb.out && !relu)) return (int)hipErrorInvalidValue;
+  }
   a.cin_per_src = cin_per_src;
   a.n_chunks = n_src * cin_per_src / kCh;
   a.N = N; a.H = H; a.W = W; a.pitch = pitch;
@@ -1503,8 +1559,9 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
     epi = base ? kEpiShuffleBase : kEpiShuffle;
   } else {
     if (base) return (int)hipErrorInvalidValue;
-    const int code = (relu ? 1 : 0) | (mask ? 2 : 0) | (res0 ? 4 : 0) | (res1 ? 8 : 0);
+    const int code = (relu ? 1 : 0) | (mask ? 2 : 0) | (res0 ? 4 : 0) | (res1 ? 8 : 0) | (mb.in ? 16 : 0);
     switch (code) {
+      case 16: epi = kEpiMaskBits; break;
       case 0: epi = kEpiPlain; break;
       case 1: epi = kEpiRelu; break;
       case 2: epi = kEpiMask; break;
@@ -1519,12 +1576,12 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
 static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                          const float* bias, const float* res0, const float* res1, const float* mask,
                          const float* base, float* out, int N, int cout, int H, int W, int pitch, int relu,
-                         int mode, void* stream, const LaunchTiming* tm) {
+                         int mode, void* stream, const LaunchTiming* tm, MaskBitsArg mb = MaskBitsArg{}) {
   ConvArgs a;
   bool aligned;
   int epi;
   const int rc = conv_build(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, H, W, pitch, relu,
-                            mode, a, aligned, epi);
+                            mode, a, aligned, epi, mb);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   switch (cout) {
@@ -1557,16 +1614,36 @@ int larva_conv3x3_fwd_pitched(const float* const* src, int n_src, int cin_per_sr
                        relu, mode, stream, nullptr);
 }
 
+// ReLU sign bits.  larva_maskbits_bytes: size of the sign-bit tensor of an [N][cout][H][pitch] activation
+// ([N][cout / 16][H][ceil(pitch / 16)][64] bytes, see ConvArgs::maskbits).  The *_mb entry points are their namesakes
+// with two more operands: maskbits_out (conv + ReLU launches: also write the output's sign bits) and maskbits (the
+// ReLU-backward mask `h > 0` of models/LarvaNet.py:211's autograd given as those bits instead of the fp32 tensor h:
+// relu = 0, mask = res0 = res1 = NULL).  16-byte staging path only: hipErrorNotSupported otherwise (the caller
+// then passes the fp32 mask).  Results are bit-identical to the fp32-mask launch.
+long long larva_maskbits_bytes(int N, int cout, int H, int pitch) {
+  if (N <= 0 || cout <= 0 || cout % 16 || H <= 0 || pitch <= 0) return -1;
+  return (long long)N * (long long)maskbits_image_bytes(cout, H, pitch);
+}
+
+int larva_conv3x3_fwd_pitched_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                                 const float* bias, const float* res0, const float* res1, const float* mask,
+                                 const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                                 int relu, int mode, const unsigned char* maskbits, unsigned char* maskbits_out,
+                                 void* stream) {
+  return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch,
+                       relu, mode, stream, nullptr, MaskBitsArg{maskbits, maskbits_out});
+}
+
 // njobs (2..4) INDEPENDENT convolutions of one shape and one fusion in ONE launch (their workgroups
 // share the CUs two by two).  src: njobs * n_src pointers (job-major); every other operand an array
 // of njobs pointers, or NULL when no job uses it (a fusion is either used by all jobs or by none).
 // Only the 16-byte staging path (pitch % 4 == 0, 16-byte aligned tensors): otherwise
 // hipErrorNotSupported, and the caller issues the jobs one by one.
-int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int cin_per_src,
+static int conv_batch_dispatch(int njobs, const float* const* src, int n_src, int cin_per_src,
                             const float* const* wpk, const float* const* bias, const float* const* res0,
                             const float* const* res1, const float* const* mask, const float* const* base,
                             float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
-                            void* stream) {
+                            const unsigned char* const* maskbits, unsigned char* const* maskbits_out, void* stream) {
   if (njobs < 2 || njobs > kMaxConvJobs || !src || !wpk || !out) return (int)hipErrorInvalidValue;
   ConvBatch b{};
   int epi0 = -1;
@@ -1575,10 +1652,12 @@ int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int c
     int epi;
     const int rc = conv_build(src + (size_t)j * n_src, n_src, cin_per_src, wpk[j], bias ? bias[j] : nullptr,
                               res0 ? res0[j] : nullptr, res1 ? res1[j] : nullptr, mask ? mask[j] : nullptr,
-                              base ? base[j] : nullptr, out[j], N, H, W, pitch, relu, mode, b.job[j], aligned, epi);
+                              base ? base[j] : nullptr, out[j], N, H, W, pitch, relu, mode, b.job[j], aligned, epi,
+                              MaskBitsArg{maskbits ? maskbits[j] : nullptr, maskbits_out ? maskbits_out[j] : nullptr});
     if (rc) return rc;
     if (!aligned) return (int)hipErrorNotSupported;
     if (j > 0 && epi != epi0) return (int)hipErrorInvalidValue;
+    if ((maskbits && !maskbits[j]) || (maskbits_out && !maskbits_out[j])) return (int)hipErrorInvalidValue;   // all jobs or none
     epi0 = epi;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -1590,6 +1669,24 @@ int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int c
     case 48: return (int)launch_batch<48>(b, njobs, epi0, s);
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int cin_per_src,
+                            const float* const* wpk, const float* const* bias, const float* const* res0,
+                            const float* const* res1, const float* const* mask, const float* const* base,
+                            float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
+                            void* stream) {
+  return conv_batch_dispatch(njobs, src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch,
+                             relu, mode, nullptr, nullptr, stream);
+}
+
+int larva_conv3x3_fwd_batch_mb(int njobs, const float* const* src, int n_src, int cin_per_src,
+                               const float* const* wpk, const float* const* bias, const float* const* res0,
+                               const float* const* res1, const float* const* mask, const float* const* base,
+                               float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
+                               const unsigned char* const* maskbits, unsigned char* const* maskbits_out, void* stream) {
+  return conv_batch_dispatch(njobs, src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch,
+                             relu, mode, maskbits, maskbits_out, stream);
 }
 
 // njobs (2..4) EXITS of the training step in one launch (models/LarvaNet.py:104-109 for several i):
@@ -1691,14 +1788,14 @@ static int strips_dispatch(const float* const* src, int n_src, int cin_per_src, 
                            const float* bias, const float* res0, const float* res1, const float* mask,
                            const float* base, float* out, int N, int cout, int H, int W, int pitch,
                            int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
-                           void* stream, const LaunchTiming* tm) {
+                           void* stream, const LaunchTiming* tm, MaskBitsArg mb = MaskBitsArg{}) {
   if (cout != 48 && cout != 32 && cout != 64) return (int)hipErrorNotSupported;
   if (!tile_tab || tiles_per_image < 1) return (int)hipErrorInvalidValue;
   ConvArgs a;
   bool aligned;
   int epi;
   const int rc = conv_build(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, H, W, pitch, relu,
-                            mode, a, aligned, epi);
+                            mode, a, aligned, epi, mb);
   if (rc) return rc;
   if (!aligned) return (int)hipErrorNotSupported;
   if ((long long)N * tiles_per_image >= (1ll << 20)) return (int)hipErrorInvalidValue;  // div_by_magic range
@@ -1727,6 +1824,15 @@ int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src
                              void* stream) {
   return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu, mode,
                          tile_tab, tiles_per_image, plain_stores, stream, nullptr);
+}
+
+int larva_conv3x3_fwd_strips_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                                const float* bias, const float* res0, const float* res1, const float* mask,
+                                const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                                int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
+                                const unsigned char* maskbits, unsigned char* maskbits_out, void* stream) {
+  return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu, mode,
+                         tile_tab, tiles_per_image, plain_stores, stream, nullptr, MaskBitsArg{maskbits, maskbits_out});
 }
 
 #if LARVA_DIAG & 32

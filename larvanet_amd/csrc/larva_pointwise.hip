@@ -766,6 +766,6 @@ int larva_sqerr_u8(const float* out, const unsigned char* truth, int C, int H, i
 
 const char* larva_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
-int larva_abi_version(void) { return 3; }   // 3: unpadded, swizzled packed weight rows at 32 / 64 channels; AdamW hyper-parameters as doubles
+int larva_abi_version(void) { return 4; }   // 4: ReLU sign-bit operands (*_mb entry points).  3: unpadded, swizzled packed weight rows at 32 / 64 channels; AdamW hyper-parameters as doubles
 
 }  // extern "C"

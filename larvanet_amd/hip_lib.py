@@ -35,6 +35,22 @@ SIGNATURES = {
     "larva_conv3x3_fwd_batch": (ctypes.c_int, [ctypes.c_int, _c_pp, ctypes.c_int, ctypes.c_int, _c_pp, _c_pp, _c_pp, _c_pp,
                                                _c_pp, _c_pp, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_maskbits_bytes": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "larva_conv3x3_fwd_pitched_mb": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
+                                                    _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p]),
+    "larva_conv3x3_fwd_batch_mb": (ctypes.c_int, [ctypes.c_int, _c_pp, ctypes.c_int, ctypes.c_int, _c_pp, _c_pp, _c_pp, _c_pp,
+                                                  _c_pp, _c_pp, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_pp, _c_pp,
+                                                  ctypes.c_void_p]),
+    "larva_conv3x3_fwd_strips_mb": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
+                                                   _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_void_p]),
     "larva_head_conv3_direct": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_exit_l1_partials": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),

@@ -141,8 +141,39 @@ def step_prologue(jobs, x, x16, base):
     hip_lib.check(code, "larva_step_prologue")
 
 
+def maskbits_bytes(N, cout, H, P):
+    """Bytes of the ReLU sign-bit tensor of an [N][cout][H][P] activation (include/larva_hip.h: larva_maskbits_bytes)."""
+    n = int(hip_lib.load().larva_maskbits_bytes(int(N), int(cout), int(H), int(P)))
+    if n < 0:
+        raise RuntimeError("larvanet_amd: no sign-bit layout for %s" % ((N, cout, H, P),))
+    return n
+
+
+def maskbits_ok(*tensors):
+    """Can launches over these [N][c][H][P] operands take the conv kernel's 16-byte staging path -- the only one that
+    writes / reads ReLU sign bits?  (Row pitch a multiple of 4 floats, every tensor 16-byte aligned.)"""
+    return all(t is not None and t.is_cuda and int(t.shape[-1]) % 4 == 0 and t.data_ptr() % 16 == 0 for t in tensors)
+
+
+def new_maskbits(like, cout=None):
+    """Uninitialised sign-bit tensor for an activation shaped like `like` ([N][c][H][P])."""
+    N, c, H, P = (int(v) for v in like.shape)
+    return torch.empty(maskbits_bytes(N, c if cout is None else cout, H, P), device=like.device, dtype=torch.uint8)
+
+
+def _chk_bits(t, name, N, cout, H, P):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous():
+        raise RuntimeError("larvanet_amd: %s must be a contiguous uint8 tensor on the HIP device" % name)
+    if t.numel() != maskbits_bytes(N, cout, H, P):
+        raise RuntimeError("larvanet_amd: %s has %d bytes, expected %d" % (name, t.numel(), maskbits_bytes(N, cout, H, P)))
+    return t.data_ptr()
+
+
 def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=None,
-            shuffle=False, base=None, out=None, logical_w=None, images=None, strips=False, plain_stores=False):
+            shuffle=False, base=None, out=None, logical_w=None, images=None, strips=False, plain_stores=False,
+            maskbits=None, maskbits_out=None):
     """Fused 3x3 conv over the channel concatenation of `srcs` (list of [N][c][H][P]).
 
     shuffle=False: returns [N][cout][H][P]; shuffle=True: returns PixelShuffle(4) layout
@@ -153,7 +184,10 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     tensor; the other images of `out` are left untouched).  strips=True (or 2: the tile table
     starts with the other tile height): 5 x 16 / 4 x 16 tiles instead of 3 x 48 (same results bit for
     bit; see larva_conv3x3_fwd_strips) where the shape allows, else the regular tiles; plain_stores:
-    the strip launch writes its output with plain instead of non-temporal stores."""
+    the strip launch writes its output with plain instead of non-temporal stores.
+    maskbits_out (with relu=True): the launch also writes the sign bits of its output (new_maskbits());
+    maskbits: the ReLU-backward mask given as those bits instead of `mask` (same result bit for bit).  Both need
+    maskbits_ok() operands (the 16-byte staging path) and raise otherwise."""
     lib = hip_lib.load()
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
@@ -182,6 +216,13 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     def at(ptr, per_image_floats):   # the same operand, starting at image `lo`
         return None if ptr is None else ptr + 4 * lo * per_image_floats
 
+    bits_in = _chk_bits(maskbits, "maskbits", N, cout, H, P)
+    bits_out = _chk_bits(maskbits_out, "maskbits_out", N, cout, H, P)
+    use_bits = bits_in is not None or bits_out is not None
+    if use_bits:
+        per = maskbits_bytes(1, cout, H, P)
+        bits_in = None if bits_in is None else bits_in + lo * per
+        bits_out = None if bits_out is None else bits_out + lo * per
     lr_img, hr_img = H * P, 16 * H * W
     args = (hip_lib.ptr_array([at(p, cps * lr_img) for p in ptrs]), len(srcs), cps, wpk.data_ptr(),
             _opt(bias, "bias", (cout,)), at(_opt(res0, "res0", full), cout * lr_img),
@@ -192,11 +233,18 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     if strips and cout in (48, 32, 64):
         tab = strip_tile_table(H, P, out.device, phase=1 if strips == 2 else 0)
         if tab is not None:
-            code = lib.larva_conv3x3_fwd_strips(*args, tab[0].data_ptr(), tab[1], 1 if plain_stores else 0, _stream())
+            if use_bits:
+                code = lib.larva_conv3x3_fwd_strips_mb(*args, tab[0].data_ptr(), tab[1], 1 if plain_stores else 0,
+                                                       bits_in, bits_out, _stream())
+            else:
+                code = lib.larva_conv3x3_fwd_strips(*args, tab[0].data_ptr(), tab[1], 1 if plain_stores else 0, _stream())
             if code != 801:   # hipErrorNotSupported: unaligned operands -> the regular tiles below
                 hip_lib.check(code, "larva_conv3x3_fwd_strips")
                 return out
-    code = lib.larva_conv3x3_fwd_pitched(*args, _stream())
+    if use_bits:   # (unaligned operands: hipErrorNotSupported is raised -- callers ask maskbits_ok() first)
+        code = lib.larva_conv3x3_fwd_pitched_mb(*args, bits_in, bits_out, _stream())
+    else:
+        code = lib.larva_conv3x3_fwd_pitched(*args, _stream())
     hip_lib.check(code, "larva_conv3x3_fwd")
     return out
 
@@ -220,7 +268,7 @@ def conv3x3_batch(jobs, cout, relu=False, shuffle=False, logical_w=None):
         raise RuntimeError("larvanet_amd: unsupported batched conv shape")
     cin = cps * n_src
     full, hr = (N, cout, H, P), (N, cout // 16, 4 * H, 4 * W)
-    names = ("bias", "res0", "res1", "mask", "base")
+    names = ("bias", "res0", "res1", "mask", "base", "maskbits", "maskbits_out")
     used = {k: norm[0].get(k) is not None for k in names}
     src_ptrs, cols, outs = [], {k: [] for k in names}, []
     for j in norm:
@@ -231,20 +279,26 @@ def conv3x3_batch(jobs, cout, relu=False, shuffle=False, logical_w=None):
         for k, shape in (("bias", (cout,)), ("res0", full), ("res1", full), ("mask", full), ("base", hr)):
             if used[k]:
                 cols[k].append(_chk(j[k], k, shape))
+        for k in ("maskbits", "maskbits_out"):
+            if used[k]:
+                cols[k].append(_chk_bits(j[k], k, N, cout, H, P))
         outs.append(torch.empty(hr if shuffle else full, device=j["srcs"][0].device, dtype=torch.float32))
 
     def arr(k):
         return hip_lib.ptr_array(cols[k]) if used[k] else None
 
-    code = lib.larva_conv3x3_fwd_batch(
-        len(norm), hip_lib.ptr_array(src_ptrs), n_src, cps, hip_lib.ptr_array([j["wpk"].data_ptr() for j in norm]),
-        arr("bias"), arr("res0"), arr("res1"), arr("mask"), arr("base"),
-        hip_lib.ptr_array([o.data_ptr() for o in outs]), N, cout, H, W, P, 1 if relu else 0, 1 if shuffle else 0,
-        _stream())
+    common = (len(norm), hip_lib.ptr_array(src_ptrs), n_src, cps, hip_lib.ptr_array([j["wpk"].data_ptr() for j in norm]),
+              arr("bias"), arr("res0"), arr("res1"), arr("mask"), arr("base"),
+              hip_lib.ptr_array([o.data_ptr() for o in outs]), N, cout, H, W, P, 1 if relu else 0, 1 if shuffle else 0)
+    if used["maskbits"] or used["maskbits_out"]:
+        code = lib.larva_conv3x3_fwd_batch_mb(*common, arr("maskbits"), arr("maskbits_out"), _stream())
+    else:
+        code = lib.larva_conv3x3_fwd_batch(*common, _stream())
     if code == 801:  # hipErrorNotSupported: unaligned shape, one launch per job
         return [conv3x3(j["srcs"], j["wpk"], cout, bias=j.get("bias"), relu=relu, mask=j.get("mask"),
                         res0=j.get("res0"), res1=j.get("res1"), shuffle=shuffle, base=j.get("base"), out=o,
-                        logical_w=logical_w) for j, o in zip(norm, outs)]
+                        logical_w=logical_w, maskbits=j.get("maskbits"), maskbits_out=j.get("maskbits_out"))
+                for j, o in zip(norm, outs)]
     hip_lib.check(code, "larva_conv3x3_fwd_batch")
     return outs
 

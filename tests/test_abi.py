@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(hip_lib.SIGNATURES) == declared  # binding table and header agree
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.larva_abi_version() == 3
+    assert lib.larva_abi_version() == 4
     # pure host-side size helpers need no device
     def stride(c):   # cout_stride() of csrc/larva_common.h: c itself where c % 32 is 16 (or 0: swizzled rows), else c + 16
         return c if c % 32 in (0, 16) else c + 16

@@ -420,3 +420,59 @@ def test_headline_v2_train_step_against_oracle(hip_device):
         assert np.abs(ga - gb).max() <= 2e-4 * max(np.abs(gb).max(), 1e-30), k
         n += 1
     assert n == 88
+
+
+@pytest.mark.parametrize("nf", [32, 64])
+def test_train_step_at_the_timed_size_with_num_filters_32_and_64(hip_device, nf):
+    """bench.py's `other_widths` times `train_step_larva` of the M4B4 network built with --num_filters=32 / 64 on the
+    headline batch (BASELINE configs 2 / 5 read literally; a build-side extension).  Until round 4 those
+    networks were value-checked only at M2 on 4 x 3 x 12 x 16.  Here: the captured (hipGraph) step at M4B4 on
+    16 x 3 x 48 x 48 -- the flat (nf, nf) weight-gradient grid over 40 layers, the (48, nf) leg gradients, the
+    nf-channel strip chains of the DualChain -- loss and EVERY gradient element against oracle/larva_torch.py built at
+    the same width from the same seed (weights bit-identical, asserted)."""
+    from oracle import larva_torch as T
+    m = _model("LarvaNet", FLAGS + ["--num_filters=%d" % nf], training=True, seed=0)
+    assert m.use_hip_graph and m.dual_chain
+    sd = {k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()}
+    ref_sd = T.init_state_dict(BLOCKS, seed=0, nf=nf)
+    assert sorted(sd) == sorted(ref_sd) and all(torch.equal(sd[k], ref_sd[k]) for k in sd)
+    x, truth = _canonical_batch()
+    torch.set_num_threads(8)
+    ref_losses, ref_grads = T.train_steps(dict(sd), x, truth, BLOCKS, steps=1, lr=m.get_lr())
+    m.volume_per_step = 48 * 48 * 16 * 3
+    args = types.SimpleNamespace(train_path="/tmp")
+    loss = m.train_step_larva(args, FakeValLoader(7), x.to(hip_device), truth.to(hip_device))
+    assert m.use_hip_graph and m.hip_graph_fell_back is None   # the captured step ran, not an eager fall-back
+    assert abs(loss - ref_losses[0]) <= 2e-5 * abs(ref_losses[0])
+    n = 0
+    for k, p in m.model.named_parameters():
+        got, ref = p.grad.detach().cpu().numpy(), ref_grads[k].numpy()
+        assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), k
+        n += 1
+    assert n == 82
+
+
+def test_full_image_upscale_339x510_v2_with_64_filters_against_oracle(hip_device):
+    """BASELINE configs[4] read literally -- "LarvaNetV2 x4, 64ch body, full-image inference" -- is what bench.py times
+    as infer_full_image.LarvaNetV2_64ch: `upscale` of a 3 x 339 x 510 image through the --num_filters=64 V2 network
+    (wide 64-channel tiles on the pitched rows, the K = 256 merge conv over four feature tensors, the 64 -> 48 tail),
+    against oracle/larva_torch.py at that width: fp32 output, uint8 protocol, PSNR."""
+    from oracle import larva_torch as T
+    from larvanet_amd import metrics
+    m = _model("LarvaNetV2", FLAGS + ["--num_filters=64"], seed=0)
+    rng = np.random.RandomState(511)
+    img = rng.randint(0, 256, size=(3, 339, 510)).astype(np.float32)
+    got = m.upscale([img], 4)[0]
+    assert got.shape == (3, 1356, 2040)
+    sd = {k: v.detach().cpu() for k, v in m.model.state_dict().items()}
+    ref_sd = T.init_state_dict(BLOCKS, v2=True, seed=0, nf=64)
+    assert all(torch.equal(sd[k], ref_sd[k]) for k in sd)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ref = T.forward_v2(sd, torch.from_numpy(img)[None], BLOCKS)[0].numpy()
+    assert float(np.abs(got - ref).max()) <= 2e-3, float(np.abs(got - ref).max())
+    g8, r8 = metrics.image_to_uint8(got), metrics.image_to_uint8(ref)
+    diff = np.abs(g8.astype(np.int16) - r8.astype(np.int16))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+    hr = rng.randint(0, 256, size=(3, 1356, 2040)).astype(np.uint8)
+    assert abs(float(metrics.image_psnr(g8, hr)) - float(metrics.image_psnr(r8, hr))) < 1e-3

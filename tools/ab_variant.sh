@@ -1,8 +1,11 @@
 #!/bin/bash
 # Same-box A/B of a build variant (tools/build_variant.sh <name> -D...) against the product build:
 #   tools/ab_variant.sh <name>     -> two-chain epilogue chains + the training step, alternating
+set -euo pipefail
 cd "$(dirname "$0")/.."
 V=tools/_diag/$1.so
+[ -f "$V" ] || { echo "missing $V: build it first (tools/build_variant.sh)"; exit 1; }
+[ "$V" -nt larvanet_amd/csrc/conv3x3_mfma.hip ] || { echo "$V is older than conv3x3_mfma.hip: rebuild the variant"; exit 1; }
 for round in 1 2; do
   python tools/bench_epilogues.py 2>&1 | grep -v amdgpu
   LARVA_HIP_LIB=$V python tools/bench_epilogues.py 2>&1 | grep -v amdgpu

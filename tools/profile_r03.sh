@@ -2,6 +2,8 @@
 # Round-3 profiles (GPU box): kernel inventory of the step, then PMC passes -- one counter set per pass, as the guide
 # prescribes -- over the dominant conv kernels (`bench.py --roofline-only`) and the weight-gradient launch pair
 # (`bench.py --wgrad-only`).  Summaries land in gpurun_out/r03_prof/ (copy the ones to keep into profiles/).
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03_prof
