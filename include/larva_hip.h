@@ -154,10 +154,14 @@ int larva_conv3x3_fwd_batch_mb(int njobs, const float* const* src, int n_src, in
                                const float* const* res1, const float* const* mask, const float* const* base,
                                float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
                                const unsigned char* const* maskbits, unsigned char* const* maskbits_out, void* stream);
+/* larva_conv3x3_fwd_strips_mb also takes `tile_tab_host`: the HOST array larva_strip_tile_table filled (the entries of
+ * the device copy `tile_tab`), or NULL.  Given, and small enough (<= 64 tiles per image, H <= 256, pitch <= 2048), the
+ * table travels inside the kernel arguments and a workgroup finds its tile without a dependent memory round trip. */
 int larva_conv3x3_fwd_strips_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                                 const float* bias, const float* res0, const float* res1, const float* mask,
                                 const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                                int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
+                                int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
+                                int tiles_per_image, int plain_stores,
                                 const unsigned char* maskbits, unsigned char* maskbits_out, void* stream);
 
 /* Measurement only: the same launch `iters` times with kernel-attached events
@@ -166,13 +170,14 @@ int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src,
                             const float* bias, const float* res0, const float* res1, const float* mask,
                             const float* base, float* out, int N, int cout, int H, int W, int relu,
                             int mode, void* stream, int iters, float* mean_ms, float* min_ms);
-/* The same for a strip-tile launch (larva_conv3x3_fwd_strips below; same arguments): what a profiler reports for
+/* The same for a strip-tile launch (larva_conv3x3_fwd_strips + the host table of larva_conv3x3_fwd_strips_mb): what a profiler reports for
  * one half-batch launch running alone, beside bench.py's time per layer with two of them running concurrently. */
 int larva_conv3x3_fwd_strips_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                                    const float* bias, const float* res0, const float* res1, const float* mask,
                                    const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                                   int relu, int mode, const unsigned* tile_tab, int tiles_per_image,
-                                   int plain_stores, void* stream, int iters, float* mean_ms, float* min_ms);
+                                   int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
+                                   int tiles_per_image, int plain_stores, void* stream, int iters, float* mean_ms,
+                                   float* min_ms);
 
 /* ---- weight / bias gradient ---------------------------------------------------------------
  * Replaces autograd's conv weight/bias gradient for the call sites above (loss.backward(),
@@ -251,6 +256,9 @@ int larva_l1_bwd(const float* a, const float* b, const float* gout, long long nu
  * exits (models/LarvaNet.py:109) so that no separate scaling pass is needed. */
 int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, float gscale, float* ga, int N,
                             int C, int H, int W, void* stream);
+/* Measurement only: a one-lane launch that stores the 100 MHz wall clock into *dst in stream order (a capturable
+ * marker between the launches of a graph; no reference counterpart). */
+int larva_stamp_clock(unsigned long long* dst, void* stream);
 /* `loss += ...; loss / num_modules` (models/LarvaNet.py:104-109): out = (sum of n <= 8 device scalars) / divisor. */
 int larva_sum_scalars(const float* const* terms, int n, float divisor, float* out, void* stream);
 /* The same loss tail in two launches less per exit: larva_l1_partial leaves the block partial sums

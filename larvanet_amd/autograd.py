@@ -61,7 +61,7 @@ class MaskBits:
     (include/larva_hip.h: larva_conv3x3_fwd_*_mb).  h itself is still kept: the next conv and the weight gradient read it.
     LARVA_MASK_BITS=0: the fp32 mask operand (A/B timing; same results bit for bit, tested)."""
 
-    enabled = os.environ.get("LARVA_MASK_BITS", "1") != "0"
+    enabled = os.environ.get("LARVA_MASK_BITS", "0") != "0"
 
     @classmethod
     def new(cls, like, *operands):
@@ -463,6 +463,11 @@ class DeferredWgrad:
     jobs_per_launch = int(os.environ.get("LARVA_WGRAD_JOBS", "32"))
     _pending = {}   # (cout, cin) -> list of jobs (they keep dy / x / targets alive)
 
+    # (Round 4, measured and removed: the exits' eight layers issued BESIDE the backward chain as a small grid on a
+    # stream of their own -- they are complete when the chain starts, and a weight-gradient workgroup owns a whole CU.  The
+    # workgroups did get their CUs within 16 us, but every chain launch is 256 workgroups for 512 slots: with 64 CUs gone
+    # the two chains queue for slots, fall into step and run at 18.6 instead of 14.6 us per layer -- step 1.78 against
+    # 1.67 ms with 48-128 early workgroups, 1.86 with 32.  profiles/r04_ab_early_wgrad.txt, r04_step_timeline_early64.txt.)
     @classmethod
     def push(cls, cout, cin, jobs):
         cls._pending.setdefault((cout, cin), []).extend(jobs)

@@ -66,6 +66,12 @@
 // 14.9-15.4 against 14.2-14.6 us per layer, step 1.664-1.672 against 1.653-1.657 ms (same box, tools/ab_variant.sh).
 #define LARVA_TABLE_SCALAR 0
 #endif
+#ifndef LARVA_PIN_SCALARS
+#define LARVA_PIN_SCALARS 1    // 0: the epilogue's H / W / pitch / plain_stores re-loaded from the kernarg segment (A/B timing)
+#endif
+#ifndef LARVA_INLINE_TABLE
+#define LARVA_INLINE_TABLE 1   // 0: the strip kernel always looks its tile up in the device table (A/B timing)
+#endif
 #ifndef LARVA_RING_STAGES
 // Stages of the LDS-DMA ring (loader-wave path).  3 (the product): chunks c + 1 and c + 2 in flight while chunk c
 // multiplies, two workgroups per CU.  2 (experiment, with -DLARVA_WG_PER_CU=3): one chunk in flight, 40 instead of 60 KiB
@@ -188,6 +194,13 @@ struct ConvArgs {
   // for `ReLU` backward (models/LarvaNet.py:211); the predicate is the same `h > 0`.
   const unsigned char* maskbits;   // kEpiMaskBits
   unsigned char* maskbits_out;     // kEpiRelu, or null
+  // Strip kernel, round 4: ONE image's tile table inline, 16 bits per tile (y0 | (x0 / 16) << 8 | (5-row tile ? 1 << 15 : 0)),
+  // when it fits (tab_n = its entry count <= 64, H <= 256, pitch <= 2048; else tab_n = 0 and the workgroup looks its
+  // tile up in tile_tab).  It then arrives with the kernel's other arguments in the first batch of scalar loads and
+  // the entry is picked out of SGPRs: the table look-up used to be a vector load whose address needs the arguments,
+  // i.e. a second dependent memory round trip (~0.5 us) in front of every workgroup's first LDS-DMA request.
+  int tab_n;
+  alignas(64) int tab16[32];   // (two 64-byte lines of the kernarg segment: see fetch_args)
   float gval;                 // d loss / d out element = seed * (1/M) / numel
                               // (`out` may be null with this epilogue: the exit's image is not wanted)
   // ceil(2^40 / d) for d = tiles_x, tiles_y, cin_per_src / 8: the kernel's wave-uniform divisions
@@ -335,7 +348,14 @@ __device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int 
   const int s_idx = div_by_magic(chunk, a.magic_cps);
   const int c_in_src = c0 - s_idx * a.cin_per_src;
   ChunkSrc cs;
-  cs.img_ptr = a.src[s_idx] + ((size_t)n * a.cin_per_src + c_in_src) * ((size_t)a.H * a.pitch);
+  // (one source tensor -- every launch of the layer chains: src[0] came with the first batch of arguments; only a
+  // concatenated input pays the dependent kernarg load of its pointer, a scalar round trip per chunk)
+  const float* src = a.src[0];
+  if (s_idx != 0) {
+    asm volatile("" ::: "memory");   // (keeps the branch: hipcc otherwise folds it back into one unconditional indexed load)
+    src = a.src[s_idx];
+  }
+  cs.img_ptr = src + ((size_t)n * a.cin_per_src + c_in_src) * ((size_t)a.H * a.pitch);
   cs.wgt_ptr = a.wpk + (size_t)chunk * C::W_USED;
   cs.img = dma_rsrc(cs.img_ptr);
   cs.wgt = dma_rsrc(cs.wgt_ptr);
@@ -671,6 +691,15 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
                 "epilogue operands in LDS: the loader-wave path's mask / residual epilogues");
   const int lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
+  // The epilogue's scalars, PINNED in SGPRs from here on (round 4).  Left alone hipcc drops them after the prologue and
+  // re-loads each from the kernarg segment where the epilogue uses it -- H / pitch / plain_stores after the K loop and
+  // W once per (channel group, pixel group) unit, every one an s_load + s_waitcnt lgkmcnt(0) in front of that unit's
+  // stores: five dependent scalar round trips at the tail of every workgroup's life (read off the ISA of round 3's
+  // binary).  An opaque asm operand cannot be rematerialised from memory.
+  struct { int H, W, pitch, plain; } k = {a.H, a.W, a.pitch, a.plain_stores};
+#if LARVA_PIN_SCALARS
+  asm volatile("" : "+s"(k.H), "+s"(k.W), "+s"(k.pitch), "+s"(k.plain));
+#endif
 
   // Bias (added in the epilogue) and the epilogue's other operands are fetched inside the DMA
   // prologue, older than chunk 1's pieces, so the first counted wait of the ring covers them.
@@ -704,9 +733,9 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   f32x4 aux[(NAUX > 0 && !AUXLDS) ? NAUX : 1][(NAUX > 0 && !AUXLDS) ? NCT : 1][(NAUX > 0 && !AUXLDS) ? NPG : 1];
   static_assert(EPI != kEpiMaskBits || kPixMajor, "sign-bit masks: pixel-major accumulators (16-byte path) only");
   unsigned mbits[EPI == kEpiMaskBits ? NCT : 1][EPI == kEpiMaskBits ? NPG : 1];   // one byte per (c, p) unit
-  const int nxg = (a.pitch + 15) >> 4;   // 16-pixel groups per row of the sign-bit tensor
+  const int nxg = (k.pitch + 15) >> 4;   // 16-pixel groups per row of the sign-bit tensor
   auto bits_at = [&](int c, int y, int xcol) {   // byte offset of this lane's nibble of unit (channel group ct0 + c, row y, column xcol)
-    return ((((size_t)n * C::CT + (ct0 + c)) * a.H + y) * nxg + (xcol >> 4)) * 64 + lane;
+    return ((((size_t)n * C::CT + (ct0 + c)) * k.H + y) * nxg + (xcol >> 4)) * 64 + lane;
   };
   auto load_aux = [&]() {
     if constexpr (EPI == kEpiMaskBits) {
@@ -893,8 +922,8 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     // by the leg's dgrad / wgrad (models/LarvaNet.py:107-109 + autograd of :261).  sign(0) = 0 as
     // in ATen's l1 backward.  The |out - truth| sum of this wave's share goes to partial[4 tile + wave]
     // (fixed order everywhere: the loss is reproducible run to run).
-    const int HH = 4 * a.H, WW = 4 * a.W;
-    const size_t plane = (size_t)a.H * a.pitch;
+    const int HH = 4 * k.H, WW = 4 * k.W;
+    const size_t plane = (size_t)k.H * k.pitch;
     const float g = a.gval;
     float s = 0.f;
 #pragma unroll
@@ -904,14 +933,14 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
         const int y = y0 + prow, x = x0 + pcol * 16 + lr;
         const f32x4 v = (acc[c][p] + bias[c]) + aux[0][c][p];
-        if (y < a.H && x < a.W) {
+        if (y < k.H && x < k.W) {
           if (a.out) {
             const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
             __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
           }
           const f32x4 d = v - aux[1][c][p];
           s += fabsf(d[0]) + fabsf(d[1]) + fabsf(d[2]) + fabsf(d[3]);
-          const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
+          const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * k.pitch + x;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             __builtin_nontemporal_store(d[r] > 0.f ? g : (d[r] < 0.f ? -g : 0.f), &a.grad[idx0 + r * plane]);
@@ -923,7 +952,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   } else if constexpr (EPI == kEpiShuffle || EPI == kEpiShuffleBase) {
     // PixelShuffle(4): out[n, C, 4y+i, 4x+j] = conv[n, 16C + 4i + j, y, x]; here C = ct0+c,
     // i = lq, j = r -> one aligned 16-byte store per lane (models/LarvaNet.py:261,265-266).
-    const int HH = 4 * a.H, WW = 4 * a.W;
+    const int HH = 4 * k.H, WW = 4 * k.W;
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -933,30 +962,31 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
         f32x4 v = acc[c][p] + bias[c];
         if constexpr (EPI == kEpiShuffleBase) v += aux[0][c][p];
-        if (y < a.H && x < a.W) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
+        if (y < k.H && x < k.W) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
       }
   } else if constexpr (kPixMajor) {
     // Pixel-major accumulators: acc[c][p][r] = output channel (ct0+c)*16 + lr of pixel
     // (y0 + pg / PC, x0 + (pg % PC) * 16 + 4 lq + r): one 16-byte store per (c, p).  Store policy as below.
-    const size_t plane = (size_t)a.H * a.pitch;
+    const size_t plane = (size_t)k.H * k.pitch;
     auto store_all = [&](auto plain_tag) {
       constexpr bool kPlain = decltype(plain_tag)::value;
+      unsigned nib[EPI == kEpiRelu ? NCT : 1][EPI == kEpiRelu ? NPG : 1] = {};   // sign nibbles (maskbits_out)
 #pragma unroll
       for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int p = 0; p < NPG; ++p) {
           const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
           const int y = y0 + prow, xb = x0 + pcol * 16 + lq * 4;
-          size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * a.pitch + xb;
+          size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * k.pitch + xb;
           if constexpr ((LARVA_DIAG & 1024) != 0 && G::COLS == 16) {
             // timing-only ablation (results land in the wrong places): the tile's COUT x ROWS x 16 floats as ONE
             // contiguous run per workgroup -- a workgroup-contiguous ("blocked") activation layout's store side,
             // with every load left as it is: what would DESIGN 9.0 buy in the two-chain regime?  tools/ab_blocked_stores.sh
-            idx = (((size_t)n * (a.pitch / 16) + x0 / 16) * a.H + y0) * 16 * COUT +
+            idx = (((size_t)n * (k.pitch / 16) + x0 / 16) * k.H + y0) * 16 * COUT +
                   (size_t)(((ct0 + c) * 16 + lr) * G::ROWS + prow) * 16 + lq * 4;
           }
           f32x4 v = acc[c][p] + bias[c];
-          if (y < a.H && xb < a.pitch) {
+          if (y < k.H && xb < k.pitch) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float o = v[r];
@@ -971,23 +1001,40 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
                 if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
                 if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
               }
-              v[r] = (xb + r < a.W) ? o : 0.f;   // columns [W, pitch) are kept at zero for the next layer
+              v[r] = (xb + r < k.W) ? o : 0.f;   // columns [W, pitch) are kept at zero for the next layer
             }
             if constexpr (kPlain) *reinterpret_cast<f32x4*>(a.out + idx) = v;
             else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
-            if constexpr (EPI == kEpiRelu) {
-              if (a.maskbits_out) {   // (wave-uniform) the sign bits of what was just stored: `h > 0` of the ReLU backward
-                const unsigned b = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
-                a.maskbits_out[bits_at(c, y, x0 + pcol * 16)] = (unsigned char)b;
-              }
-            }
+            if constexpr (EPI == kEpiRelu)   // the sign bits of what was just stored: `h > 0` of the ReLU backward
+              nib[c][p] = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
           }
         }
+      if constexpr (EPI == kEpiRelu) {
+        if (a.maskbits_out) {   // (wave-uniform)
+          // One byte per lane, written as DWORDS: lane 4k gathers the bytes of lanes 4k .. 4k + 3 (a quad shares its
+          // pixel quad lq, hence its validity) with three quad-permute DPP moves and stores 4 bytes -- 16 dword stores
+          // of one 64-byte run per unit.  (First version: 64 byte stores per unit, +1.0-1.7 us per two-chain layer,
+          // profiles/r04_ab_maskbits.txt: sub-dword writes are what cost, not the 327 KB.)
+#pragma unroll
+          for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int p = 0; p < NPG; ++p) {
+              const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
+              const int y = y0 + prow, xb = x0 + pcol * 16 + lq * 4;
+              const int b = (int)nib[c][p];
+              const unsigned w = (unsigned)b | ((unsigned)__builtin_amdgcn_mov_dpp(b, 0x55, 0xf, 0xf, true) << 8) |
+                                 ((unsigned)__builtin_amdgcn_mov_dpp(b, 0xaa, 0xf, 0xf, true) << 16) |
+                                 ((unsigned)__builtin_amdgcn_mov_dpp(b, 0xff, 0xf, 0xf, true) << 24);
+              if ((lane & 3) == 0 && y < k.H && xb < k.pitch)
+                *reinterpret_cast<unsigned*>(a.maskbits_out + bits_at(c, y, x0 + pcol * 16)) = w;
+            }
+        }
+      }
     };
     if constexpr ((LARVA_DIAG & 16) != 0) {
       store_all(std::true_type{});
     } else if constexpr (G::COLS == 16) {
-      if (a.plain_stores) store_all(std::true_type{});
+      if (k.plain) store_all(std::true_type{});
       else store_all(std::false_type{});
     } else {
       store_all(std::false_type{});
@@ -996,11 +1043,11 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     // Output store policy.  Non-temporal for the 3 x 48 tiles: the 7 MB store burst of the 256
     // workgroups drains faster (-0.7 us per launch in a chain of whole-batch launches that writes a
     // tensor per layer: 15.3 vs 16.1 us).  The strip kernel takes the policy per launch
-    // (a.plain_stores): with two half-batch chains sharing the CUs, plain stores are 0.5 us per
+    // (k.plain): with two half-batch chains sharing the CUs, plain stores are 0.5 us per
     // layer faster in the FORWARD chain (the next layer reads the tensor at once: 14.2-14.5 ->
     // 13.75-14.0 us, forward region of the step 604 -> 581 us) and 0.6 us per layer slower in the
     // backward chain (same-box A/B of the step: 1.696 ms all-plain vs 1.688 all-non-temporal).
-    const size_t plane = (size_t)a.H * a.pitch;
+    const size_t plane = (size_t)k.H * k.pitch;
     auto store_all = [&](auto plain_tag) {
       constexpr bool kPlain = decltype(plain_tag)::value;
 #pragma unroll
@@ -1009,10 +1056,10 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         for (int p = 0; p < NPG; ++p) {
           const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
           const int y = y0 + prow, x = x0 + pcol * 16 + lr;
-          const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
+          const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * k.pitch + x;
           const f32x4 v = acc[c][p] + bias[c];
-          if (y < a.H && x < a.pitch) {
-            const bool real = x < a.W;  // columns [W, pitch) are kept at zero for the next layer
+          if (y < k.H && x < k.pitch) {
+            const bool real = x < k.W;  // columns [W, pitch) are kept at zero for the next layer
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float o = v[r];
@@ -1030,7 +1077,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     if constexpr ((LARVA_DIAG & 16) != 0) {
       store_all(std::true_type{});
     } else if constexpr (G::COLS == 16) {
-      if (a.plain_stores) store_all(std::true_type{});
+      if (k.plain) store_all(std::true_type{});
       else store_all(std::false_type{});
     } else {
       store_all(std::false_type{});
@@ -1049,7 +1096,8 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
 __device__ __forceinline__ void fetch_args(const ConvArgs& a) {
   asm volatile("" ::"s"(a.src[0]), "s"(a.wpk), "s"(a.bias), "s"(a.out), "s"(a.cin_per_src), "s"(a.n_chunks), "s"(a.N),
                "s"(a.H), "s"(a.W), "s"(a.pitch), "s"(a.tiles_x), "s"(a.tiles_y), "s"(a.magic_tx), "s"(a.magic_ty),
-               "s"(a.magic_cps), "s"(a.nwg), "s"(a.tile_tab), "s"(a.maskbits_out));
+               "s"(a.magic_cps), "s"(a.nwg), "s"(a.tile_tab), "s"(a.maskbits_out), "s"(a.plain_stores), "s"(a.tab_n),
+               "s"(a.tab16[0]), "s"(a.tab16[16]));
 }
 
 // VEC: 2 workgroups per CU (launch bound 2 waves/SIMD caps the registers at 256).
@@ -1143,12 +1191,21 @@ __global__ __launch_bounds__(320, LARVA_WG_PER_CU) void conv3x3_mfma_strip_kerne
   fetch_args(a);
   const int tile = xcd_remap(blockIdx.x, a.nwg);
   const int n = div_by_magic(tile, a.magic_tx);   // tiles_x = tiles per image
+  const int slot = tile - n * a.tiles_x;
+  unsigned e;
+  if (LARVA_INLINE_TABLE && a.tab_n) {   // (uniform)
+    // a scalar load at a computed offset of the kernarg segment, whose two table lines fetch_args has just pulled into
+    // the scalar cache with the other arguments: a cache hit instead of a vector load's trip to L2
+    const unsigned pair = (unsigned)a.tab16[slot >> 1];
+    const unsigned h = (slot & 1) ? pair >> 16 : pair & 0xffffu;
+    e = (h & 0xffu) | (((h >> 8) & 0x7fu) << 16) | ((h >> 15) << 31);   // -> y0 | x0 << 12 | five << 31
+  } else {
 #if LARVA_TABLE_SCALAR
-  const unsigned e = reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(
-      reinterpret_cast<uintptr_t>(a.tile_tab))[tile - n * a.tiles_x];
+    e = reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(reinterpret_cast<uintptr_t>(a.tile_tab))[slot];
 #else
-  const unsigned e = a.tile_tab[tile - n * a.tiles_x];
+    e = a.tile_tab[slot];
 #endif
+  }
   const int y0 = (int)(e & 0xfffu), x0 = (int)((e >> 12) & 0xfffu);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1498,6 +1555,7 @@ int larva_diag_arm_slots(int first, int cap) {
   g_diag_slot_cap = cap;
   return was;
 }
+int larva_diag_next_slot(void) { return g_diag_next_slot; }
 #endif
 
 // Fused 3x3 convolution.  `src` is an array of `n_src` device pointers (channel concatenation,
@@ -1788,7 +1846,8 @@ static int strips_dispatch(const float* const* src, int n_src, int cin_per_src, 
                            const float* bias, const float* res0, const float* res1, const float* mask,
                            const float* base, float* out, int N, int cout, int H, int W, int pitch,
                            int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
-                           void* stream, const LaunchTiming* tm, MaskBitsArg mb = MaskBitsArg{}) {
+                           void* stream, const LaunchTiming* tm, MaskBitsArg mb = MaskBitsArg{},
+                           const unsigned* tile_tab_host = nullptr) {
   if (cout != 48 && cout != 32 && cout != 64) return (int)hipErrorNotSupported;
   if (!tile_tab || tiles_per_image < 1) return (int)hipErrorInvalidValue;
   ConvArgs a;
@@ -1804,6 +1863,17 @@ static int strips_dispatch(const float* const* src, int n_src, int cin_per_src, 
     if (a.n_chunks < 2 || (long long)cout * H * pitch >= (1ll << 29)) return (int)hipErrorNotSupported;
   }
   a.tile_tab = tile_tab;
+  if (tile_tab_host && tiles_per_image <= 64 && H <= 256 && pitch <= 2048) {
+    // the same table inline in the kernel arguments, 16 bits per tile (ConvArgs::tab16)
+    a.tab_n = tiles_per_image;
+    for (int t = 0; t < tiles_per_image; ++t) {
+      const unsigned e = tile_tab_host[t];
+      const unsigned y0 = e & 0xfffu, x0 = (e >> 12) & 0xfffu;
+      if (y0 > 255u || (x0 & 15u) || (x0 >> 4) > 127u) { a.tab_n = 0; break; }
+      const unsigned h = y0 | ((x0 >> 4) << 8) | ((e >> 31) << 15);
+      a.tab16[t >> 1] |= (int)(h << ((t & 1) * 16));
+    }
+  }
   a.plain_stores = plain_stores ? 1 : 0;
   a.tiles_x = tiles_per_image;
   a.tiles_y = 1;
@@ -1826,13 +1896,18 @@ int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src
                          tile_tab, tiles_per_image, plain_stores, stream, nullptr);
 }
 
+// ... and `tile_tab_host`: the HOST array larva_strip_tile_table filled (the same entries as the device copy), or NULL.
+// Given, and small enough (<= 64 tiles, H <= 256, pitch <= 2048), the table travels inside the kernel arguments and a
+// workgroup finds its tile without a dependent memory round trip (ConvArgs::tab16).
 int larva_conv3x3_fwd_strips_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                                 const float* bias, const float* res0, const float* res1, const float* mask,
                                 const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                                int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
+                                int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
+                                int tiles_per_image, int plain_stores,
                                 const unsigned char* maskbits, unsigned char* maskbits_out, void* stream) {
   return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu, mode,
-                         tile_tab, tiles_per_image, plain_stores, stream, nullptr, MaskBitsArg{maskbits, maskbits_out});
+                         tile_tab, tiles_per_image, plain_stores, stream, nullptr, MaskBitsArg{maskbits, maskbits_out},
+                         tile_tab_host);
 }
 
 #if LARVA_DIAG & 32
@@ -1888,11 +1963,12 @@ int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src,
 int larva_conv3x3_fwd_strips_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                                    const float* bias, const float* res0, const float* res1, const float* mask,
                                    const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                                   int relu, int mode, const unsigned* tile_tab, int tiles_per_image,
-                                   int plain_stores, void* stream, int iters, float* mean_ms, float* min_ms) {
+                                   int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
+                                   int tiles_per_image, int plain_stores, void* stream, int iters, float* mean_ms,
+                                   float* min_ms) {
   return timed_launches(iters, mean_ms, min_ms, [&](const LaunchTiming* tm) {
     return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu,
-                           mode, tile_tab, tiles_per_image, plain_stores, stream, tm);
+                           mode, tile_tab, tiles_per_image, plain_stores, stream, tm, MaskBitsArg{}, tile_tab_host);
   });
 }
 

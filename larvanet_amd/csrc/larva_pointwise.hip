@@ -672,6 +672,17 @@ int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, f
   return (int)hipGetLastError();
 }
 
+// Measurement only: one lane stores the 100 MHz wall clock (s_memrealtime) into *dst, in stream order -- a capturable
+// marker between the launches of a hipGraph whose kernels must stay exactly the product's (tools/step_marks.py:
+// when does each chain of the captured step start and end?).  Costs one launch slot (~2 us) on its stream.
+__global__ void stamp_clock_kernel(unsigned long long* dst) { *dst = __builtin_amdgcn_s_memrealtime(); }
+
+int larva_stamp_clock(unsigned long long* dst, void* stream) {
+  if (!dst) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(stamp_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst);
+  return (int)hipGetLastError();
+}
+
 // out[0] = (sum of n <= 8 device scalars, added in index order) / divisor.
 int larva_sum_scalars(const float* const* terms, int n, float divisor, float* out, void* stream) {
   if (!terms || n < 1 || n > 8 || !out) return (int)hipErrorInvalidValue;

@@ -68,7 +68,30 @@ struct WgradBatch {
   WgradJob head;
   int head_units;       // 0: no head job
   int head_first_wg;    // the first workgroup whose share reaches into the head
+#if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
+  int diag_slot;        // stamp area of this launch (tools/diag_step.py), -1: none
+#endif
 };
+
+#if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
+// In-kernel timeline of the flat weight-gradient launches (with the conv kernels' own stamps, conv3x3_mfma.hip): wave 0
+// of every workgroup writes the 100 MHz wall clock at entry and before it ends, and its HW_ID | XCC_ID << 32, into
+// g_wstamps[(slot * 256 + workgroup) * 4 + {0, 1, 2}].
+__device__ unsigned long long* g_wstamps = nullptr;
+__device__ __forceinline__ void wstamp(int slot, int k) {
+  if (!g_wstamps || threadIdx.x != 0 || slot < 0 || blockIdx.x >= 256) return;
+  unsigned long long* p = g_wstamps + ((size_t)slot * 256 + blockIdx.x) * 4;
+  p[k] = __builtin_amdgcn_s_memrealtime();
+  if (k == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    p[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
+}
+#define WSTAMP(b, k) wstamp((b).diag_slot, (k))
+#else
+#define WSTAMP(b, k) ((void)0)
+#endif
 
 // A (48, 16) tile on the register-staged role against a (48, 48) tile on the pipelined one: a third of the MFMAs,
 // but two workgroup barriers and an exposed LDS write per tile -- measured 0.58 of the time (same-box builds with
@@ -755,6 +778,7 @@ template <int COUT, int CIN>
 __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_flat_kernel(WgradBatch b) {
   using C = WgCfg<COUT, CIN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  WSTAMP(b, 0);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w = blockIdx.x, nwg = gridDim.x;
@@ -790,6 +814,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_flat_kernel(WgradBatch b
     else if (wave == 2) wg_role_range<COUT, 16, true, W0 + W1, W2>(b, b.head, smem, h_begin, h_end, part, tid, false);
     else wg_role_range<COUT, 16, true, W0 + W1 + W2, W3>(b, b.head, smem, h_begin, h_end, part, tid, false);
   }
+#if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WSTAMP(b, 1);
+#endif
 }
 
 // Workgroups per CU of the register-staged kernel.  Its tile loop is "stage (global loads -> LDS, two barriers), then
@@ -1035,6 +1064,9 @@ int larva_wgrad_flat_max_splits(int njobs, int nwg, int tiles_per_layer) {
 
 int larva_wgrad_flat_head_splits(int njobs, int nwg, int tiles_per_layer);
 
+#if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
+static int g_wdiag_next = -1, g_wdiag_cap = 0;
+#endif
 static int wgrad_flat_impl(const float* const* dy, const float* const* x, float* const* partial, int njobs,
                            const float* head_dy, const float* head_x16, float* head_partial, int nwg, int N, int cout,
                            int cin, int H, int W, int* splits_out, int* head_splits_out, void* stream) {
@@ -1083,9 +1115,26 @@ static int wgrad_flat_impl(const float* const* dy, const float* const* x, float*
     *head_splits_out = nwg - w;
     if (*head_splits_out > larva_wgrad_flat_head_splits(njobs, nwg, (int)total)) return (int)hipErrorInvalidValue;
   }
+#if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
+  b.diag_slot = (g_wdiag_next >= 0 && g_wdiag_next < g_wdiag_cap) ? g_wdiag_next++ : -1;
+#endif
   if (cout == 32) return (int)launch_wgrad_flat<32, 32>(b, nwg, (hipStream_t)stream);
   return (int)launch_wgrad_flat<48, 48>(b, nwg, (hipStream_t)stream);
 }
+
+#if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
+int larva_diag_set_wgrad_stamps(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(larva::g_wstamps), &buf, sizeof(buf));
+}
+// flat weight-gradient launches built from now on take slots first, first + 1, ... < cap (first < 0: off); returns
+// the slot the next launch would have taken
+int larva_diag_arm_wgrad_slots(int first, int cap) {
+  const int was = g_wdiag_next;
+  g_wdiag_next = first;
+  g_wdiag_cap = cap;
+  return was;
+}
+#endif
 
 int larva_conv3x3_wgrad_partial_flat(const float* const* dy, const float* const* x, float* const* partial,
                                      int njobs, int nwg, int N, int cout, int cin, int H, int W,

@@ -49,8 +49,8 @@ SIGNATURES = {
                                                    _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                                   ctypes.c_void_p]),
+                                                   ctypes.POINTER(ctypes.c_uint), ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "larva_head_conv3_direct": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_exit_l1_partials": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -68,7 +68,8 @@ SIGNATURES = {
                                                       _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                      ctypes.POINTER(ctypes.c_uint), ctypes.c_int, ctypes.c_int,
+                                                      ctypes.c_void_p, ctypes.c_int,
                                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "larva_conv3x3_fwd_timed": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
                                                _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
@@ -124,6 +125,7 @@ SIGNATURES = {
     "larva_host_cell_free": (ctypes.c_int, [_c_float_p]),
     "larva_loss_from_partials": (ctypes.c_int, [_c_pp, _c_int_p, _c_float_p, ctypes.c_int, ctypes.c_float,
                                                 _c_float_p, ctypes.c_void_p]),
+    "larva_stamp_clock": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "larva_sum_scalars": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_void_p]),
     "larva_pixel_unshuffle4": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

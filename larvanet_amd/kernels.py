@@ -89,6 +89,7 @@ def pack_weights_batch(jobs):
 
 
 _STRIP_TABLES = {}
+INLINE_TILE_TABLE = os.environ.get("LARVA_INLINE_TABLE", "1") != "0"   # A/B: 0 = always the device table
 
 
 def strip_tile_table(H, P, device, phase=0):
@@ -109,8 +110,9 @@ def strip_tile_table(H, P, device, phase=0):
                 raise RuntimeError("larvanet_amd: strip-tile table for %dx%d requested during stream capture "
                                    "(run the step once outside the capture first)" % (H, P))
             import numpy as np
-            # (entries use bit 31: the raw 32-bit patterns travel as int32)
-            hit = (torch.from_numpy(np.frombuffer(buf, dtype=np.int32, count=n).copy()).to(device), n)
+            # (entries use bit 31: the raw 32-bit patterns travel as int32); the host array is kept: the launch passes
+            # it along, and small tables then travel inside the kernel arguments (larva_conv3x3_fwd_strips_mb)
+            hit = (torch.from_numpy(np.frombuffer(buf, dtype=np.int32, count=n).copy()).to(device), n, buf)
         _STRIP_TABLES[key] = hit
     return hit or None
 
@@ -233,11 +235,8 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     if strips and cout in (48, 32, 64):
         tab = strip_tile_table(H, P, out.device, phase=1 if strips == 2 else 0)
         if tab is not None:
-            if use_bits:
-                code = lib.larva_conv3x3_fwd_strips_mb(*args, tab[0].data_ptr(), tab[1], 1 if plain_stores else 0,
-                                                       bits_in, bits_out, _stream())
-            else:
-                code = lib.larva_conv3x3_fwd_strips(*args, tab[0].data_ptr(), tab[1], 1 if plain_stores else 0, _stream())
+            code = lib.larva_conv3x3_fwd_strips_mb(*args, tab[0].data_ptr(), tab[2] if INLINE_TILE_TABLE else None, tab[1],
+                                                   1 if plain_stores else 0, bits_in, bits_out, _stream())
             if code != 801:   # hipErrorNotSupported: unaligned operands -> the regular tiles below
                 hip_lib.check(code, "larva_conv3x3_fwd_strips")
                 return out
@@ -402,7 +401,8 @@ def conv3x3_strips_timed(x, wpk, cout, bias, out, iters, images=None, phase=0, r
     code = lib.larva_conv3x3_fwd_strips_timed(
         hip_lib.ptr_array([x.data_ptr() + 4 * lo * cin * H * W]), 1, cin, wpk.data_ptr(), _opt(bias, "bias", (cout,)),
         at(res0, "res0"), at(res1, "res1"), at(mask, "mask"), None, out.data_ptr() + 4 * lo * cout * H * W, hi - lo, cout, H, W, W,
-        1 if relu else 0, 0, tab[0].data_ptr(), tab[1], 1 if plain_stores else 0, _stream(), iters, ctypes.byref(mean),
+        1 if relu else 0, 0, tab[0].data_ptr(), tab[2] if INLINE_TILE_TABLE else None, tab[1], 1 if plain_stores else 0,
+        _stream(), iters, ctypes.byref(mean),
         ctypes.byref(best))
     hip_lib.check(code, "larva_conv3x3_fwd_strips_timed")
     return float(mean.value), float(best.value)

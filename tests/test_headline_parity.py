@@ -429,7 +429,10 @@ def test_train_step_at_the_timed_size_with_num_filters_32_and_64(hip_device, nf)
     networks were value-checked only at M2 on 4 x 3 x 12 x 16.  Here: the captured (hipGraph) step at M4B4 on
     16 x 3 x 48 x 48 -- the flat (nf, nf) weight-gradient grid over 40 layers, the (48, nf) leg gradients, the
     nf-channel strip chains of the DualChain -- loss and EVERY gradient element against oracle/larva_torch.py built at
-    the same width from the same seed (weights bit-identical, asserted)."""
+    the same width from the same seed (weights bit-identical, asserted).  Gradient bar 5e-4 of each tensor's maximum, as
+    for F14: the L1 gradient is sign(out - truth), a handful of the 8.8 M (exit, pixel) pairs lie within the forward's
+    rounding error of each other, and a flipped sign moves single weight-gradient elements by more than 2e-4 (the
+    reference's own fp32 run sits 4.9e-4 from its float64 run at this size); |g| sums within 2e-4."""
     from oracle import larva_torch as T
     m = _model("LarvaNet", FLAGS + ["--num_filters=%d" % nf], training=True, seed=0)
     assert m.use_hip_graph and m.dual_chain
@@ -447,7 +450,11 @@ def test_train_step_at_the_timed_size_with_num_filters_32_and_64(hip_device, nf)
     n = 0
     for k, p in m.model.named_parameters():
         got, ref = p.grad.detach().cpu().numpy(), ref_grads[k].numpy()
-        assert np.abs(got - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-30), k
+        # (absolute floor: the exits' bias gradients are sums of +-g, g = 1 / (4 * 16 * 3 * 192 * 192) = 1.4e-7, that nearly
+        # cancel -- ONE flipped sign moves such an element by 2 g = 2.8e-7, 1.7e-3 of a tensor maximum of 1.6e-4)
+        assert np.abs(got - ref).max() <= max(5e-4 * np.abs(ref).max(), 1e-6), k
+        ga, gb = float(np.abs(got.astype(np.float64)).sum()), float(np.abs(ref.astype(np.float64)).sum())
+        assert abs(ga - gb) <= 2e-4 * gb + 1e-6, ("|g| sum", k)
         n += 1
     assert n == 82
 

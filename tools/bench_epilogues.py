@@ -26,9 +26,18 @@ streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 HALVES = [(0, 8), (8, 16)]
 
 
+BITS = [K.new_maskbits(acts[0]) for _ in range(LAYERS)]
+
+
 def operands(kind, i):
     if kind == "relu":
         return {"relu": True}
+    if kind == "plain":         # no epilogue operand, non-temporal stores: the floor of the mask / residual links
+        return {}
+    if kind == "relu+bits":     # the producer of round 4's sign bits
+        return {"relu": True, "maskbits_out": BITS[i]}
+    if kind == "maskbits":      # the ReLU-backward mask as sign bits
+        return {"maskbits": BITS[(i + 3) % LAYERS]}
     if kind == "mask":
         return {"mask": acts[(i + 3) % LAYERS]}
     if kind == "res0":
@@ -44,7 +53,7 @@ def epilogue_chain(kind):
         with torch.cuda.stream(st):
             for i in range(LAYERS):
                 K.conv3x3(acts[i], wpks[i], C, bias=b, out=acts[i + 1], images=rng, strips=2 if k else True,
-                          plain_stores=kind == "relu", **operands(kind, i))
+                          plain_stores=kind.startswith("relu"), **operands(kind, i))
     for k in range(2):
         cur.wait_stream(streams[k])
 
@@ -75,11 +84,14 @@ def timed(fn, reps=20):
 
 
 print("lib: %s   channels: %d" % (os.environ.get("LARVA_HIP_LIB", "default"), C))
-for kind in ("relu", "mask", "res0", "res2"):
+for kind in ("relu", "relu+bits", "plain", "mask", "maskbits", "res0", "res2"):
     kw = operands(kind, 0)
-    K.conv3x3_strips_timed(acts[0], wpks[0], C, b, acts[1], 5, images=(0, 8), **kw)
-    mean, best = K.conv3x3_strips_timed(acts[0], wpks[0], C, b, acts[1], 100, images=(0, 8), **kw)
+    if "bits" in kind:          # (no kernel-attached timing entry for the *_mb launches: rocprofv3 --kernel-trace has it)
+        mean = best = float("nan")
+    else:
+        K.conv3x3_strips_timed(acts[0], wpks[0], C, b, acts[1], 5, images=(0, 8), **kw)
+        mean, best = K.conv3x3_strips_timed(acts[0], wpks[0], C, b, acts[1], 100, images=(0, 8), **kw)
     for a in acts[1:]:
         a.copy_(acts[0])
     chain = timed(graphed(lambda: epilogue_chain(kind)))
-    print("  %-5s  alone: mean %.2f us  min %.2f us     two chains, every link: %.2f us per full-batch layer" % (kind, mean * 1e3, best * 1e3, chain))
+    print("  %-9s  alone: mean %.2f us  min %.2f us     two chains, every link: %.2f us per full-batch layer" % (kind, mean * 1e3, best * 1e3, chain))
