@@ -875,14 +875,16 @@ def main():
         line["rccl_ranks"] = td.get_world_size() if td.get_backend() == "nccl" else 0
         line["dist_backend"] = td.get_backend()
         line["allreduce_exposed_us"] = exposed
+        line["dp_schedule"] = model.dp_schedule   # isolated all-reduce time measured at prepare() and the schedule it chose
         if getattr(timed_rounds, "per_rank", None):
             # every rank's own ms_per_step (median round): a straggler or an exposed collective shows here
             per = [float(np.median([s / a.steps * 1e3 for s in r])) for r in timed_rounds.per_rank]
             line["ms_per_step_per_rank"] = {"min": min(per), "max": max(per), "ranks": per}
-        line["wgrad_schedule"] = ("data parallel: the deferred weight gradients go out as two launch groups (the layers of the "
-                                  "bucket's upper ~80 %, then the rest + the head), so that the first group's slice is all-reduced "
-                                  "beside the second group's kernels; `dp_schedule_1gpu` in the N = 1 line prices that schedule "
-                                  "without collectives")
+        line["wgrad_schedule"] = ("data parallel, chosen at prepare() from a timed isolated all-reduce of the bucket (`dp_schedule`): "
+                                  "`split` = the deferred weight gradients go out as two launch groups (the layers of the bucket's "
+                                  "upper ~80 %, then the rest + the head) so that the first group's slice is all-reduced beside the "
+                                  "second group's kernels (`dp_schedule_1gpu` in the N = 1 line prices that schedule without "
+                                  "collectives); `flat` = the single-GPU step's one grid + ONE collective after backward")
 
     # the whole step against the fp32 matrix peak: the only fraction tied to the driver-timed number
     flop_step = (2 * sum(BLOCKS) + 2 * len(BLOCKS)) * 3 * conv_flop(CH) + 2 * (2 * 9 * 3 * CH * BATCH * PATCH * PATCH)

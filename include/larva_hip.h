@@ -143,12 +143,16 @@ int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src
  * fusion: the launch also writes the bits of its output) and `maskbits` (relu = 0, mask = res0 = res1 = NULL: the
  * ReLU-backward mask given as bits); both NULL = the namesake.  Same predicate, bit-identical results.  16-byte
  * staging path only (hipErrorNotSupported otherwise: the caller then passes the fp32 mask). */
+/* tile_rows (larva_conv3x3_fwd_pitched_mb): 0 = the library picks the height of the 48-column tiles -- 3 rows, or 4
+ * for large 32-channel launches (339 x 510: 32.9 instead of 39.1 us per layer; 16-byte path, the epilogues of an
+ * inference forward; at 48 channels the two heights measure the same and 3 stays) -- as every other entry point
+ * does; 3 / 4 = that height (4 where it does not exist: hipErrorNotSupported).  Same results bit for bit. */
 long long larva_maskbits_bytes(int N, int cout, int H, int pitch);
 int larva_conv3x3_fwd_pitched_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                                  const float* bias, const float* res0, const float* res1, const float* mask,
                                  const float* base, float* out, int N, int cout, int H, int W, int pitch,
                                  int relu, int mode, const unsigned char* maskbits, unsigned char* maskbits_out,
-                                 void* stream);
+                                 int tile_rows, void* stream);
 int larva_conv3x3_fwd_batch_mb(int njobs, const float* const* src, int n_src, int cin_per_src,
                                const float* const* wpk, const float* const* bias, const float* const* res0,
                                const float* const* res1, const float* const* mask, const float* const* base,

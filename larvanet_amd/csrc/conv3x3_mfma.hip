@@ -159,6 +159,10 @@ struct TileGeo {
   static_assert(COLS % 16 == 0 && PS >= HALO * RS && PS % 32 == 16, "tile geometry");
 };
 using GeoWide = TileGeo<kTileRows, kTileCols>;
+// 4 x 48 (round 4): 12 pixel groups, 36 (cout group x pixel group) units at 48 channels = 9 / 9 / 9 / 9 over the four
+// waves, 24 = 6 / 6 / 6 / 6 at 32 channels.  The host picks the height per launch (conv_tile_rows: what was measured);
+// results are bit-identical (an output pixel's K loop does not depend on its tile).
+using GeoWide4 = TileGeo<4, kTileCols>;
 using GeoS5 = TileGeo<5, 16>;
 using GeoS4 = TileGeo<4, 16>;
 static_assert(GeoWide::RS == kRS && GeoWide::PS == 304, "the 3 x 48 tile of larva_common.h");
@@ -1101,9 +1105,8 @@ __device__ __forceinline__ void fetch_args(const ConvArgs& a) {
 }
 
 // VEC: 2 workgroups per CU (launch bound 2 waves/SIMD caps the registers at 256).
-template <int COUT, bool VEC, int EPI>
+template <int COUT, bool VEC, int EPI, typename G = GeoWide>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
-  using G = GeoWide;
   if constexpr ((LARVA_DIAG & 8) != 0) return;
   stamp(0);
   fetch_args(a);
@@ -1125,9 +1128,18 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
       return;
     }
   }
-  // 9 pixel groups x CT cout groups, dealt to the 4 waves (one per SIMD) as evenly as a
+  // ROWS * 3 pixel groups x CT cout groups, dealt to the 4 waves (one per SIMD) as evenly as a
   // rectangular (cout groups) x (pixel groups) ownership allows.
-  if constexpr (COUT == 48) {  // 27 -> 7,7,7,6
+  if constexpr (G::ROWS == 4) {
+    static_assert(VEC && (COUT == 48 || COUT == 32), "4 x 48 tiles: the 16-byte path at 48 / 32 channels");
+    if constexpr (COUT == 48) {  // 36 -> 9,9,9,9
+      if (wave < 3) run_role<COUT, G, VEC, EPI, 1, 0, 9>(a, smem, wave, wave, n, y0, x0, tid);
+      else run_role<COUT, G, VEC, EPI, 3, 9, 3>(a, smem, 0, wave, n, y0, x0, tid);
+    } else {                     // 24 -> 6,6,6,6
+      if (wave < 2) run_role<COUT, G, VEC, EPI, 1, 0, 6>(a, smem, wave, wave, n, y0, x0, tid);
+      else run_role<COUT, G, VEC, EPI, 1, 6, 6>(a, smem, wave - 2, wave, n, y0, x0, tid);
+    }
+  } else if constexpr (COUT == 48) {  // 27 -> 7,7,7,6
     if (wave < 3) run_role<COUT, G, VEC, EPI, 1, 0, 7>(a, smem, wave, wave, n, y0, x0, tid);
     else run_role<COUT, G, VEC, EPI, 3, 7, 2>(a, smem, 0, wave, n, y0, x0, tid);
   } else if constexpr (COUT == 32) {  // 18 -> 5,5,4,4
@@ -1144,6 +1156,14 @@ __global__ __launch_bounds__(VEC ? ConvCfg<COUT>::THREADS_DMA : 256, VEC ? LARVA
   extern __shared__ __attribute__((aligned(16))) float smem[];
   conv_tile<COUT, VEC, EPI>(a, smem);
 }
+
+// the same launch on 4 x 48 tiles (16-byte path, 48 / 32 channels)
+template <int COUT, int EPI>
+__global__ __launch_bounds__((ConvCfg<COUT, GeoWide4>::THREADS_DMA), LARVA_WG_PER_CU) void conv3x3_mfma_rows4_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv_tile<COUT, true, EPI, GeoWide4>(a, smem);
+}
+static_assert(2 * ConvCfg<48, GeoWide4>::LDS_BYTES_DMA <= 160 * 1024, "two 4 x 48 workgroups per CU");
 
 // Strip tiles (48 output channels, LDS-DMA path): every workgroup looks its tile up in a table of
 // ONE image's tiles -- 5 x 16 or 4 x 16 pixels -- and runs the matching instantiation.  ROWS pixel
@@ -1384,6 +1404,40 @@ static hipError_t launch_conv_e(const ConvArgs& a, hipStream_t stream, const Lau
   else
     hipLaunchKernelGGL((conv3x3_mfma_kernel<COUT, VEC, EPI>), dim3(grid), dim3(threads), lds, stream, a);
   return hipGetLastError();
+}
+
+template <int COUT, int EPI>
+static hipError_t launch_rows4_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
+  using C = ConvCfg<COUT, GeoWide4>;
+  constexpr size_t lds = C::LDS_BYTES_DMA;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_rows4_kernel<COUT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (tm)
+    hipExtLaunchKernelGGL((conv3x3_mfma_rows4_kernel<COUT, EPI>), dim3(a.nwg), dim3(C::THREADS_DMA), lds, stream,
+                          tm->start, tm->stop, 0, a);
+  else
+    hipLaunchKernelGGL((conv3x3_mfma_rows4_kernel<COUT, EPI>), dim3(a.nwg), dim3(C::THREADS_DMA), lds, stream, a);
+  return hipGetLastError();
+}
+
+// 4 x 48 tiles exist for the epilogues of an inference forward (head, conv + ReLU, the two residual forms, the
+// pixel-shuffle exits); anything else: hipErrorNotSupported, the caller launches the 3 x 48 tiles
+template <int COUT>
+static hipError_t launch_rows4(const ConvArgs& a, int epi, hipStream_t stream, const LaunchTiming* tm) {
+  switch (epi) {
+    case kEpiPlain: return launch_rows4_e<COUT, kEpiPlain>(a, stream, tm);
+    case kEpiRelu: return launch_rows4_e<COUT, kEpiRelu>(a, stream, tm);
+    case kEpiRes1: return launch_rows4_e<COUT, kEpiRes1>(a, stream, tm);
+    case kEpiRes2: return launch_rows4_e<COUT, kEpiRes2>(a, stream, tm);
+    case kEpiShuffle: return launch_rows4_e<COUT, kEpiShuffle>(a, stream, tm);
+    case kEpiShuffleBase: return launch_rows4_e<COUT, kEpiShuffleBase>(a, stream, tm);
+    default: return hipErrorNotSupported;
+  }
 }
 
 template <int COUT, bool VEC>
@@ -1631,10 +1685,25 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
   return 0;
 }
 
+// Tile height of a whole-tensor launch: 3 (the tile every shape has) or 4 (16-byte path, 48 / 32 channels, inference
+// epilogues).  Measured on a 339 x 510 image (tools/ab_tile_rows.py, profiles/r04_ab_tile_rows.txt): at 32 channels
+// 4 x 48 tiles take 32.9 instead of 39.1 us per layer (0.62 against 0.52 of the matrix peak: the short K loop of a
+// 32-channel layer amortises its prologue / epilogue over 6 instead of 4-5 MFMAs per k-step and wave); at 48 channels
+// 65.1 against 64.0 us -- the "fewer rounds" argument (935 instead of 1243 tiles) does not hold, workgroups are placed
+// as slots free up, not in rounds.  So: 4 rows for 32-channel launches of more than one round's worth of tiles.
+static int conv_tile_rows(int N, int H, int pitch, int cout, int epi, bool aligned, int forced) {
+  const bool can4 = aligned && LARVA_PIXEL_MAJOR && (cout == 48 || cout == 32) &&
+                    (epi == kEpiPlain || epi == kEpiRelu || epi == kEpiRes1 || epi == kEpiRes2 || epi == kEpiShuffle || epi == kEpiShuffleBase);
+  if (forced == 3 || !can4) return 3;
+  if (forced == 4) return 4;
+  const long long tiles3 = (long long)N * ((pitch + kTileCols - 1) / kTileCols) * ((H + 2) / 3);
+  return (cout == 32 && tiles3 > 512) ? 4 : 3;
+}
+
 static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                          const float* bias, const float* res0, const float* res1, const float* mask,
                          const float* base, float* out, int N, int cout, int H, int W, int pitch, int relu,
-                         int mode, void* stream, const LaunchTiming* tm, MaskBitsArg mb = MaskBitsArg{}) {
+                         int mode, void* stream, const LaunchTiming* tm, MaskBitsArg mb = MaskBitsArg{}, int tile_rows = 0) {
   ConvArgs a;
   bool aligned;
   int epi;
@@ -1642,6 +1711,17 @@ static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, co
                             mode, a, aligned, epi, mb);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (tile_rows != 0 && tile_rows != 3 && tile_rows != 4) return (int)hipErrorInvalidValue;
+  if (!mb.in && !mb.out && conv_tile_rows(N, H, a.pitch, cout, epi, aligned, tile_rows) == 4) {
+    a.tiles_y = (H + 3) / 4;
+    a.magic_ty = div_magic(a.tiles_y);
+    a.nwg = N * a.tiles_x * a.tiles_y;
+#if !LARVA_DIAG_ONLY48
+    if (cout == 32) return (int)launch_rows4<32>(a, epi, s, tm);
+#endif
+    return (int)launch_rows4<48>(a, epi, s, tm);
+  }
+  if (tile_rows == 4) return (int)hipErrorNotSupported;
   switch (cout) {
 #if !LARVA_DIAG_ONLY48
     case 32: return (int)launch_conv<32>(a, aligned, epi, s, tm);
@@ -1687,9 +1767,9 @@ int larva_conv3x3_fwd_pitched_mb(const float* const* src, int n_src, int cin_per
                                  const float* bias, const float* res0, const float* res1, const float* mask,
                                  const float* base, float* out, int N, int cout, int H, int W, int pitch,
                                  int relu, int mode, const unsigned char* maskbits, unsigned char* maskbits_out,
-                                 void* stream) {
+                                 int tile_rows, void* stream) {
   return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch,
-                       relu, mode, stream, nullptr, MaskBitsArg{maskbits, maskbits_out});
+                       relu, mode, stream, nullptr, MaskBitsArg{maskbits, maskbits_out}, tile_rows);
 }
 
 // njobs (2..4) INDEPENDENT convolutions of one shape and one fusion in ONE launch (their workgroups

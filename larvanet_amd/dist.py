@@ -76,6 +76,33 @@ def allreduce_sum(t, async_op=False):
     return td.all_reduce(t, op=td.ReduceOp.SUM, async_op=async_op)
 
 
+def time_allreduce_us(flat, warmup=3, iters=10):
+    """Median wall time (us) of an ISOLATED sum all-reduce of `flat` (the gradient bucket), agreed on by all ranks
+    (MAX over ranks): what the training step would wait for if it issued ONE collective after backward.  The buffer's
+    contents are restored.  Used once at prepare() to choose the data-parallel weight-gradient schedule."""
+    if world_size() == 1:
+        return 0.0
+    import time
+    keep = flat.clone()
+    cuda = flat.is_cuda
+    times = []
+    for i in range(warmup + iters):
+        if cuda:
+            torch.cuda.synchronize()
+        td.barrier()
+        t0 = time.perf_counter()
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        if cuda:
+            torch.cuda.synchronize()
+        if i >= warmup:
+            times.append((time.perf_counter() - t0) * 1e6)
+        flat.copy_(keep)
+    med = sorted(times)[len(times) // 2]
+    t = torch.tensor([med], dtype=torch.float64, device=flat.device if td.get_backend() == "nccl" else "cpu")
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t.item())
+
+
 def allreduce_gradients(module, bucket=None):
     """Mean of the gradients over ranks as ONE collective.  With a GradBucket the gradients already
     live in one flat buffer (no flatten / unflatten copies); otherwise they are flattened here."""

@@ -40,7 +40,7 @@ SIGNATURES = {
                                                     _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                    ctypes.c_void_p, ctypes.c_void_p]),
+                                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "larva_conv3x3_fwd_batch_mb": (ctypes.c_int, [ctypes.c_int, _c_pp, ctypes.c_int, ctypes.c_int, _c_pp, _c_pp, _c_pp, _c_pp,
                                                   _c_pp, _c_pp, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_pp, _c_pp,

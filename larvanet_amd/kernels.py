@@ -175,7 +175,7 @@ def _chk_bits(t, name, N, cout, H, P):
 
 def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=None,
             shuffle=False, base=None, out=None, logical_w=None, images=None, strips=False, plain_stores=False,
-            maskbits=None, maskbits_out=None):
+            maskbits=None, maskbits_out=None, tile_rows=0):
     """Fused 3x3 conv over the channel concatenation of `srcs` (list of [N][c][H][P]).
 
     shuffle=False: returns [N][cout][H][P]; shuffle=True: returns PixelShuffle(4) layout
@@ -189,7 +189,9 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     the strip launch writes its output with plain instead of non-temporal stores.
     maskbits_out (with relu=True): the launch also writes the sign bits of its output (new_maskbits());
     maskbits: the ReLU-backward mask given as those bits instead of `mask` (same result bit for bit).  Both need
-    maskbits_ok() operands (the 16-byte staging path) and raise otherwise."""
+    maskbits_ok() operands (the 16-byte staging path) and raise otherwise.
+    tile_rows: 0 = the library picks 3 x 48 or 4 x 48 tiles for a whole-tensor launch (fewer rounds of resident
+    workgroups on large images), 3 / 4 = that height (tests, A/B timing)."""
     lib = hip_lib.load()
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
@@ -240,8 +242,8 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
             if code != 801:   # hipErrorNotSupported: unaligned operands -> the regular tiles below
                 hip_lib.check(code, "larva_conv3x3_fwd_strips")
                 return out
-    if use_bits:   # (unaligned operands: hipErrorNotSupported is raised -- callers ask maskbits_ok() first)
-        code = lib.larva_conv3x3_fwd_pitched_mb(*args, bits_in, bits_out, _stream())
+    if use_bits or tile_rows:   # (unaligned operands: hipErrorNotSupported is raised -- callers ask maskbits_ok() first)
+        code = lib.larva_conv3x3_fwd_pitched_mb(*args, bits_in, bits_out, int(tile_rows), _stream())
     else:
         code = lib.larva_conv3x3_fwd_pitched(*args, _stream())
     hip_lib.check(code, "larva_conv3x3_fwd")

@@ -272,8 +272,10 @@ class LarvaNet(BaseModel):
         self.batch_exits = os.environ.get("LARVA_BATCH_EXITS", "1") != "0"
         # the exits' L1 gradient is written by the forward sweep that computes the L1 value
         self.l1_grad_in_forward = os.environ.get("LARVA_L1_GRAD_FWD", "1") != "0"
-        # data parallel: all-reduce the first half of the bucket beside the second half's wgrad kernels
-        self.overlap_allreduce = os.environ.get("LARVA_OVERLAP_ALLREDUCE", "1") != "0"
+        # data parallel: all-reduce the first half of the bucket beside the second half's wgrad kernels.  "auto" (the
+        # default): decided once at prepare() from a timed isolated all-reduce of the bucket (_choose_dp_schedule)
+        self.overlap_allreduce = {"0": False, "1": True}.get(os.environ.get("LARVA_OVERLAP_ALLREDUCE", "auto"), "auto")
+        self.dp_schedule = None   # what _choose_dp_schedule measured and chose (bench.py prints it)
         # the body chain as two half-batch chains of strip-tile launches on two streams (autograd.DualChain)
         self.dual_chain = os.environ.get("LARVA_DUAL_CHAIN", "1") != "0"
         # measurement: run the data-parallel step's weight-gradient schedule (two launch groups, so that the first
@@ -349,10 +351,40 @@ class LarvaNet(BaseModel):
                 self.model.invalidate_packed_weights()
                 self.grad_bucket = GradBucket(self.model, self.model.packed_convs())
                 self.optim = FlatAdamW(params, flat, self.grad_bucket, lr=self.args.lr)
+                self._choose_dp_schedule()
             else:
                 self.grad_bucket = None
                 self.optim = torch.optim.AdamW(params, lr=self.args.lr)
             self.scheduler = self._make_scheduler()
+
+    # Splitting the weight gradients into two launch groups so that the first group's slice of the bucket (its upper
+    # ~80 %) can be all-reduced beside the second group's kernels costs a rank a fixed ~36 us per step (two grids + two
+    # reductions instead of one flat grid: bench.py's dp_schedule_1gpu, 1.683 against 1.647 ms) and hides at most the
+    # first slice's collective under the second group's ~140 us.  With ONE collective after backward the step waits
+    # T for it; with the split it waits about 36 + 0.2 T + max(0, 0.8 T - 140).  The split pays for 0.8 T > 36, i.e.
+    # T > 45 us if the overlap were perfect; it is not (RCCL's kernels take CUs from the weight-gradient grid), so the
+    # rule keeps a factor of two: split when the isolated all-reduce of the bucket takes more than 90 us.
+    DP_SPLIT_ABOVE_US = 90.0
+
+    def _choose_dp_schedule(self):
+        """LARVA_OVERLAP_ALLREDUCE=auto: time the bucket's all-reduce once and pick the schedule."""
+        ws = ldist.world_size()
+        if self.overlap_allreduce != "auto":
+            self.dp_schedule = {"choice": "split" if self.overlap_allreduce else "flat", "why": "LARVA_OVERLAP_ALLREDUCE"}
+            return
+        if ws == 1:
+            self.overlap_allreduce = True     # (only consulted with more than one rank, or by LARVA_FORCE_SPLIT)
+            self.dp_schedule = {"choice": "flat", "why": "one rank"}
+            return
+        t_us = ldist.time_allreduce_us(self.grad_bucket.flat)
+        self.overlap_allreduce = t_us > self.DP_SPLIT_ABOVE_US
+        self.dp_schedule = {"choice": "split" if self.overlap_allreduce else "flat", "allreduce_isolated_us": t_us,
+                            "bucket_bytes": int(self.grad_bucket.flat.numel()) * 4, "ranks": ws,
+                            "rule": "split (two weight-gradient launch groups, the first slice all-reduced beside the second) "
+                                    "when the isolated all-reduce of the bucket takes more than %.0f us" % self.DP_SPLIT_ABOVE_US}
+        if ldist.is_main():
+            print("data-parallel weight-gradient schedule: %s (isolated all-reduce of the %.2f MB bucket over %d ranks: %.1f us)"
+                  % (self.dp_schedule["choice"], self.dp_schedule["bucket_bytes"] / 1e6, ws, t_us))
 
     # ------------------------------------------------------------------ training
     def _grad_one(self, loss):

@@ -56,6 +56,11 @@ def _worker(rank, world, port, q, backend="gloo"):
             m.parse_args(["--num_modules=2", "--num_blocks=2,1"])
             torch.manual_seed(7)
             m.prepare(is_training=True, scales=[4])
+            # prepare() timed the bucket's isolated all-reduce and chose a schedule from it (LARVA_OVERLAP_ALLREDUCE=auto)
+            assert m.dp_schedule["choice"] in ("split", "flat") and m.dp_schedule["allreduce_isolated_us"] > 0
+            assert isinstance(m.overlap_allreduce, bool) and m.overlap_allreduce == (m.dp_schedule["choice"] == "split")
+            assert m.overlap_allreduce == (m.dp_schedule["allreduce_isolated_us"] > m.DP_SPLIT_ABOVE_US)
+            out.setdefault("choices", []).append(m.dp_schedule["choice"])
             m.overlap_allreduce = mode != "whole"
             m.use_hip_graph = mode == "overlap_graph"
             losses = [m.train_step_larva(args, _Val(), x, t) for _ in range(3)]
@@ -89,6 +94,7 @@ def test_two_ranks_overlapped_allreduce_trains_like_one_collective(hip_device, b
     for rank, err, _ in res:
         assert err is None, "rank %d: %s" % (rank, err)
     (_, _, a), (_, _, b) = res
+    assert a.pop("choices") == b.pop("choices")    # both ranks chose the same schedule every time (MAX over ranks)
     assert a["whole"]["split_at"] is None
     for mode in ("overlap_eager", "overlap_graph"):
         assert a[mode]["split_at"] and a[mode]["split_at"] > 0, "backward was not split: nothing overlapped"

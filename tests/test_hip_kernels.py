@@ -1182,3 +1182,51 @@ def test_sign_bits_are_refused_off_the_16_byte_path(hip_device):
     with pytest.raises(RuntimeError):                       # a consumer with another fusion is an invalid request
         K.conv3x3(torch.zeros(1, 48, 8, 16, device=hip_device), fwd, 48, relu=True,
                   maskbits=torch.zeros(K.maskbits_bytes(1, 48, 8, 16), dtype=torch.uint8, device=hip_device))
+
+
+@pytest.mark.parametrize("N,C,H,W", [(1, 48, 23, 100), (2, 48, 9, 48), (1, 32, 14, 52), (1, 48, 5, 20)])
+@pytest.mark.parametrize("epi", ["plain", "relu", "res1", "res2", "shuffle", "shuffle_base", "two_sources"])
+def test_four_row_tiles_equal_three_row_tiles_bit_for_bit(hip_device, N, C, H, W, epi):
+    """Round 4: whole-tensor launches may run on 4 x 48 tiles (fewer rounds of resident workgroups on large images, 9
+    MFMAs per k-step per wave).  An output pixel's K loop does not depend on the tile it sits in: the two tile heights
+    give the same bits for every epilogue the 4-row tiles exist for, heights that are not a multiple of 4, row-padded
+    widths and concatenated sources; and the library's own choice (tile_rows = 0) is one of the two."""
+    from larvanet_amd import kernels as K
+    from oracle import larva_ref as R
+    if epi.startswith("shuffle") and C != 48:
+        pytest.skip("pixel-shuffle exits have 48 output channels")
+    rng = np.random.default_rng(N * 31 + C + H * 7 + W + len(epi))
+    two = epi == "two_sources"
+    x = _rand(rng, (N, C, H, W), 20.0)
+    x2 = _rand(rng, (N, C, H, W), 20.0)
+    w = _rand(rng, (C, 2 * C if two else C, 3, 3), 0.05)
+    b = _rand(rng, (C,), 1.0)
+    kw = {"bias": _dev(b, hip_device)}
+    if epi == "relu":
+        kw["relu"] = True
+    if epi in ("res1", "res2"):
+        kw["res0"] = _dev(_rand(rng, (N, C, H, W), 20.0), hip_device)
+    if epi == "res2":
+        kw["res1"] = _dev(_rand(rng, (N, C, H, W), 20.0), hip_device)
+    if epi.startswith("shuffle"):
+        kw["shuffle"] = True
+    if epi == "shuffle_base":
+        kw["base"] = _dev(_rand(rng, (N, 3, 4 * H, 4 * W), 50.0), hip_device)
+    fwd, _ = K.pack_weights(_dev(w, hip_device))
+    srcs = [_dev(x, hip_device), _dev(x2, hip_device)] if two else _dev(x, hip_device)
+    outs = {r: K.conv3x3(srcs, fwd, C, tile_rows=r, **kw) for r in (3, 4, 0)}
+    torch.cuda.synchronize()
+    assert torch.equal(outs[3], outs[4]) and torch.equal(outs[0], outs[3])
+    if epi == "plain":
+        _report("conv3x3 on 4-row tiles", outs[4].cpu().numpy(), R.conv3x3(x, w, b), 2e-5)
+
+
+def test_four_row_tiles_are_refused_where_they_do_not_exist(hip_device):
+    from larvanet_amd import kernels as K
+    x = torch.zeros(1, 48, 8, 16, device=hip_device)
+    fwd, _ = K.pack_weights(torch.zeros(48, 48, 3, 3, device=hip_device))
+    with pytest.raises(RuntimeError, match="hip error 801"):
+        K.conv3x3(x, fwd, 48, mask=torch.ones_like(x), tile_rows=4)      # (no ReLU-backward epilogue on 4-row tiles)
+    x13 = torch.zeros(1, 48, 5, 13, device=hip_device)                   # register-staged path
+    with pytest.raises(RuntimeError, match="hip error 801"):
+        K.conv3x3(x13, fwd, 48, tile_rows=4)
