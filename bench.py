@@ -65,8 +65,8 @@ FULL_IMAGE = (3, 339, 510)                               # DIV2K-val-like LR ima
 # itself); they are READ from the CSVs under profiles/ at run time -- a tile change that is not followed by new PMC
 # passes shows as a stale file name here, not as a silently wrong constant.  FETCH_SIZE is doubled per the guide's
 # gfx950 correction for 16-byte-per-lane streams; both counters are in KB.
-PMC_CONV_CSV = "profiles/r03_pmc_conv.csv"      # tools/profile_r03.sh: passes over `bench.py --roofline-only`
-PMC_WGRAD_CSV = "profiles/r03_pmc_wgrad.csv"    # passes over `bench.py --wgrad-only` (flat grid over 40 layers + reduction)
+PMC_CONV_CSV = "profiles/r04_pmc_conv.csv"      # tools/profile_r04.sh: passes over `bench.py --roofline-only`
+PMC_WGRAD_CSV = "profiles/r04_pmc_wgrad.csv"    # passes over `bench.py --wgrad-only` (flat grid over 40 layers + reduction)
 PMC_WGRAD_LAYERS = 40
 
 
@@ -542,6 +542,36 @@ def wgrad_in_step(model, x, truth, reps=30):
                     "(HIP events, median of 3 x %d replays)" % reps}
 
 
+def chains_in_step():
+    """The layer chains INSIDE the captured training step, product kernels: one-lane marker launches (larva_stamp_clock)
+    at the fork and at the end of each chain, forward and backward (tools/step_marks.py; four markers per phase, ~2 us each
+    on their stream).  The forward chain is head + 32 conv(+ReLU / +residual) layers; fork -> last chain's end over its
+    algorithmic FLOPs is the fraction of the matrix peak the step's own chain runs at -- the figure `roofline.frac`
+    (a captured 40-link conv+ReLU chain, replay / 40) stands in for."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("step_marks", os.path.join(ROOT, "tools", "step_marks.py"))
+    sm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sm)
+    names, queued, lone, event_us, host_us = sm.measure(link_marks=())
+    ph = sm.chain_phases(names, queued)
+    out = {"graph_replay_us_with_markers": event_us, "host_us_per_graph_launch": host_us,
+           "what": "tools/step_marks.py: markers between the product kernels of the captured forward+backward, last of 10 "
+                   "back-to-back replays; fork -> the later chain's end"}
+    head_flop = 2 * 9 * 3 * CH * BATCH * PATCH * PATCH
+    if "fwd" in ph:
+        us, links = ph["fwd"]
+        flop = (links - 1) * conv_flop(CH) + head_flop
+        out["forward_chain"] = {"us": us, "links": links, "us_per_layer": us / links, "flop": flop,
+                                "achieved": flop / us / 1e6, "frac": flop / us / 1e6 / FP32_MFMA_PEAK_TFLOPS}
+    if "bwd" in ph:
+        us, links = ph["bwd"]
+        joint = len(BLOCKS) - 1                      # K = 96 joint input gradients: two layers' work in one link
+        flop = (links + joint) * conv_flop(CH)
+        out["backward_chain"] = {"us": us, "links": links, "joint_k96_links": joint, "us_per_layer": us / (links + joint),
+                                 "flop": flop, "achieved": flop / us / 1e6, "frac": flop / us / 1e6 / FP32_MFMA_PEAK_TFLOPS}
+    return out
+
+
 def host_cores():
     """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota (a GPU
     box hands each job a share of a large host; 256 threads on a 16-CPU share thrash)."""
@@ -1004,6 +1034,7 @@ def main():
                 "traffic": iso.get("traffic"), "traffic_source": iso.get("traffic_source"),
                 "timing": ins["what"], "in_step": ins, "isolated_loop": iso}
         guarded(line, "roofline_wgrad", wgrad_in_the_step)
+        guarded(line["roofline"], "in_step", chains_in_step)
         if "error" in line["roofline_wgrad"]:
             line["roofline_wgrad"] = dict(iso, in_step_error=line["roofline_wgrad"]["error"])
     infer_flop = infer_flop_per_lr_pixel(BLOCKS, CH, v2=False) * BATCH * PATCH * PATCH     # 52.08 GFLOP

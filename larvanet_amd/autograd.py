@@ -150,7 +150,9 @@ class DualChain:
     enabled = False      # set by StepScope
     # output store policy of the strip launches: "fwd" = plain stores in the forward chain (read at once by
     # the next launch), non-temporal in the backward chain; "all" / "none" for A/B timing
-    plain_stores = os.environ.get("LARVA_STRIP_PLAIN", "fwd")
+    # round 4, same box, three alternating rounds (profiles/r04_ab_strip_plain.txt): all 1.634-1.641 ms, fwd 1.648-1.650,
+    # none 1.657-1.660 -- round 2's A/B (all-plain 1.696 against forward-only 1.688) no longer holds for today's kernels
+    plain_stores = os.environ.get("LARVA_STRIP_PLAIN", "all")
     lazy_fwd = False
     lazy_bwd = False
     max_workgroups = 512   # one full-batch launch with more 3 x 48 tiles than this already overlaps by itself
@@ -167,8 +169,16 @@ class DualChain:
             return False
         return K.strip_tile_table(h, p, torch.device("cuda", torch.cuda.current_device())) is not None
 
+    # Round 4: chain 0 runs on the stream that was current at the fork (the capture's own stream) and only chain 1 on a
+    # side stream: one cross-stream edge per fork and per join instead of two (each costs the dependent launch ~3-10 us,
+    # tools/step_marks.py).  LARVA_CHAIN0_ON_MAIN=0: both chains on side streams (rounds 2-3).
+    chain0_on_main = os.environ.get("LARVA_CHAIN0_ON_MAIN", "1") != "0"
+    _main = None
+
     @classmethod
     def _stream(cls, k):
+        if k == 0 and cls.chain0_on_main and cls._main is not None:
+            return cls._main
         key = (torch.cuda.current_device(), k)
         if key not in cls._streams:
             cls._streams[key] = torch.cuda.Stream(device=key[0])
@@ -187,8 +197,10 @@ class DualChain:
         out = torch.empty((n, cout, h, p), device=first.device, dtype=torch.float32)
         cur = torch.cuda.current_stream()
         if not cls._forked:
+            cls._main = cur
             for k in range(2):
-                cls._stream(k).wait_stream(cur)
+                if cls._stream(k) != cur:
+                    cls._stream(k).wait_stream(cur)
             cls._forked = True
         cls._keep.append(out)
         cls._keep.extend([srcs] if isinstance(srcs, torch.Tensor) else list(srcs))
@@ -206,16 +218,19 @@ class DualChain:
             if cls._forked:
                 cur = torch.cuda.current_stream()
                 for k in range(2):
-                    cur.wait_stream(cls._stream(k))
+                    if cls._stream(k) != cur:
+                        cur.wait_stream(cls._stream(k))
         finally:
             # (also when a wait raises -- a stream capture that died mid-chain: the next step must fork afresh)
             cls._forked = False
+            cls._main = None
             cls._keep.clear()
 
     @classmethod
     def reset(cls):
         """Forget a fork without waiting (after a failed capture + a device synchronisation)."""
         cls._forked = False
+        cls._main = None
         cls._keep.clear()
 
     @classmethod

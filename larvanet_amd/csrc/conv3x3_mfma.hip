@@ -66,6 +66,12 @@
 // 14.9-15.4 against 14.2-14.6 us per layer, step 1.664-1.672 against 1.653-1.657 ms (same box, tools/ab_variant.sh).
 #define LARVA_TABLE_SCALAR 0
 #endif
+#ifndef LARVA_WIDE_PLAIN
+#define LARVA_WIDE_PLAIN 0     // 1: the 48-column tiles' mode-0 output with plain instead of non-temporal stores (A/B timing)
+#endif
+#ifndef LARVA_AUX_LATE
+#define LARVA_AUX_LATE 1       // 0: the epilogue's operands requested in front of chunk 0's input pieces (rounds 1-3; A/B timing)
+#endif
 #ifndef LARVA_PIN_SCALARS
 #define LARVA_PIN_SCALARS 1    // 0: the epilogue's H / W / pitch / plain_stores re-loaded from the kernarg segment (A/B timing)
 #endif
@@ -107,13 +113,16 @@ __device__ unsigned long long* g_stamps = nullptr;
 // requested, [8] chunk 0's input pieces issued, [9] chunk 1 issued.
 constexpr int kDiagWgPerSlot = 256;
 __device__ int g_slot_of_launch = 0;   // (unused on the device: the slot travels in ConvArgs)
-__device__ __forceinline__ void stamp_slot(int slot, int k) {
-  if (!g_stamps || threadIdx.x != 0 || slot < 0 || blockIdx.x >= kDiagWgPerSlot) return;
+// (round 4: the launch carries the ADDRESS of its stamp area in its arguments -- null when no slot is armed.  Until
+// then every stamp() first loaded g_stamps from memory, armed or not: ten dependent scalar round trips per workgroup,
+// which is what made this build ~1 us per layer slower than the product even with the stamps disarmed.)
+__device__ __forceinline__ void stamp_slot(unsigned long long* area, int k) {
+  if (!area || threadIdx.x != 0 || blockIdx.x >= kDiagWgPerSlot) return;
   // (bit 11, 2048: also the prologue's steps -- five more stamps per workgroup cost ~1 us of its life)
   const int idx = k == 0 ? 0 : k == 2 ? 1 : k == 3 ? 2 : k == 5 ? 3
                   : !(LARVA_DIAG & 2048) ? -1 : k == 6 ? 5 : k == 7 ? 6 : k == 14 ? 7 : k == 15 ? 8 : k == 1 ? 9 : -1;
   if (idx < 0) return;
-  unsigned long long* p = g_stamps + ((size_t)slot * kDiagWgPerSlot + blockIdx.x) * 16;
+  unsigned long long* p = area + (size_t)blockIdx.x * 16;
   p[idx] = __builtin_amdgcn_s_memrealtime();
   if (k == 0) {
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
@@ -121,7 +130,7 @@ __device__ __forceinline__ void stamp_slot(int slot, int k) {
     p[4] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
   }
 }
-#define stamp(k) stamp_slot(a.diag_slot, (k))
+#define stamp(k) stamp_slot(a.diag_area, (k))
 #else
 __device__ __forceinline__ void stamp(int k) {
   // bit 6 (64): stamps in SHADER-CLOCK cycles (s_memtime) instead of the 100 MHz wall clock: the two runs
@@ -212,7 +221,7 @@ struct ConvArgs {
   // them stood at the very start of every workgroup); exact while dividend * divisor < 2^40
   unsigned long long magic_tx, magic_ty, magic_cps;
 #if LARVA_DIAG & 512
-  int diag_slot;              // stamp area of this launch (-1: none)
+  unsigned long long* diag_area;   // stamp area of this launch (null: none)
 #endif
 };
 
@@ -781,9 +790,23 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         }
       }
   };
+  // Round 4: on the loader-wave path the epilogue's operands are requested BEHIND chunk 1's pieces, not in front of
+  // chunk 0's.  vmcnt retires in order: requested first (rounds 1-3), the first counted wait of the ring -- "chunk 0 has
+  // landed" -- also waited for them, and in a training step they are COLD (the ReLU mask is an activation the forward
+  // pass wrote a millisecond ago, the residuals come from two layers back): the K loop of every mask / residual link
+  // started ~1.3 us later than a conv + ReLU link's (in-kernel stamps of the captured step, profiles/r04_step_timeline_
+  // stamped.txt: workgroup life 10.4-11.5 against 9.0-10.0 us at the same 5.8-5.9 us of K loop).  Requested last, every
+  // wait of the ring leaves exactly these kAuxLoads vector loads in flight (one 16-byte load per operand and (channel
+  // group, pixel group) unit with pixel-major or pixel-shuffle accumulators; one byte load for the sign bits) and the
+  // vmcnt(0) behind the K loop collects them.  kAuxLoads must not EXCEED the loads the compiler really emits between
+  // chunk 1's pieces and the first wait (a smaller real count would let a wait pass with a piece still in flight):
+  // tools/check_aux_loads.py counts them in the ISA of every instantiation.
+  constexpr bool kAuxLate = LARVA_AUX_LATE && VEC && C::LOADER && C::NST == 3 && LARVA_AUX_EARLY && LARVA_PIXEL_MAJOR && !AUXLDS &&
+                            !(LARVA_DIAG & 6) && (NAUX > 0 || EPI == kEpiMaskBits);
+  constexpr int kAuxLoads = kAuxLate ? (EPI == kEpiMaskBits ? 1 : NAUX) * NCT * NPG : 0;
   auto load_early = [&]() {
     load_bias();
-    if constexpr ((NAUX > 0 || EPI == kEpiMaskBits) && LARVA_AUX_EARLY && !(LARVA_DIAG & 4)) load_aux();
+    if constexpr ((NAUX > 0 || EPI == kEpiMaskBits) && LARVA_AUX_EARLY && !kAuxLate && !(LARVA_DIAG & 4)) load_aux();
   };
   if constexpr (!VEC || (LARVA_DIAG & 2)) load_early();
 
@@ -827,6 +850,11 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         for (int i = 0; i < C::NPW; ++i) dma_piece<COUT, G>(pl, i, wave, cs1, st1);
       }
       (void)st1;
+      if constexpr (kAuxLate) {   // the youngest vector loads of the wave (see above)
+        __builtin_amdgcn_sched_barrier(0);
+        load_aux();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     stamp(1);
     int stage = 0;
@@ -838,8 +866,8 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         // pieces in flight, every later one finds nothing outstanding
         if constexpr ((LARVA_DIAG & 256) != 0) {
           // timing ablation (with bit 1: nothing is staged): no barrier between the chunks
-        } else if (chunk == 0) wait_and_barrier<((LARVA_DIAG & 2) || C::NST == 2) ? 0 : C::NPW>();
-        else wait_and_barrier<0>();
+        } else if (chunk == 0) wait_and_barrier<(((LARVA_DIAG & 2) || C::NST == 2) ? 0 : C::NPW) + kAuxLoads>();
+        else wait_and_barrier<kAuxLoads>();
       } else {
         // (the NPW youngest operations belong to chunk+1)
         wait_and_barrier<(LARVA_DIAG & 2) ? 0 : C::NPW>();
@@ -1040,6 +1068,8 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     } else if constexpr (G::COLS == 16) {
       if (k.plain) store_all(std::true_type{});
       else store_all(std::false_type{});
+    } else if constexpr (LARVA_WIDE_PLAIN != 0) {
+      store_all(std::true_type{});
     } else {
       store_all(std::false_type{});
     }
@@ -1597,6 +1627,7 @@ int larva_pack_weights(const float* w, float* wpk_fwd, float* wpk_bwd, int cout,
 
 #if LARVA_DIAG & 512
 static int g_diag_next_slot = -1, g_diag_slot_cap = 0;
+static unsigned long long* g_diag_host_base = nullptr;   // larva_diag_set_stamps' buffer, as the host knows it
 static int diag_take_slot() {
   if (g_diag_next_slot < 0 || g_diag_next_slot >= g_diag_slot_cap) return -1;
   return g_diag_next_slot++;
@@ -1635,7 +1666,10 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
   if (!wpk || !out) return (int)hipErrorInvalidValue;
   a = ConvArgs{};
 #if LARVA_DIAG & 512
-  a.diag_slot = diag_take_slot();
+  {
+    const int slot = diag_take_slot();
+    a.diag_area = (slot >= 0 && g_diag_host_base) ? g_diag_host_base + (size_t)slot * kDiagWgPerSlot * 16 : nullptr;
+  }
 #endif
   aligned = (pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(wpk) & 15) == 0);
   for (int i = 0; i < n_src; ++i) {
@@ -1992,6 +2026,9 @@ int larva_conv3x3_fwd_strips_mb(const float* const* src, int n_src, int cin_per_
 
 #if LARVA_DIAG & 32
 int larva_diag_set_stamps(unsigned long long* buf) {
+#if LARVA_DIAG & 512
+  g_diag_host_base = buf;
+#endif
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(larva::g_stamps), &buf, sizeof(buf));
 }
 #endif

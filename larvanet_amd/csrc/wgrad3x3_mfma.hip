@@ -69,18 +69,17 @@ struct WgradBatch {
   int head_units;       // 0: no head job
   int head_first_wg;    // the first workgroup whose share reaches into the head
 #if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
-  int diag_slot;        // stamp area of this launch (tools/diag_step.py), -1: none
+  unsigned long long* diag_area;   // stamp area of this launch (tools/diag_step.py), null: none
 #endif
 };
 
 #if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
 // In-kernel timeline of the flat weight-gradient launches (with the conv kernels' own stamps, conv3x3_mfma.hip): wave 0
 // of every workgroup writes the 100 MHz wall clock at entry and before it ends, and its HW_ID | XCC_ID << 32, into
-// g_wstamps[(slot * 256 + workgroup) * 4 + {0, 1, 2}].
-__device__ unsigned long long* g_wstamps = nullptr;
-__device__ __forceinline__ void wstamp(int slot, int k) {
-  if (!g_wstamps || threadIdx.x != 0 || slot < 0 || blockIdx.x >= 256) return;
-  unsigned long long* p = g_wstamps + ((size_t)slot * 256 + blockIdx.x) * 4;
+// area[workgroup * 4 + {0, 1, 2}] (the launch carries its area's address in its arguments).
+__device__ __forceinline__ void wstamp(unsigned long long* area, int k) {
+  if (!area || threadIdx.x != 0 || blockIdx.x >= 256) return;
+  unsigned long long* p = area + (size_t)blockIdx.x * 4;
   p[k] = __builtin_amdgcn_s_memrealtime();
   if (k == 0) {
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -88,7 +87,7 @@ __device__ __forceinline__ void wstamp(int slot, int k) {
     p[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
   }
 }
-#define WSTAMP(b, k) wstamp((b).diag_slot, (k))
+#define WSTAMP(b, k) wstamp((b).diag_area, (k))
 #else
 #define WSTAMP(b, k) ((void)0)
 #endif
@@ -1066,6 +1065,7 @@ int larva_wgrad_flat_head_splits(int njobs, int nwg, int tiles_per_layer);
 
 #if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
 static int g_wdiag_next = -1, g_wdiag_cap = 0;
+static unsigned long long* g_wdiag_base = nullptr;
 #endif
 static int wgrad_flat_impl(const float* const* dy, const float* const* x, float* const* partial, int njobs,
                            const float* head_dy, const float* head_x16, float* head_partial, int nwg, int N, int cout,
@@ -1116,7 +1116,7 @@ static int wgrad_flat_impl(const float* const* dy, const float* const* x, float*
     if (*head_splits_out > larva_wgrad_flat_head_splits(njobs, nwg, (int)total)) return (int)hipErrorInvalidValue;
   }
 #if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
-  b.diag_slot = (g_wdiag_next >= 0 && g_wdiag_next < g_wdiag_cap) ? g_wdiag_next++ : -1;
+  b.diag_area = (g_wdiag_base && g_wdiag_next >= 0 && g_wdiag_next < g_wdiag_cap) ? g_wdiag_base + (size_t)(g_wdiag_next++) * 256 * 4 : nullptr;
 #endif
   if (cout == 32) return (int)launch_wgrad_flat<32, 32>(b, nwg, (hipStream_t)stream);
   return (int)launch_wgrad_flat<48, 48>(b, nwg, (hipStream_t)stream);
@@ -1124,7 +1124,8 @@ static int wgrad_flat_impl(const float* const* dy, const float* const* x, float*
 
 #if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
 int larva_diag_set_wgrad_stamps(unsigned long long* buf) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(larva::g_wstamps), &buf, sizeof(buf));
+  g_wdiag_base = buf;
+  return 0;
 }
 // flat weight-gradient launches built from now on take slots first, first + 1, ... < cap (first < 0: off); returns
 // the slot the next launch would have taken

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""The conv kernel's loader-wave path issues its epilogue operands (mask / residuals / base / truth / sign bits) as the
+YOUNGEST vector loads of an MFMA wave's prologue and every counted wait of the LDS-DMA ring leaves `kAuxLoads` of them
+in flight (run_role, LARVA_AUX_LATE).  That count is a compile-time product; the loads are the compiler's.  If it
+emitted FEWER vector loads than counted, `s_waitcnt vmcnt(NPW + kAuxLoads)` could pass with a piece of chunk 0 still
+in flight.  This script reads the device assembly (hipcc -S) and, for every ring wait of every kernel, counts the
+global loads between the last LDS-DMA piece in front of it and the wait:
+
+  first wait of a role   vmcnt(N):  N - (global loads since the last piece) must equal the role's pieces per wave (NPW)
+  later waits            vmcnt(N):  N must equal the first wait's load count
+
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -o /tmp/conv.s larvanet_amd/csrc/conv3x3_mfma.hip
+  python tools/check_aux_loads.py /tmp/conv.s
+"""
+import re
+import sys
+
+path = sys.argv[1]
+kernel = None
+bad = 0
+rows = {}
+state = None
+with open(path) as f:
+    lines = f.read().split("\n")
+i = 0
+while i < len(lines):
+    ln = lines[i].strip()
+    m = re.match(r"^(_ZN5larva\w+):", lines[i])
+    if m:
+        kernel = m.group(1)
+        state = {"loads_since_dma": 0, "dma_run": 0, "first": None, "pieces_last_run": 0}
+        rows[kernel] = []
+    elif kernel and state is not None:
+        if ln.startswith("buffer_load_dwordx4") and " lds" in ln:
+            if state["loads_since_dma"] or state["dma_run"] == 0:
+                state["pieces_last_run"] = 0
+            state["dma_run"] += 1
+            state["pieces_last_run"] += 1
+            state["loads_since_dma"] = 0
+        elif re.match(r"^(global_load_|buffer_load_(?!dwordx4.* lds))", ln):
+            state["loads_since_dma"] += 1
+        elif ln.startswith("s_waitcnt vmcnt(") and i + 1 < len(lines) and lines[i + 1].strip() == "s_barrier":
+            n = int(re.search(r"vmcnt\((\d+)\)", ln).group(1))
+            rows[kernel].append((n, state["loads_since_dma"], state["dma_run"]))
+            state["dma_run"] = 0
+        elif ln.startswith(".Lfunc_end"):
+            kernel, state = None, None
+    i += 1
+
+import subprocess
+def demangle(n):
+    try:
+        return subprocess.check_output(["c++filt", n]).decode().strip().replace("larva::", "").replace("(larva::ConvArgs)", "").replace("(larva::ConvBatch)", "")
+    except Exception:
+        return n
+
+for k, r in rows.items():
+    if not r:
+        continue
+    # a role's first wait follows a run of DMA pieces (dma_run > 0); later waits of the same role have dma_run == 0
+    out, first_loads = [], None
+    j = 0
+    while j < len(r):
+        n, loads, run = r[j]
+        if run > 0 and loads == 0 and n >= 12:
+            out.append("loader wave: vmcnt(%d) = one chunk's pieces" % n)     # (run_loader: a whole chunk in flight)
+            first_loads = None
+        elif run > 0:
+            npw = n - loads
+            if loads <= n and 3 <= npw <= 9:
+                first_loads = loads
+                out.append("first vmcnt(%d) = %d pieces + %d operand loads" % (n, npw, loads))
+            elif n == loads and j + 1 < len(r) and r[j + 1][2] == 0 and 3 <= r[j + 1][0] - loads <= 9:
+                # the loop was laid out in front of its entry: this is the LATER wait, the next one the first
+                first_loads = loads
+                out.append("first vmcnt(%d) = %d pieces + %d operand loads; later vmcnt(%d)   (loop rotated in the listing)"
+                           % (r[j + 1][0], r[j + 1][0] - loads, loads, n))
+                j += 1
+            else:
+                out.append("first vmcnt(%d) with %d operand loads in front of it  <-- CHECK" % (n, loads))
+                bad += 1
+        elif first_loads is None:
+            out.append("loader wave: vmcnt(%d)" % n)
+        else:
+            ok = n == first_loads
+            out.append("later vmcnt(%d)%s" % (n, "" if ok else "  <-- expected %s" % first_loads))
+            bad += 0 if ok else 1
+        j += 1
+    uniq = []
+    for o in out:
+        if not uniq or uniq[-1][0] != o:
+            uniq.append([o, 1])
+        else:
+            uniq[-1][1] += 1
+    print(demangle(k))
+    for o, c in uniq:
+        print("    %s%s" % (o, " (x%d)" % c if c > 1 else ""))
+print("%d suspicious waits" % bad)
+sys.exit(1 if bad else 0)

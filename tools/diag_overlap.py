@@ -18,6 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 STEPS = "--prologue-steps" in sys.argv     # the heavier build that also stamps the prologue's steps
 LIB = os.path.join(ROOT, "tools", "_diag", "liblarva_overlap%s.so" % ("_steps" if STEPS else ""))
+if not STEPS and not os.path.exists(LIB) and os.path.exists(os.path.join(ROOT, "tools", "_diag", "liblarva_step.so")):
+    LIB = os.path.join(ROOT, "tools", "_diag", "liblarva_step.so")   # tools/diag_step.py's build: the same -DLARVA_DIAG=544
 WG, SLOT_WORDS = 256, 16
 
 
@@ -117,17 +119,19 @@ def main():
     w("two half-batch chains of %d conv3x3+ReLU strip launches (8x48x48x48 each, 256 workgroups), one captured graph, "
       "un-profiled replay; in-kernel 100 MHz stamps of the LAST of 33 replays" % chain)
     w("activations N(0,1)*20 kept at that scale (RMS after the last layer %.1f); build -DLARVA_DIAG=%d" % (rms, 544 + (2048 if STEPS else 0)))
-    w("HIP event pair around 10 replays (median of 3): %.2f us per full-batch layer  <- what bench.py's roofline.avg_ms measures "
-      "(the stamped build pays for its stamps: compare with the bench line of the same box)" % event_us)
-    w("same process, stamps not armed: bench.py's roofline.avg_ms = (t160 - t40) / 120 = %.2f us per full-batch layer; t40 / 40 = %.2f us"
-      % (slope_ms * 1e3, ms40 * 1e3))
+    w("HIP event pair around 10 replays (median of 3): %.2f us per full-batch layer = replay / 40 with the stamps ARMED  <- the "
+      "definition of bench.py's roofline.avg_ms / roofline.frac since round 4 (replay of a captured 40-link chain / 40)" % event_us)
+    w("same process, stamps not armed, bench.py's own functions: roofline.avg_ms = t40 / 40 = %.2f us per full-batch layer (%.3f of "
+      "the fp32 matrix peak); roofline.avg_ms_steady_state = (t160 - t40) / 120 = %.2f us (%.3f)"
+      % (ms40 * 1e3, bench.conv_flop(c) / (ms40 * 1e-3) / 1e12 / bench.FP32_MFMA_PEAK_TFLOPS,
+         slope_ms * 1e3, bench.conv_flop(c) / (slope_ms * 1e-3) / 1e12 / bench.FP32_MFMA_PEAK_TFLOPS))
     span = tt[:, :, 3].max() - tt[:, :, 0].min()
-    w("stamps: first kernel entry -> last store drained %.1f us = %.2f us per full-batch layer" % (span, span / chain))
+    w("stamps: first kernel entry -> last store drained %.1f us = %.2f us per full-batch layer (a replay's kernels only: the "
+      "event figure also holds the graph launch gap between two replays, %.1f us)" % (span, span / chain, event_us * chain - span))
     starts = [min(tt[2 * i, :, 0].min(), tt[2 * i + 1, :, 0].min()) for i in range(chain)]
     steady = (starts[chain - 1] - starts[8]) / (chain - 1 - 8)
     w("stamps, steady state: layer 8's first entry -> layer %d's first entry = %.2f us per full-batch layer  <- what bench.py's "
-      "roofline.avg_ms (slope between a 160- and a 40-layer chain) measures, plus what the armed stamps cost (the event figure above "
-      "against t40 / 40: per layer); the replay's fixed cost (graph launch gap, the second "
+      "roofline.avg_ms_steady_state (slope between a 160- and a 40-layer chain) measures; the replay's fixed cost (graph launch gap, the second "
       "chain starting %.1f us after the first, the first layers' cold operands) is %.1f us per replay by the event pair"
       % (chain - 1, steady, tt[1, :, 0].min() - tt[0, :, 0].min(), event_us * chain - steady * chain))
     w("")

@@ -6,7 +6,7 @@ rocprofv3 cannot answer this (its per-dispatch overhead serialises the two chain
 -DLARVA_DIAG=544 build gives every conv launch and every flat weight-gradient launch of the captured forward+backward
 its own stamp area; wave 0 of every workgroup writes the 100 MHz wall clock at entry / first K chunk landed / K loop
 done / stores drained (conv) or entry / exit (wgrad).  The graph is the plugin's own (`_scope()` + `_exit_losses` +
-`backward`, M4B4, 16 x 3 x 48 x 48), replayed un-profiled; the stamps of the LAST replay are read.
+`backward`, M4B4, 16 x 3 x 48 x 48), replayed un-profiled; the stamps of the LAST of six back-to-back replays are read.
 
   python tools/diag_step.py --build            (build container)
   python tools/diag_step.py [out.txt]          (GPU box; environment switches of the plugin apply, e.g. LARVA_WGRAD_EARLY_WG)
@@ -126,7 +126,11 @@ def main():
         torch.cuda.synchronize()
         runs.append(s.elapsed_time(e) / 20 * 1e3)
     event_us = sorted(runs)[1]
-    graph.replay()
+    # the stamps read are those of the LAST of six back-to-back replays: the host is then far ahead of the GPU, as it is
+    # in a training loop (a lone replay after a synchronisation starts its second chain ~100 us late: the host is still
+    # enqueueing the graph's ~140 nodes, 460 us of host time per launch, while the first ones already run)
+    for _ in range(6):
+        graph.replay()
     torch.cuda.synchronize()
     st = stamps.cpu().numpy().reshape(CAP, WG, WORDS).astype(np.float64) * 0.01
     ws = wstamps.cpu().numpy().reshape(WCAP, WG, WWORDS).astype(np.float64) * 0.01
@@ -170,7 +174,8 @@ def main():
     out = []
     w = out.append
     w("captured forward+backward of the plugin's training step (M4B4, 48 channels, 16 x 3 x 48 x 48), one graph, un-profiled "
-      "replay; in-kernel 100 MHz stamps of the last replay; build -DLARVA_DIAG=544 (stamps cost ~0.9 us per chain layer)")
+      "replay; in-kernel 100 MHz stamps of the last of six back-to-back replays; build -DLARVA_DIAG=544 (the launch carries its stamp "
+      "area's address: a stamp is one s_memrealtime + one store)")
     w("environment: " + " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("LARVA_") and k != "LARVA_HIP_LIB"))
     w("HIP event pair around 20 replays (median of 3): %.1f us per forward+backward" % event_us)
     w("stamps: first kernel entry -> last stamped exit %.1f us (the reduction / loss launches behind it carry no stamps)"

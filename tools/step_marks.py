@@ -17,14 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def measure(every=False, link_marks=(0, 8, 16, 24)):
+    """-> (names, queued us, lone us, event us per replay, host us per graph launch).  link_marks: chain links behind which
+    a marker is captured on each chain stream (() = only the chains' starts and ends: four markers per phase)."""
     import importlib
     import numpy as np
     import torch
     from larvanet_amd import autograd as A, hip_lib, kernels as K
     lib = hip_lib.load()
-    every = "--marks-every-link" in sys.argv
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator().manual_seed(1)
     x = (torch.rand(16, 3, 48, 48, generator=g) * 255).to(dev)
     t = (torch.rand(16, 3, 192, 192, generator=g) * 255).to(dev)
@@ -70,14 +71,16 @@ def main():
             cur = torch.cuda.current_stream()
             phase["name"], phase["link"] = ("fwd" if forward else "bwd"), 0
             mark("%s: main stream at the fork" % phase["name"])
+            cls._main = cur     # (DualChain.conv's own fork: chain 0 may run on the current stream itself)
             for k in range(2):
-                cls._stream(k).wait_stream(cur)
+                if cls._stream(k) != cur:
+                    cls._stream(k).wait_stream(cur)
                 mark("%s chain %d: start (before link 0)" % (phase["name"], k), cls._stream(k))
             cls._forked = True
         out = real_conv(cls, srcs, wpk, cout, forward=forward, **kw)
         if on[0] and splits:
             i = phase["link"]
-            if every or i in (0, 8, 16, 24):
+            if every or i in link_marks:
                 for k in range(2):
                     mark("%s chain %d: after link %d" % (phase["name"], k, i), cls._stream(k))
             phase["link"] = i + 1
@@ -94,9 +97,11 @@ def main():
 
     A.DualChain.conv = classmethod(conv)
     A.DualChain.join = classmethod(join)
+    restore = []
 
     def wrap(name, label):
         real = getattr(K, name)
+        restore.append((name, real))
 
         def fn(*a, **kw):
             out = real(*a, **kw)
@@ -143,6 +148,32 @@ def main():
     graph.replay()
     torch.cuda.synchronize()
     lone = marks.cpu().numpy()[:len(names)].astype(np.float64) * 0.01
+    A.DualChain.conv = classmethod(real_conv)
+    A.DualChain.join = classmethod(real_join)
+    for name, real in restore:
+        setattr(K, name, real)
+    del graph
+    return names, ahead, lone, event_us, host_us
+
+
+def chain_phases(names, arr):
+    """{phase: (fork -> last chain end in us, links per chain)} from one column of measure()."""
+    d = dict(zip(names, arr))
+    out = {}
+    for ph in ("fwd", "bwd"):
+        fork = d.get("%s: main stream at the fork" % ph)
+        ends = [(v, n_) for n_, v in d.items() if n_.startswith("%s chain" % ph) and ": end" in n_]
+        if fork is None or not ends:
+            continue
+        links = int(ends[0][1].rsplit("link ", 1)[1].rstrip(")")) + 1
+        out[ph] = (max(v for v, _ in ends) - fork, links)
+    return out
+
+
+def main():
+    import numpy as np
+    every = "--marks-every-link" in sys.argv
+    names, ahead, lone, event_us, host_us = measure(every)
     out = []
     w = out.append
     w("markers between the PRODUCT kernels of the captured forward+backward (M4B4, 48 channels, 16 x 3 x 48 x 48); %d markers%s"
