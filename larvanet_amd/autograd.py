@@ -1108,6 +1108,9 @@ class MeanTermsFn(torch.autograd.Function):
             DeferredWgrad.pending_loss = (ts, scales, float(len(ts)), out)
             return out
         cell = StepScope.early_loss if isinstance(StepScope.early_loss, K.HostCell) else None
+        # (round 4, measured and removed: this 8 us single-block launch on a stream of its own, so that it does not stand
+        # between the exits' forward and their backward -- step 1.631-1.657 against 1.628-1.635 ms: a third branch in the
+        # captured graph costs more than the launch, profiles/r04_ab_loss_side.txt)
         if len(ts) <= 8:
             return K.loss_from_partials(ts, scales, float(len(ts)), host_cell=cell)
         # more terms than one launch takes: sums of groups of 8 first, then their mean

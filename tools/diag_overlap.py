@@ -213,6 +213,17 @@ def main():
         return 5 if (tabs[ph][tile % per_img] >> 31) & 1 else 4
 
     heights = np.array([[rows_of(g_, s_ & 1) for g_ in range(WG)] for s_ in range(nslots)])
+    # a workgroup's phases by tile height (layers 8+): does the 4-row tile, with 3 / 4 of the MFMAs, finish earlier?
+    for hgt in (5, 4):
+        sel_h = heights[16:] == hgt
+        seg = tt[16:]
+        w("  %d-row tiles (layers 8+, medians): entry -> first chunk landed %.2f us, K loop %.2f us (p10 %.2f, p90 %.2f), K loop done -> "
+          "drained %.2f us, lifetime %.2f us; enter %.2f us and drain %.2f us after their launch's first workgroup"
+          % (hgt, np.median((seg[:, :, 1] - seg[:, :, 0])[sel_h]), np.median((seg[:, :, 2] - seg[:, :, 1])[sel_h]),
+             np.percentile((seg[:, :, 2] - seg[:, :, 1])[sel_h], 10), np.percentile((seg[:, :, 2] - seg[:, :, 1])[sel_h], 90),
+             np.median((seg[:, :, 3] - seg[:, :, 2])[sel_h]), np.median((seg[:, :, 3] - seg[:, :, 0])[sel_h]),
+             np.median((seg[:, :, 0] - seg[:, :, 0].min(axis=1, keepdims=True))[sel_h]),
+             np.median((seg[:, :, 3] - seg[:, :, 0].min(axis=1, keepdims=True))[sel_h])))
     pairs = {"5+4": 0.0, "5+5": 0.0, "4+4": 0.0}
     for key in keys:
         sel = [(s_, g_) for s_, g_ in np.argwhere(cu_key == key)]
