@@ -147,6 +147,15 @@ def main():
                 continue
             rows.append((sel[:, 0].min(), sel[:, 0].max(), sel[:, 3].min(), sel[:, 3].max(), np.median(sel[:, 3] - sel[:, 0]),
                          np.median(sel[:, 2] - sel[:, 1]), len(sel), desc, sid))
+            if n > 1:   # a batched launch: its jobs enter in rounds -- do later rounds (warm instruction / scalar caches) start faster?
+                per_job = []
+                for jslot in range(s0, s0 + n):
+                    sj = st[jslot]
+                    sj = sj[sj[:, 0] > 0]
+                    per_job.append("job %d: enters %.1f..%.1f us, entry -> first chunk landed %.2f, K loop %.2f" % (
+                        jslot - s0, sj[:, 0].min() - st[s0:s0 + n][st[s0:s0 + n][:, :, 0] > 0][:, 0].min(), sj[:, 0].max() - st[s0:s0 + n][st[s0:s0 + n][:, :, 0] > 0][:, 0].min(),
+                        np.median(sj[:, 1] - sj[:, 0]), np.median(sj[:, 2] - sj[:, 1])))
+                wg_notes.append("%s: %s" % (desc, "; ".join(per_job)))
         else:
             sel = ws[s0]
             sel = sel[sel[:, 0] > 0]
