@@ -282,6 +282,11 @@ int larva_loss_from_partials(const float* const* terms, const int* count, const 
  * host_cell may be NULL (= larva_loss_from_partials).  larva_host_cell_free waits for the device before it frees. */
 int larva_loss_from_partials_to_host(const float* const* terms, const int* count, const float* scale, int n,
                                      float divisor, float* out, float* host_cell, void* stream);
+/* ... _seq: the same with the cell's sequence number ALSO kept in device memory (`dev_seq`, one zero-initialised
+ * unsigned owned by the caller, used by no other cell): the launch takes the number from there instead of reading the
+ * host cell back over PCIe before it can store (NULL = larva_loss_from_partials_to_host). */
+int larva_loss_from_partials_to_host_seq(const float* const* terms, const int* count, const float* scale, int n,
+                                         float divisor, float* out, float* host_cell, unsigned* dev_seq, void* stream);
 int larva_host_cell_alloc(float** cell);
 int larva_host_cell_free(float* cell);
 /* larva_l1_partial and larva_l1_bwd_unshuffle4 in one pass over (a, b), for a gradient value known

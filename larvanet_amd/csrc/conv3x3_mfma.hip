@@ -801,8 +801,11 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   // vmcnt(0) behind the K loop collects them.  kAuxLoads must not EXCEED the loads the compiler really emits between
   // chunk 1's pieces and the first wait (a smaller real count would let a wait pass with a piece still in flight):
   // tools/check_aux_loads.py counts them in the ISA of every instantiation.
+  // (not for the pixel-shuffle exits: their base / truth operands are 2 x 7 sixteen-byte loads per wave from the HR
+  // images, and requested late the batched L1 launch got SLOWER -- 66 against 58 us under rocprofv3, the exits' forward
+  // 120 against 112 us in the stamped step: they then queue in front of the loader wave's chunk-2 pieces)
   constexpr bool kAuxLate = LARVA_AUX_LATE && VEC && C::LOADER && C::NST == 3 && LARVA_AUX_EARLY && LARVA_PIXEL_MAJOR && !AUXLDS &&
-                            !(LARVA_DIAG & 6) && (NAUX > 0 || EPI == kEpiMaskBits);
+                            !kShuffleEpi && !(LARVA_DIAG & 6) && (NAUX > 0 || EPI == kEpiMaskBits);
   constexpr int kAuxLoads = kAuxLate ? (EPI == kEpiMaskBits ? 1 : NAUX) * NCT * NPG : 0;
   auto load_early = [&]() {
     load_bias();

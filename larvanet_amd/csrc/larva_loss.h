@@ -19,28 +19,45 @@ struct TermList {
 // pinned host memory that receives the value too -- the host polls it instead of synchronising with the stream
 // (larva_host_cell_alloc).  Every store bumps the sequence number and both words leave as ONE 8-byte store, so the
 // host can tell this launch's value from an earlier launch's (it counts its own launches).
+// dev_seq (may be null): the cell's sequence number kept in DEVICE memory as well (round 4): the launch then need not
+// read it back over PCIe first -- a ~3 us round trip in an 8.5 us launch that stands between the exits' forward and
+// their backward.
 __device__ __forceinline__ void loss_terms_block(const TermList& l, float divisor, float* __restrict__ out,
-                                                 float* __restrict__ host_cell = nullptr) {
-  __shared__ float ws[4];
-  // (the sequence number comes over PCIe: asked for first, needed last)
+                                                 float* __restrict__ host_cell = nullptr, unsigned* __restrict__ dev_seq = nullptr) {
+  // (without a device copy the sequence number comes over PCIe: asked for first, needed last)
   unsigned long long seq = 0ull;
-  if (host_cell && threadIdx.x == 0)
-    seq = __hip_atomic_load(reinterpret_cast<unsigned long long*>(host_cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> 32;
-  float total = 0.f;
-  for (int i = 0; i < l.n; ++i) {
-    float s = 0.f;
-    for (int k = threadIdx.x; k < l.count[i]; k += 256) s += l.p[i][k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-    __syncthreads();
-    total += ((ws[0] + ws[1]) + (ws[2] + ws[3])) * l.scale[i];
+  if (host_cell && threadIdx.x == 0) {
+    if (dev_seq) seq = dev_seq[0];
+    else seq = __hip_atomic_load(reinterpret_cast<unsigned long long*>(host_cell), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> 32;
   }
+  // every term's strided partial sums first (all their loads in flight together), then ONE pair of block barriers for
+  // all terms: per term the same additions in the same order as a loop of "sum, barrier, combine" (round 4: that loop
+  // took 8 us for four terms of 1024 partial sums, a dependent chain of four load latencies and eight barriers)
+  float sv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float s_ = 0.f;
+    if (i < l.n)
+      for (int k = threadIdx.x; k < l.count[i]; k += 256) s_ += l.p[i][k];
+    sv[i] = s_;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sv[i] += __shfl_xor(sv[i], o);
+  __shared__ float wsa[8][4];
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wsa[i][threadIdx.x >> 6] = sv[i];
+  }
+  __syncthreads();
+  float total = 0.f;
+  for (int i = 0; i < l.n; ++i) total += ((wsa[i][0] + wsa[i][1]) + (wsa[i][2] + wsa[i][3])) * l.scale[i];
   if (threadIdx.x == 0) {
     const float v = total / divisor;
     out[0] = v;
     if (host_cell) {
+      if (dev_seq) dev_seq[0] = (unsigned)(seq + 1ull);
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_cell),
                          ((seq + 1ull) << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_SYSTEM);

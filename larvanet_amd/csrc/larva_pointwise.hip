@@ -310,8 +310,8 @@ __global__ __launch_bounds__(256) void l1_partial_grad_batch_kernel(L1Jobs jobs,
 // reduced exactly like l1_finish_kernel does, the terms are added in index order: bit-identical
 // to l1_finish + sum_scalars, in one launch instead of n + 1.
 __global__ __launch_bounds__(256) void loss_from_partials_kernel(TermList l, float divisor, float* __restrict__ out,
-                                                                 float* __restrict__ host_cell) {
-  loss_terms_block(l, divisor, out, host_cell);
+                                                                 float* __restrict__ host_cell, unsigned* __restrict__ dev_seq) {
+  loss_terms_block(l, divisor, out, host_cell, dev_seq);
 }
 
 // out[0] = (t0 + t1 + ... ) / divisor over up to 8 device scalars, added in index order.
@@ -616,9 +616,9 @@ int larva_l1_partial_grad_batch(const float* const* a, const float* b, int n, fl
 // out[0] = ( sum_i scale[i] * (sum of count[i] floats at terms[i]) ) / divisor, n <= 8 terms; host_cell (may be
 // NULL, else from larva_host_cell_alloc) receives the same float and the next sequence number with one system-scope
 // 8-byte release store.
-int larva_loss_from_partials_to_host(const float* const* terms, const int* count, const float* scale, int n,
-                                     float divisor, float* out, float* host_cell, void* stream) {
-  if (!terms || !count || !scale || n < 1 || n > 8 || !out) return (int)hipErrorInvalidValue;
+int larva_loss_from_partials_to_host_seq(const float* const* terms, const int* count, const float* scale, int n,
+                                         float divisor, float* out, float* host_cell, unsigned* dev_seq, void* stream) {
+  if (!terms || !count || !scale || n < 1 || n > 8 || !out || (dev_seq && !host_cell)) return (int)hipErrorInvalidValue;
   TermList l{};
   for (int i = 0; i < n; ++i) {
     if (!terms[i] || count[i] < 1) return (int)hipErrorInvalidValue;
@@ -627,8 +627,13 @@ int larva_loss_from_partials_to_host(const float* const* terms, const int* count
     l.scale[i] = scale[i];
   }
   l.n = n;
-  hipLaunchKernelGGL(loss_from_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, l, divisor, out, host_cell);
+  hipLaunchKernelGGL(loss_from_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, l, divisor, out, host_cell, dev_seq);
   return (int)hipGetLastError();
+}
+
+int larva_loss_from_partials_to_host(const float* const* terms, const int* count, const float* scale, int n,
+                                     float divisor, float* out, float* host_cell, void* stream) {
+  return larva_loss_from_partials_to_host_seq(terms, count, scale, n, divisor, out, host_cell, nullptr, stream);
 }
 
 int larva_loss_from_partials(const float* const* terms, const int* count, const float* scale, int n,

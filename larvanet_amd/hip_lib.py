@@ -121,6 +121,8 @@ SIGNATURES = {
                                                    ctypes.c_int, ctypes.c_void_p]),
     "larva_loss_from_partials_to_host": (ctypes.c_int, [_c_pp, _c_int_p, _c_float_p, ctypes.c_int, ctypes.c_float,
                                                         _c_float_p, _c_float_p, ctypes.c_void_p]),
+    "larva_loss_from_partials_to_host_seq": (ctypes.c_int, [_c_pp, _c_int_p, _c_float_p, ctypes.c_int, ctypes.c_float,
+                                                            _c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
     "larva_host_cell_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "larva_host_cell_free": (ctypes.c_int, [_c_float_p]),
     "larva_loss_from_partials": (ctypes.c_int, [_c_pp, _c_int_p, _c_float_p, ctypes.c_int, ctypes.c_float,

@@ -706,6 +706,8 @@ class HostCell:
         self.ptr = int(p.value)
         self._cell = ctypes.c_uint64.from_address(self.ptr)
         self.expected = 0
+        # the sequence number in device memory as well: the storing launch reads it there instead of over PCIe
+        self.dev_seq = torch.zeros(1, dtype=torch.int32, device="cuda") if torch.cuda.is_available() else None
 
     def expect(self):
         """Call once per launch (or graph replay) that stores into the cell, before it is issued."""
@@ -750,10 +752,11 @@ def loss_from_partials(terms, scales, divisor, host_cell=None):
         counts.append(max(1, int(t.numel())))
     out = torch.empty((), device=terms[0].device, dtype=torch.float32)
     sc = (ctypes.c_float * len(terms))(*[float(v) for v in scales])
-    hip_lib.check(lib.larva_loss_from_partials_to_host(hip_lib.ptr_array(ptrs), hip_lib.int_array(counts), sc, len(terms),
-                                                       float(divisor), out.data_ptr(),
-                                                       host_cell.ptr if host_cell is not None else None, _stream()),
-                  "larva_loss_from_partials_to_host")
+    hip_lib.check(lib.larva_loss_from_partials_to_host_seq(
+        hip_lib.ptr_array(ptrs), hip_lib.int_array(counts), sc, len(terms), float(divisor), out.data_ptr(),
+        host_cell.ptr if host_cell is not None else None,
+        host_cell.dev_seq.data_ptr() if host_cell is not None and host_cell.dev_seq is not None else None, _stream()),
+        "larva_loss_from_partials_to_host")
     return out
 
 
