@@ -72,6 +72,9 @@
 #ifndef LARVA_AUX_LATE
 #define LARVA_AUX_LATE 1       // 0: the epilogue's operands requested in front of chunk 0's input pieces (rounds 1-3; A/B timing)
 #endif
+#ifndef LARVA_AUX_LATE_EXITS
+#define LARVA_AUX_LATE_EXITS 0 // 1: also the pixel-shuffle exits' base / truth operands behind chunk 1's pieces (measured slower)
+#endif
 #ifndef LARVA_PIN_SCALARS
 #define LARVA_PIN_SCALARS 1    // 0: the epilogue's H / W / pitch / plain_stores re-loaded from the kernarg segment (A/B timing)
 #endif
@@ -805,7 +808,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   // images, and requested late the batched L1 launch got SLOWER -- 66 against 58 us under rocprofv3, the exits' forward
   // 120 against 112 us in the stamped step: they then queue in front of the loader wave's chunk-2 pieces)
   constexpr bool kAuxLate = LARVA_AUX_LATE && VEC && C::LOADER && C::NST == 3 && LARVA_AUX_EARLY && LARVA_PIXEL_MAJOR && !AUXLDS &&
-                            !kShuffleEpi && !(LARVA_DIAG & 6) && (NAUX > 0 || EPI == kEpiMaskBits);
+                            (!kShuffleEpi || LARVA_AUX_LATE_EXITS) && !(LARVA_DIAG & 6) && (NAUX > 0 || EPI == kEpiMaskBits);
   constexpr int kAuxLoads = kAuxLate ? (EPI == kEpiMaskBits ? 1 : NAUX) * NCT * NPG : 0;
   auto load_early = [&]() {
     load_bias();
