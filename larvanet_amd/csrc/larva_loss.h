@@ -59,8 +59,11 @@ __device__ __forceinline__ void loss_terms_block(const TermList& l, float diviso
     if (host_cell) {
       if (dev_seq) dev_seq[0] = (unsigned)(seq + 1ull);
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_cell),
-                         ((seq + 1ull) << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELEASE,
+                         ((seq + 1ull) << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
+      // (relaxed on purpose: the cell IS the message -- value and sequence number leave as one 8-byte store and the host
+      // reads nothing else the device wrote.  A system-scope RELEASE store first writes the whole L2 back to memory,
+      // megabytes of the exits' outputs, which is most of what this launch used to take.)
     }
   }
 }
