@@ -1085,8 +1085,11 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     // tensor per layer: 15.3 vs 16.1 us).  The strip kernel takes the policy per launch
     // (k.plain): with two half-batch chains sharing the CUs, plain stores are 0.5 us per
     // layer faster in the FORWARD chain (the next layer reads the tensor at once: 14.2-14.5 ->
-    // 13.75-14.0 us, forward region of the step 604 -> 581 us) and 0.6 us per layer slower in the
-    // backward chain (same-box A/B of the step: 1.696 ms all-plain vs 1.688 all-non-temporal).
+    // 13.75-14.0 us, forward region of the step 604 -> 581 us); in the backward chain they were 0.6 us per layer
+    // slower in round 2 (step 1.696 ms all-plain vs 1.688) and are FASTER with round 4's kernels (1.634-1.641 ms all-plain,
+    // 1.648-1.650 forward only, 1.657-1.660 all-non-temporal: profiles/r04_ab_strip_plain.txt) -- the caller's default
+    // (autograd.DualChain.plain_stores) is now `all`.  The 48-column tiles were re-measured too and stay non-temporal
+    // (LARVA_WIDE_PLAIN, profiles/r04_ab_wide_plain.txt).
     const size_t plane = (size_t)k.H * k.pitch;
     auto store_all = [&](auto plain_tag) {
       constexpr bool kPlain = decltype(plain_tag)::value;
