@@ -476,7 +476,8 @@ def wgrad_block(dev, c=CH, jobs=40, iters=10):
         runs.append(s.elapsed_time(e) / iters)
     ms = sorted(runs)[1]
     achieved = conv_flop(c) * nlayers / (ms * 1e-3) / 1e12
-    kernel = ("wgrad3x3_pipe_flat_kernel<%d, %d> (one grid of 256 workgroups over %d layers) + wgrad_reduce_kernel" % (c, c, nlayers)
+    kernel = (("wgrad3x3_pipe_flat_kernel<64, 32>, two passes over 32 input channels each per workgroup and layer" if c == 64 else
+               "wgrad3x3_pipe_flat_kernel<%d, %d>" % (c, c)) + " (one grid of 256 workgroups over %d layers) + wgrad_reduce_kernel" % nlayers
               if flat else "wgrad3x3 kernel for (%d, %d) + wgrad_reduce_kernel, 32 layers x %d workgroups" % (c, c, 8 * K.wgrad_cu_share(c, c)))
     blk = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "kernel": kernel + ", 16x%dx48x48 fp32" % c, "layers": nlayers,

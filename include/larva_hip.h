@@ -201,7 +201,8 @@ int larva_conv3x3_wgrad(const float* const* dy, const float* const* x, float* co
 
 /* Phase 1 as ONE grid of nwg workgroups over all njobs (<= 64) layers: their tiles form one sequence
  * cut evenly over the workgroups (no CU idles at any layer count; a workgroup whose share crosses a
- * layer boundary contributes a partial image to both layers).  48 -> 48 channels, W % 4 == 0, 16-byte
+ * layer boundary contributes a partial image to both layers).  48 -> 48, 32 -> 32 or 64 -> 64 channels (the last
+ * as two passes over 32 input channels each per workgroup and layer), W % 4 == 0, 16-byte
  * aligned tensors (hipErrorNotSupported otherwise).  splits_out[i] = partial images of layer i for
  * larva_wgrad_reduce; partial[i] holds larva_wgrad_flat_max_splits(njobs, nwg, tiles per layer) images
  * (tiles per layer = N * ceil(H/3) * ceil(W/48)). */

@@ -68,6 +68,10 @@ struct WgradBatch {
   WgradJob head;
   int head_units;       // 0: no head job
   int head_first_wg;    // the first workgroup whose share reaches into the head
+  // pipelined kernels only (round 4): x has halves * CIN channels and a workgroup walks its tiles once per half -- a
+  // (64, 64) layer, whose two tile buffers (217 KB) do not fit the LDS, runs as two (64, 32) passes into ONE partial
+  // image of the (64, 64) layout ((ci group, tap) operands 18 h .. 18 h + 17 come from pass h).  0 / 1: one pass.
+  int halves;
 #if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
   unsigned long long* diag_area;   // stamp area of this launch (tools/diag_step.py), null: none
 #endif
@@ -651,10 +655,27 @@ __device__ __forceinline__ void pipe_first_tile(const WgradBatch& b, const PipeG
   }
 }
 
-// Tiles [t_begin, t_end) of layer `j` -> the partial image at `part`.
+// One pass of the pipelined kernel over a layer: CIN of the x tensor's channels (x already points at the first of them,
+// x_nstride = floats per image of x) against all of dy.
+struct PipeSeg {
+  const float* dy;
+  const float* x;
+  size_t x_nstride;
+  float* part_w;   // this pass's (ci group, tap) operands of the partial image
+  float* part_b;   // the image's bias sums; null: another pass writes them
+};
+
+__device__ __forceinline__ PipeSeg pipe_seg(const WgradBatch& b, const WgradJob& j, float* image, int cin, int nb_ct_floats,
+                                            int h, int halves) {
+  const size_t plane = (size_t)b.H * b.W;
+  return PipeSeg{j.dy, j.x + (size_t)h * cin * plane, (size_t)cin * halves * plane, image + (size_t)h * nb_ct_floats,
+                 h == 0 ? image + (size_t)halves * nb_ct_floats : nullptr};
+}
+
+// Tiles [t_begin, t_end) of one pass -> its part of the partial image.
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV>
-__device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob& j, float* smem, int t_begin,
-                                             int t_end, float* part, int tid) {
+__device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const PipeSeg& j, float* smem, int t_begin,
+                                             int t_end, int tid) {
   using C = WgCfg<COUT, CIN>;
   using P = WgPipe<COUT, CIN>;
   const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
@@ -679,7 +700,7 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob
   auto tile_at = [&]() {
     PipeTile t;
     t.dyimg = j.dy + (size_t)n * COUT * plane;
-    t.ximg = j.x + (size_t)n * CIN * plane;
+    t.ximg = j.x + (size_t)n * j.x_nstride;
     t.y0 = ty * kTileRows;
     t.x0 = tx * kTileCols;
     t.org = t.y0 * b.W + t.x0;
@@ -729,27 +750,44 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const WgradJob
   for (int c = 0; c < C::CT; ++c)
 #pragma unroll
     for (int k = 0; k < NBW; ++k)
-      *reinterpret_cast<f32x4*>(part + (((B0 + k) * C::CT + c) * 64 + lane) * 4) = acc[c][k];
+      *reinterpret_cast<f32x4*>(j.part_w + (((B0 + k) * C::CT + c) * 64 + lane) * 4) = acc[c][k];
   if constexpr (BIAS) {  // column 0 of the bias accumulators: lane 16*lq holds co = 16c + 4lq + r
-    if (lr == 0) {
+    if (lr == 0 && j.part_b) {
 #pragma unroll
-      for (int c = 0; c < C::CT; ++c)
-        *reinterpret_cast<f32x4*>(part + C::NB * C::CT * 256 + c * 16 + 4 * lq) = bacc[c];
+      for (int c = 0; c < C::CT; ++c) *reinterpret_cast<f32x4*>(j.part_b + c * 16 + 4 * lq) = bacc[c];
     }
   }
 }
 
 template <int COUT, int CIN>
-__device__ __forceinline__ void wg_pipe_waves(const WgradBatch& b, const WgradJob& j, float* smem, int t_begin, int t_end,
-                                              float* part, int tid, int wave) {
+__device__ __forceinline__ void wg_pipe_pass(const WgradBatch& b, const PipeSeg& j, float* smem, int t_begin, int t_end,
+                                             int tid, int wave) {
   using C = WgCfg<COUT, CIN>;
   constexpr int NB = C::NB;
   constexpr int W0 = (NB + 3) / 4, W1 = (NB + 2) / 4, W2 = (NB + 1) / 4, W3 = NB / 4;
   // the bias sums ride on the last wave: it owns the fewest (ci group, tap) operands
-  if (wave == 0) wg_role_pipe<COUT, CIN, 0, W0, false, 0>(b, j, smem, t_begin, t_end, part, tid);
-  else if (wave == 1) wg_role_pipe<COUT, CIN, W0, W1, false, 1>(b, j, smem, t_begin, t_end, part, tid);
-  else if (wave == 2) wg_role_pipe<COUT, CIN, W0 + W1, W2, false, 2>(b, j, smem, t_begin, t_end, part, tid);
-  else wg_role_pipe<COUT, CIN, W0 + W1 + W2, W3, true, 3>(b, j, smem, t_begin, t_end, part, tid);
+  if (wave == 0) wg_role_pipe<COUT, CIN, 0, W0, false, 0>(b, j, smem, t_begin, t_end, tid);
+  else if (wave == 1) wg_role_pipe<COUT, CIN, W0, W1, false, 1>(b, j, smem, t_begin, t_end, tid);
+  else if (wave == 2) wg_role_pipe<COUT, CIN, W0 + W1, W2, false, 2>(b, j, smem, t_begin, t_end, tid);
+  else wg_role_pipe<COUT, CIN, W0 + W1 + W2, W3, true, 3>(b, j, smem, t_begin, t_end, tid);
+}
+
+// Tiles [t_begin, t_end) of layer `j` -> the partial image at `image`: one pass per half of x's channels.
+template <int COUT, int CIN>
+__device__ __forceinline__ void wg_pipe_waves(const WgradBatch& b, const WgradJob& j, float* smem, int t_begin, int t_end,
+                                              float* image, int tid, int wave) {
+  using C = WgCfg<COUT, CIN>;
+  const int halves = b.halves > 1 ? b.halves : 1;   // (uniform)
+  for (int h = 0; h < halves; ++h) {
+    if (h) __syncthreads();   // every wave is done with the tile buffers before the next pass restages them
+    wg_pipe_pass<COUT, CIN>(b, pipe_seg(b, j, image, CIN, C::NB * C::CT * 256, h, halves), smem, t_begin, t_end, tid, wave);
+  }
+}
+
+// floats of one partial image of a launch whose x tensors have halves * CIN channels
+template <int COUT, int CIN>
+__device__ __forceinline__ int pipe_image_floats(const WgradBatch& b) {
+  return WgCfg<COUT, CIN>::NB * WgCfg<COUT, CIN>::CT * 256 * (b.halves > 1 ? b.halves : 1) + COUT;
 }
 
 template <int COUT, int CIN>
@@ -764,7 +802,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_kernel(WgradBatch b) {
   // (64-bit divisions run on the vector ALU: bring the wave-uniform results back to SGPRs)
   const int t_begin = __builtin_amdgcn_readfirstlane((int)(((long long)total * split) / splits));
   const int t_end = __builtin_amdgcn_readfirstlane((int)(((long long)total * (split + 1)) / splits));
-  wg_pipe_waves<COUT, CIN>(b, j, smem, t_begin, t_end, j.partial + (size_t)split * C::PARTIAL_FLOATS, tid, wave);
+  wg_pipe_waves<COUT, CIN>(b, j, smem, t_begin, t_end, j.partial + (size_t)split * pipe_image_floats<COUT, CIN>(b), tid, wave);
 }
 
 // One grid over ALL layers of a launch: the njobs x (tiles per layer) tiles form one sequence, workgroup w
@@ -793,7 +831,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_flat_kernel(WgradBatch b
     const int base = jb * total;
     const int seg_end = min(g_end, base + total);
     const WgradJob& j = b.job[jb];
-    float* part = j.partial + (size_t)(w - b.first_wg[jb]) * C::PARTIAL_FLOATS;
+    float* part = j.partial + (size_t)(w - b.first_wg[jb]) * pipe_image_floats<COUT, CIN>(b);
     wg_pipe_waves<COUT, CIN>(b, j, smem, g - base, seg_end - base, part, tid, wave);
     __syncthreads();    // every wave is done with the tile buffers before the next layer restages them
     g = seg_end;
@@ -994,10 +1032,31 @@ static bool wgrad_use_pipe() {
   return on;
 }
 
+// How a (COUT, CIN) layer gets onto the pipelined kernel: 1 = as it is, 2 = as two passes over 32 input channels each
+// ((64, 64) and the 64-filter legs' (48, 64): two tile buffers of the whole layer do not fit the LDS), 0 = not at all.
+template <int COUT, int CIN>
+constexpr int kPipeHalves = WgPipe<COUT, CIN>::FITS ? 1 : ((CIN == 64 && WgPipe<COUT, 32>::FITS) ? 2 : 0);
+
 template <int COUT, int CIN>
 static hipError_t launch_wgrad(const WgradBatch& b, int njobs, int splits, hipStream_t stream) {
   using C = WgCfg<COUT, CIN>;
   using P = WgPipe<COUT, CIN>;
+  if constexpr (kPipeHalves<COUT, CIN> == 2) {
+    if (b.vec_ok && wgrad_use_pipe()) {
+      using P2 = WgPipe<COUT, CIN / 2>;
+      static bool attr2_set = false;
+      if (!attr2_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_pipe_kernel<COUT, CIN / 2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P2::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr2_set = true;
+      }
+      WgradBatch b2 = b;
+      b2.halves = 2;
+      hipLaunchKernelGGL((wgrad3x3_pipe_kernel<COUT, CIN / 2>), dim3(splits, njobs), dim3(256), P2::LDS_BYTES, stream, b2);
+      return hipGetLastError();
+    }
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, true>),
@@ -1047,7 +1106,7 @@ using namespace larva;
 
 extern "C" {
 
-// Phase 1 as ONE grid of `nwg` workgroups over all njobs (<= 64) layers (48 -> 48 channels, W % 4 == 0,
+// Phase 1 as ONE grid of `nwg` workgroups over all njobs (<= 64) layers (48 -> 48, 32 -> 32 or 64 -> 64 channels, W % 4 == 0,
 // 16-byte aligned tensors; hipErrorNotSupported otherwise: use larva_conv3x3_wgrad_partial).  The layers'
 // tiles form one sequence cut evenly over the workgroups; a workgroup whose share crosses a layer boundary
 // contributes a partial image to both layers.  splits_out[i] = the number of partial images of layer i
@@ -1072,7 +1131,8 @@ static int wgrad_flat_impl(const float* const* dy, const float* const* x, float*
                            int cin, int H, int W, int* splits_out, int* head_splits_out, void* stream) {
   if (njobs < 1 || njobs > kMaxJobs || nwg < 1 || nwg > 32767 || N <= 0 || H <= 0 || W <= 0 || !splits_out)
     return (int)hipErrorInvalidValue;
-  if (!((cout == 48 && cin == 48) || (cout == 32 && cin == 32)) || W % 4 || !wgrad_use_pipe()) return (int)hipErrorNotSupported;
+  if (!((cout == 48 && cin == 48) || (cout == 32 && cin == 32) || (cout == 64 && cin == 64)) || W % 4 || !wgrad_use_pipe())
+    return (int)hipErrorNotSupported;
   const bool head = head_dy || head_x16 || head_partial;
   if (head && cout != 48) return (int)hipErrorNotSupported;   // (the head's tail role is priced for the 48-channel grid)
   if (head && (!head_dy || !head_x16 || !head_partial || !head_splits_out)) return (int)hipErrorInvalidValue;
@@ -1119,6 +1179,10 @@ static int wgrad_flat_impl(const float* const* dy, const float* const* x, float*
   b.diag_area = (g_wdiag_base && g_wdiag_next >= 0 && g_wdiag_next < g_wdiag_cap) ? g_wdiag_base + (size_t)(g_wdiag_next++) * 256 * 4 : nullptr;
 #endif
   if (cout == 32) return (int)launch_wgrad_flat<32, 32>(b, nwg, (hipStream_t)stream);
+  if (cout == 64) {   // two (64, 32) passes per workgroup and layer
+    b.halves = 2;
+    return (int)launch_wgrad_flat<64, 32>(b, nwg, (hipStream_t)stream);
+  }
   return (int)launch_wgrad_flat<48, 48>(b, nwg, (hipStream_t)stream);
 }
 

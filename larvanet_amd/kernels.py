@@ -489,12 +489,12 @@ def conv3x3_wgrad_partial(jobs, cout, cin, splits):
 
 
 def conv3x3_wgrad_partial_flat(jobs, cout, cin, nwg, head=None):
-    """Phase 1 of ALL jobs (<= 64 dicts {dy, x}, 48 -> 48 channels) as one grid of `nwg` workgroups ->
+    """Phase 1 of ALL jobs (<= 64 dicts {dy, x}; 48 -> 48, 32 -> 32 or 64 -> 64 channels) as one grid of `nwg` workgroups ->
     (partial tensors, [partial images per job]) or None when the flat launch does not apply.  head: one more dict
     {dy [N][48][H][W], x [N][16][H][W]} -- the 3 -> 48 head on its padded input -- whose tiles the last workgroups of
     the same grid take; the result then ends with that job's partial tensor / image count."""
     lib = hip_lib.load()
-    if not 1 <= len(jobs) <= 64 or (cout, cin) not in ((48, 48), (32, 32)) or (head is not None and cout != 48):
+    if not 1 <= len(jobs) <= 64 or (cout, cin) not in ((48, 48), (32, 32), (64, 64)) or (head is not None and cout != 48):
         return None
     N, _, H, W = (int(v) for v in jobs[0]["dy"].shape)
     if W % 4:
