@@ -40,6 +40,14 @@
 #ifndef WG_ASM_MFMA
 #define WG_ASM_MFMA 1   // 1: the pipelined kernel's MFMAs are inline asm with the accumulator tied in an AGPR
 #endif
+// Operand RUNS in the pipelined kernel (round 4; WgPipe::RUNS): 0 off, 1 for the shapes whose lightest wave has fewer
+// than 17 MFMAs per k-step ((32,32), (64,32), (48,32)), 2 for (48,48) too.
+#ifndef WG_RUNS
+#define WG_RUNS 1
+#endif
+#ifndef WG_MIN_GAPS
+#define WG_MIN_GAPS 6   // MFMAs per k-step of its lightest wave below which a shape stays off the pipelined kernel ((48,16): 6)
+#endif
 
 
 namespace larva {
@@ -100,9 +108,11 @@ __device__ __forceinline__ void wstamp(unsigned long long* area, int k) {
 // but two workgroup barriers and an exposed LDS write per tile -- measured 0.58 of the time (same-box builds with
 // the price at 0.4 / 0.5 / 0.6 / 0.7: step 1.835 / 1.709 / 1.636 / 1.634 ms: under-priced, the workgroups whose whole
 // share is head tiles finish last and set the launch's duration).  Priced at 0.7: finishing early costs a fraction
-// of one CU.
+// of one CU.  Round 4: the tail runs the PIPELINED role at 16 input channels (6-9 MFMAs per k-step, operand runs):
+// 0.47 of a (48, 48) tile launched on its own (tools/bench_wgrad_head.py, 0.55 register-staged on the same box);
+// priced at 0.6.
 #ifndef LARVA_HEAD_COST10
-#define LARVA_HEAD_COST10 7
+#define LARVA_HEAD_COST10 6
 #endif
 __host__ __device__ constexpr int flat_head_units(int tiles) { return (tiles * LARVA_HEAD_COST10 + 9) / 10; }
 
@@ -350,8 +360,6 @@ __device__ __attribute__((aligned(16))) float g_wg_zero_page[4] = {0.f, 0.f, 0.f
 template <int COUT, int CIN>
 struct WgPipe {
   using C = WgCfg<COUT, CIN>;
-  static constexpr int BUF_FLOATS = C::DY_FLOATS + C::X_FLOATS;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_FLOATS * sizeof(float);
   static constexpr int NSLOT = C::DY_ITERS + C::X_ITERS;
 #ifdef WG_LAG
   static constexpr int LAG = WG_LAG;   // experiment: load -> LDS-write distance in k-steps
@@ -366,7 +374,26 @@ struct WgPipe {
   // (32,32), 8-10 MFMAs) they are dealt evenly over the gaps there are, up to two per gap (gap_of in pipe_gap_asm) --
   // an MFMA's shadow holds ~24 issue cycles, a filler costs 4-16.
   static constexpr bool SPREAD = MIN_GAPS >= 17;
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NSLOT + LAG <= 36 && MIN_GAPS >= 8;
+  // Operand runs (round 4).  The K index of an MFMA (lane quarter lq) is free to mean any pixel as long as A and B agree.
+  // Until round 3 k-step ks of a tile row covered pixels 4 ks' .. 4 ks' + 3 (ks' = ks % 12), lane quarter lq pixel
+  // 4 ks' + lq: a lane's operands of successive k-steps lie 16 bytes apart and every one is a 4-byte LDS read -- CT + NBW
+  // reads per k-step beside CT * NBW MFMAs, which at 8-10 MFMAs per k-step ((32,32)) no longer fit the MFMAs' shadows
+  // (0.60 of peak against (48,48)'s 0.81).  With RUNS lane quarter lq owns the twelfth-of-a-tile-row run of pixels
+  // 12 lq .. 12 lq + 11 and k-step ks' takes pixel 12 lq + ks' of it: the dy operands of FOUR successive k-steps are one
+  // 16-byte read, and the x operands of a (ci group, ky) row for all three kx and twelve k-steps are the 14 floats
+  // 12 lq - 1 .. 12 lq + 12 = three 16-byte reads + two edge floats, kept in registers and addressed by compile-time
+  // element indices: 1.5-2 reads per k-step instead of 7-10.  Same products, another summation order.
+  // 16-byte aligned channel strides (4 x odd: the 16 lanes of a quarter hit 16 x 4 distinct banks) where two tile
+  // buffers still fit; else the old strides with 8-byte aligned 16-byte reads (ds_read2_b64).
+  static constexpr bool RUNS = WG_ASM_MFMA && !WG_DIAG && (WG_RUNS == 2 || (WG_RUNS == 1 && !SPREAD));
+  static constexpr bool ALIGNED = RUNS && 2 * (size_t)(COUT * 148 + CIN * 284 + 8) * sizeof(float) <= 160 * 1024;
+  static constexpr int PSD = ALIGNED ? 148 : C::PSD;
+  static constexpr int PSX = ALIGNED ? 284 : C::PSX;
+  static constexpr int DY_FLOATS = COUT * PSD;
+  static constexpr int X_FLOATS = CIN * PSX + 8;
+  static constexpr int BUF_FLOATS = DY_FLOATS + X_FLOATS;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_FLOATS * sizeof(float);
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NSLOT + LAG <= 36 && MIN_GAPS >= WG_MIN_GAPS;
 };
 
 // Per-thread, tile-invariant description of staging slot I: element offset of its 16 bytes
@@ -390,7 +417,7 @@ __device__ __forceinline__ void pipe_geom_slot(PipeGeom<COUT, CIN>& g, int tid, 
     const int r = rem / 12;
     const int q = rem - r * 12;
     g.goff[I] = co * plane + r * W + 4 * q;
-    g.pos[I] = (co * C::PSD + r * kTileCols + 4 * q) | (r << 16) | ((4 * q) << 20) | (live ? 0 : (1 << 30));
+    g.pos[I] = (co * WgPipe<COUT, CIN>::PSD + r * kTileCols + 4 * q) | (r << 16) | ((4 * q) << 20) | (live ? 0 : (1 << 30));
   } else {
     int s = tid + (I - C::DY_ITERS) * 256;
     const bool live = s < C::X_SLOTS;
@@ -400,7 +427,8 @@ __device__ __forceinline__ void pipe_geom_slot(PipeGeom<COUT, CIN>& g, int tid, 
     const int r = rem / 14;
     const int q = rem - r * 14;
     g.goff[I] = ci * plane + (r - 1) * W + 4 * q - 4;
-    g.pos[I] = (C::DY_FLOATS + ci * C::PSX + r * kRS + 4 * q) | (r << 16) | ((4 * q) << 20) | (live ? 0 : (1 << 30));
+    g.pos[I] = (WgPipe<COUT, CIN>::DY_FLOATS + ci * WgPipe<COUT, CIN>::PSX + r * kRS + 4 * q) | (r << 16) | ((4 * q) << 20) |
+               (live ? 0 : (1 << 30));
   }
 }
 
@@ -445,14 +473,51 @@ __device__ __forceinline__ void pipe_lds_write(const PipeGeom<COUT, CIN>& g, flo
   using C = WgCfg<COUT, CIN>;
   constexpr int slots = (I < C::DY_ITERS) ? C::DY_SLOTS : C::X_SLOTS;
   constexpr int i = (I < C::DY_ITERS) ? I : I - C::DY_ITERS;
+  auto put = [&]() {
+    if constexpr (WgPipe<COUT, CIN>::ALIGNED) *reinterpret_cast<f32x4*>(buf + (g.pos[I] & 0xffff)) = v;   // one ds_write_b128
+    else lds_store4(buf + (g.pos[I] & 0xffff), v);
+  };
   if constexpr (i * 256 + 255 < slots) {
-    lds_store4(buf + (g.pos[I] & 0xffff), v);
+    put();
   } else {  // only some threads own a slot in the last round
-    if (!(g.pos[I] >> 30)) lds_store4(buf + (g.pos[I] & 0xffff), v);
+    if (!(g.pos[I] >> 30)) put();
   }
 }
 
-template <int COUT, int CIN, int NBW>
+// Operand runs of one wave (WgPipe::RUNS): the (ci group, ky) rows its (ci group, tap) operands B0 .. B0 + NBW - 1 touch
+// are groups GF .. GF + NG - 1 (group = ci group * 3 + ky).  Per tile row (double-buffered by row parity) and group: the 14
+// floats at run positions -1 .. 12 -- eL, three 16-byte windows, eR; per quad of k-steps (double-buffered by quad
+// parity) and output-channel group: the four dy operands.
+template <int B0, int NBW>
+struct RunGroups {
+  static constexpr int GF = B0 / 3;
+  static constexpr int NG = (B0 + NBW - 1) / 3 - GF + 1;
+};
+
+template <int CT, int NG>
+struct RunOps {
+  f32x4 aq[2][CT];
+  float eL[2][NG];
+  f32x4 w[2][NG][3];
+  float eR[2][NG];
+};
+
+// Reads of quad Q (k-steps 4 Q .. 4 Q + 3; tile row Q / 3, third t = Q % 3 of the runs) in issue order: the CT dy
+// quads of quad Q + 1, then per group -- t = 0: window 2 of this row; t = 1: eR of this row; t = 2: eL and windows
+// 0, 1 of the NEXT row (what its first quad needs).  They are dealt over the quad's first three k-steps, so that the
+// youngest has a k-step's MFMAs to land under.
+template <int CT, int NG>
+struct RunPlan {
+  static constexpr int n(int Q) { return (Q < 8 ? CT : 0) + (Q % 3 < 2 ? NG : (Q / 3 < 2 ? 3 * NG : 0)); }
+  static constexpr int first(int Q, int e) {   // the first read of quad Q issued in its k-step e or later
+    int i = 0;
+    while (i < n(Q) && i * 3 / n(Q) < e) ++i;
+    return i;
+  }
+  static constexpr int count(int Q, int e) { return e >= 3 ? 0 : first(Q, e + 1) - first(Q, e); }
+};
+
+template <int COUT, int CIN, int NBW, int NG>
 struct PipeCtx {
   const WgradBatch& b;
   const PipeGeom<COUT, CIN>& g;
@@ -466,7 +531,76 @@ struct PipeCtx {
   f32x4 (&acc)[COUT / 16][NBW];
   f32x4 (&bacc)[COUT / 16];   // BIAS wave: rows = co, every column = sum over pixels of dy
   float one;                   // 1.0f in a VGPR (B operand of the bias MFMAs in the asm form)
+  RunOps<COUT / 16, NG>& ro;   // WgPipe::RUNS: the operand runs and this lane's run bases in the current buffer
+  const float* ra;
+  const float* rb;
 };
+
+// 16 bytes of LDS at a float index that is a multiple of 4 (ALIGNED strides: one ds_read_b128) or of 2 (ds_read2_b64)
+template <bool ALIGNED>
+__device__ __forceinline__ f32x4 lds_load4(const float* p) {
+  if constexpr (ALIGNED) {
+    return *reinterpret_cast<const f32x4*>(p);
+  } else {
+    typedef float f32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+    return *reinterpret_cast<const f32x4a8*>(p);
+  }
+}
+
+// Read I of quad Q (RunPlan's order).  ra = this lane's dy run base (buffer + lr * PSD + 12 lq), rb = its x run base
+// (x part + lr * PSX + 12 lq + 4: run position 0 = the pixel under the tap centre).
+template <int COUT, int CIN, int B0, int NBW, int Q, int I>
+__device__ __forceinline__ void run_read(RunOps<COUT / 16, RunGroups<B0, NBW>::NG>& o, const float* ra, const float* rb) {
+  using P = WgPipe<COUT, CIN>;
+  using G = RunGroups<B0, NBW>;
+  constexpr int CT = COUT / 16, t = Q % 3, row = Q / 3, NA = Q < 8 ? CT : 0;
+  if constexpr (I < NA) {
+    constexpr int q1 = Q + 1;
+    o.aq[q1 & 1][I] = lds_load4<P::ALIGNED>(ra + I * 16 * P::PSD + (q1 / 3) * kTileCols + 4 * (q1 % 3));
+  } else {
+    constexpr int J = I - NA;
+    constexpr int gi = t < 2 ? J : J / 3, gg = G::GF + gi, cit = gg / 3, ky = gg % 3;
+    if constexpr (t == 0) {
+      o.w[row & 1][gi][2] = lds_load4<P::ALIGNED>(rb + cit * 16 * P::PSX + (row + ky) * kRS + 8);
+    } else if constexpr (t == 1) {
+      o.eR[row & 1][gi] = rb[cit * 16 * P::PSX + (row + ky) * kRS + 12];
+    } else {
+      constexpr int r2 = row + 1, what = J % 3;
+      const float* p = rb + cit * 16 * P::PSX + (r2 + ky) * kRS;
+      if constexpr (what == 0) o.eL[r2 & 1][gi] = p[-1];
+      else o.w[r2 & 1][gi][what - 1] = lds_load4<P::ALIGNED>(p + 4 * (what - 1));
+    }
+  }
+}
+
+// What the first quad of a tile needs, read behind the tile barrier: the dy quads of quad 0, eL and windows 0, 1 of row 0.
+template <int COUT, int CIN, int B0, int NBW>
+__device__ __forceinline__ void run_prime(RunOps<COUT / 16, RunGroups<B0, NBW>::NG>& o, const float* ra, const float* rb) {
+  using P = WgPipe<COUT, CIN>;
+  using G = RunGroups<B0, NBW>;
+#pragma unroll
+  for (int c = 0; c < COUT / 16; ++c) o.aq[0][c] = lds_load4<P::ALIGNED>(ra + c * 16 * P::PSD);
+#pragma unroll
+  for (int gi = 0; gi < G::NG; ++gi) {
+    const int gg = G::GF + gi, cit = gg / 3, ky = gg % 3;
+    const float* p = rb + cit * 16 * P::PSX + ky * kRS;
+    o.eL[0][gi] = p[-1];
+    o.w[0][gi][0] = lds_load4<P::ALIGNED>(p);
+    o.w[0][gi][1] = lds_load4<P::ALIGNED>(p + 4);
+  }
+}
+
+// The operands of k-step KS: dy of output-channel group c / x of (ci group, tap) operand B0 + k.
+template <int CT, int NG, int KS, int C_>
+__device__ __forceinline__ float run_a(const RunOps<CT, NG>& o) { return o.aq[(KS / 4) & 1][C_][KS % 4]; }
+
+template <int B0, int NBW, int CT, int KS, int K>
+__device__ __forceinline__ float run_b(const RunOps<CT, RunGroups<B0, NBW>::NG>& o) {
+  constexpr int bi = B0 + K, gi = bi / 3 - RunGroups<B0, NBW>::GF, kx = bi % 3, row = KS / 12, rel = KS % 12 + kx - 1;
+  if constexpr (rel < 0) return o.eL[row & 1][gi];
+  else if constexpr (rel >= 12) return o.eR[row & 1][gi];
+  else return o.w[row & 1][gi][rel / 4][rel % 4];
+}
 
 // k-step KS of the pipelined tile loop: one scheduling region holding the step's MFMAs, the
 // operand reads of step KS+1, the address arithmetic + global load of staging slot KS and the LDS
@@ -476,7 +610,7 @@ struct PipeCtx {
 // too: CT extra MFMAs per k-step against an all-ones B operand, so that no wave issues VALU adds
 // and all four carry the same number of MFMAs.
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS>
-__device__ __forceinline__ void pipe_kstep_builtin(PipeCtx<COUT, CIN, NBW>& x) {
+__device__ __forceinline__ void pipe_kstep_builtin(PipeCtx<COUT, CIN, NBW, RunGroups<B0, NBW>::NG>& x) {
   using C = WgCfg<COUT, CIN>;
   using P = WgPipe<COUT, CIN>;
   __builtin_amdgcn_sched_barrier(0);
@@ -548,7 +682,7 @@ __host__ __device__ constexpr int gap_of(int e) {
 }
 
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS, int M, int E>
-__device__ __forceinline__ void pipe_gap_events(PipeCtx<COUT, CIN, NBW>& x, int& gy, int& gx, uint64_t& addr) {
+__device__ __forceinline__ void pipe_gap_events(PipeCtx<COUT, CIN, NBW, RunGroups<B0, NBW>::NG>& x, int& gy, int& gx, uint64_t& addr) {
   using C = WgCfg<COUT, CIN>;
   using P = WgPipe<COUT, CIN>;
   constexpr int G0 = C::CT + NBW;
@@ -578,17 +712,54 @@ __device__ __forceinline__ void pipe_gap_events(PipeCtx<COUT, CIN, NBW>& x, int&
   }
 }
 
-template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS, int M>
-__device__ __forceinline__ void pipe_gap_asm(PipeCtx<COUT, CIN, NBW>& x, int& gy, int& gx, uint64_t& addr) {
+// The same walk with operand runs: the k-step's events are the reads RunPlan deals to it, then the four staging events.
+template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS, int M, int E>
+__device__ __forceinline__ void pipe_gap_events_runs(PipeCtx<COUT, CIN, NBW, RunGroups<B0, NBW>::NG>& x, int& gy, int& gx, uint64_t& addr) {
   using C = WgCfg<COUT, CIN>;
+  using P = WgPipe<COUT, CIN>;
+  using PL = RunPlan<C::CT, RunGroups<B0, NBW>::NG>;
+  constexpr int Q = KS / 4, e = KS % 4;
+  constexpr int G0 = PL::count(Q, e);
+  constexpr int NG = C::CT * NBW + (BIAS ? C::CT : 0);
+  if constexpr (E < G0 + 4) {
+    if constexpr (E * NG / (G0 + 4) == M) {
+      if constexpr (E < G0) {
+        run_read<COUT, CIN, B0, NBW, Q, PL::first(Q, e) + E>(x.ro, x.ra, x.rb);
+      } else if constexpr (E == G0 + 3) {
+        constexpr bool kWrites = KS >= P::LAG && KS - P::LAG < P::NSLOT;
+        if constexpr (kWrites) pipe_lds_write<COUT, CIN, KS - P::LAG>(x.g, x.nxt, x.stage[KS - P::LAG]);
+      } else if constexpr (KS < P::NSLOT) {
+        if constexpr (E == G0) pipe_addr_a<COUT, CIN, KS>(x.g, x.next, gy, gx);
+        if constexpr (E == G0 + 1) addr = pipe_addr_b<COUT, CIN, KS>(x.g, x.next, x.b, gy, gx);
+        if constexpr (E == G0 + 2) x.stage[KS] = *reinterpret_cast<const f32x4*>(addr);
+      }
+    }
+    pipe_gap_events_runs<COUT, CIN, B0, NBW, BIAS, WV, KS, M, E + 1>(x, gy, gx, addr);
+  }
+}
+
+template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS, int M>
+__device__ __forceinline__ void pipe_gap_asm(PipeCtx<COUT, CIN, NBW, RunGroups<B0, NBW>::NG>& x, int& gy, int& gx, uint64_t& addr) {
+  using C = WgCfg<COUT, CIN>;
+  using P = WgPipe<COUT, CIN>;
   constexpr int NMAIN = C::CT * NBW;
+  if constexpr (P::RUNS) {
+    constexpr int NGR = RunGroups<B0, NBW>::NG;
+    if constexpr (M < NMAIN) {
+      mfma_tied(x.acc[M / NBW][M % NBW], run_a<C::CT, NGR, KS, M / NBW>(x.ro), run_b<B0, NBW, C::CT, KS, M % NBW>(x.ro));
+    } else {
+      mfma_tied(x.bacc[M - NMAIN], run_a<C::CT, NGR, KS, M - NMAIN>(x.ro), x.one);
+    }
+    pipe_gap_events_runs<COUT, CIN, B0, NBW, BIAS, WV, KS, M, 0>(x, gy, gx, addr);
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+  }
   if constexpr (M < NMAIN) {
     mfma_tied(x.acc[M / NBW][M % NBW], x.av[KS & 1][M / NBW], x.bv[KS & 1][M % NBW]);
   } else {
     mfma_tied(x.bacc[M - NMAIN], x.av[KS & 1][M - NMAIN], x.one);
   }
   // this gap's fillers: operand reads of the next k-step, then the staging slot's address, load, LDS write
-  using P = WgPipe<COUT, CIN>;
   if constexpr (P::SPREAD) {
     // one filler per gap, spelled out (the (48,48) layout as measured in round 1; same-box it is 0.7 % faster than the
     // same assignment produced by the generic walk below)
@@ -616,7 +787,7 @@ __device__ __forceinline__ void pipe_gap_asm(PipeCtx<COUT, CIN, NBW>& x, int& gy
 }
 
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS, int M>
-__device__ __forceinline__ void pipe_gaps_asm(PipeCtx<COUT, CIN, NBW>& x, int& gy, int& gx, uint64_t& addr) {
+__device__ __forceinline__ void pipe_gaps_asm(PipeCtx<COUT, CIN, NBW, RunGroups<B0, NBW>::NG>& x, int& gy, int& gx, uint64_t& addr) {
   if constexpr (M < (COUT / 16) * NBW + (BIAS ? COUT / 16 : 0)) {
     pipe_gap_asm<COUT, CIN, B0, NBW, BIAS, WV, KS, M>(x, gy, gx, addr);
     pipe_gaps_asm<COUT, CIN, B0, NBW, BIAS, WV, KS, M + 1>(x, gy, gx, addr);
@@ -624,7 +795,7 @@ __device__ __forceinline__ void pipe_gaps_asm(PipeCtx<COUT, CIN, NBW>& x, int& g
 }
 
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS>
-__device__ __forceinline__ void pipe_kstep(PipeCtx<COUT, CIN, NBW>& x) {
+__device__ __forceinline__ void pipe_kstep(PipeCtx<COUT, CIN, NBW, RunGroups<B0, NBW>::NG>& x) {
   if constexpr (WG_ASM_MFMA && !WG_DIAG) {
     int gy = 0, gx = 0;
     uint64_t addr = 0;
@@ -636,7 +807,7 @@ __device__ __forceinline__ void pipe_kstep(PipeCtx<COUT, CIN, NBW>& x) {
 }
 
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS>
-__device__ __forceinline__ void pipe_ksteps(PipeCtx<COUT, CIN, NBW>& x) {
+__device__ __forceinline__ void pipe_ksteps(PipeCtx<COUT, CIN, NBW, RunGroups<B0, NBW>::NG>& x) {
   if constexpr (KS < 36) {
     pipe_kstep<COUT, CIN, B0, NBW, BIAS, WV, KS>(x);
     pipe_ksteps<COUT, CIN, B0, NBW, BIAS, WV, KS + 1>(x);
@@ -711,6 +882,7 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const PipeSeg&
 
   f32x4 stage[P::NSLOT];
   float av[2][C::CT], bv[2][NBW];
+  RunOps<C::CT, RunGroups<B0, NBW>::NG> ro;
   float one = 1.0f;
   asm volatile("" : "+v"(one));  // keep it in a register: the asm MFMA takes no literal
   int par = 0;
@@ -727,9 +899,12 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const PipeSeg&
       }
     }
     float* cur = smem + par * P::BUF_FLOATS;
-    PipeCtx<COUT, CIN, NBW> x{b, geom, tile_at(), cur + lr * C::PSD + lq, cur + C::DY_FLOATS + lr * C::PSX + lq + 3,
-                              smem + (par ^ 1) * P::BUF_FLOATS, stage, av, bv, acc, bacc, one};
-    wg_read<COUT, CIN, B0, NBW>(x.a_base, x.b_base, 0, av[0], bv[0]);
+    PipeCtx<COUT, CIN, NBW, RunGroups<B0, NBW>::NG> x{b, geom, tile_at(), cur + lr * P::PSD + lq,
+                                                       cur + P::DY_FLOATS + lr * P::PSX + lq + 3,
+                                                       smem + (par ^ 1) * P::BUF_FLOATS, stage, av, bv, acc, bacc, one, ro,
+                                                       cur + lr * P::PSD + 12 * lq, cur + P::DY_FLOATS + lr * P::PSX + 12 * lq + 4};
+    if constexpr (P::RUNS) run_prime<COUT, CIN, B0, NBW>(ro, x.ra, x.rb);
+    else wg_read<COUT, CIN, B0, NBW>(x.a_base, x.b_base, 0, av[0], bv[0]);
     __builtin_amdgcn_sched_barrier(0);
     pipe_ksteps<COUT, CIN, B0, NBW, BIAS, WV, 0>(x);
     // pin the accumulators to AGPRs across the loop edge: left alone, the allocator carries them
@@ -792,7 +967,6 @@ __device__ __forceinline__ int pipe_image_floats(const WgradBatch& b) {
 
 template <int COUT, int CIN>
 __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_kernel(WgradBatch b) {
-  using C = WgCfg<COUT, CIN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const WgradJob& j = b.job[blockIdx.y];
   const int tid = threadIdx.x;
@@ -813,7 +987,6 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_kernel(WgradBatch b) {
 // images instead of 2 x 256.
 template <int COUT, int CIN>
 __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_flat_kernel(WgradBatch b) {
-  using C = WgCfg<COUT, CIN>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   WSTAMP(b, 0);
   const int tid = threadIdx.x;
@@ -843,13 +1016,21 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_pipe_flat_kernel(WgradBatch b
     const int h_begin = __builtin_amdgcn_readfirstlane((int)(p0 * total / b.head_units));
     const int h_end = __builtin_amdgcn_readfirstlane((int)(p1 * total / b.head_units));
     float* part = b.head.partial + (size_t)(w - b.head_first_wg) * H::PARTIAL_FLOATS;
-    // (ci group, tap) operands of the 16-channel job dealt to the 4 waves: NB = 9 -> 3, 2, 2, 2
-    constexpr int NB = H::NB;
-    constexpr int W0 = (NB + 3) / 4, W1 = (NB + 2) / 4, W2 = (NB + 1) / 4, W3 = NB / 4;
-    if (wave == 0) wg_role_range<COUT, 16, true, 0, W0>(b, b.head, smem, h_begin, h_end, part, tid, true);
-    else if (wave == 1) wg_role_range<COUT, 16, true, W0, W1>(b, b.head, smem, h_begin, h_end, part, tid, false);
-    else if (wave == 2) wg_role_range<COUT, 16, true, W0 + W1, W2>(b, b.head, smem, h_begin, h_end, part, tid, false);
-    else wg_role_range<COUT, 16, true, W0 + W1 + W2, W3>(b, b.head, smem, h_begin, h_end, part, tid, false);
+    if constexpr (WgPipe<COUT, 16>::FITS) {
+      // (round 4) the pipelined role at 16 input channels: its two tile buffers lie inside this launch's LDS
+      static_assert(WgPipe<COUT, 16>::LDS_BYTES <= WgPipe<COUT, CIN>::LDS_BYTES, "the head's tile buffers fit the launch's LDS");
+      const size_t plane = (size_t)b.H * b.W;
+      const PipeSeg seg{b.head.dy, b.head.x, 16 * plane, part, part + H::NB * H::CT * 256};
+      wg_pipe_pass<COUT, 16>(b, seg, smem, h_begin, h_end, tid, wave);
+    } else {
+      // (ci group, tap) operands of the 16-channel job dealt to the 4 waves: NB = 9 -> 3, 2, 2, 2
+      constexpr int NB = H::NB;
+      constexpr int W0 = (NB + 3) / 4, W1 = (NB + 2) / 4, W2 = (NB + 1) / 4, W3 = NB / 4;
+      if (wave == 0) wg_role_range<COUT, 16, true, 0, W0>(b, b.head, smem, h_begin, h_end, part, tid, true);
+      else if (wave == 1) wg_role_range<COUT, 16, true, W0, W1>(b, b.head, smem, h_begin, h_end, part, tid, false);
+      else if (wave == 2) wg_role_range<COUT, 16, true, W0 + W1, W2>(b, b.head, smem, h_begin, h_end, part, tid, false);
+      else wg_role_range<COUT, 16, true, W0 + W1 + W2, W3>(b, b.head, smem, h_begin, h_end, part, tid, false);
+    }
   }
 #if defined(LARVA_DIAG) && (LARVA_DIAG & 512)
   __syncthreads();
@@ -1237,9 +1418,10 @@ int larva_conv3x3_wgrad_partial_flat_head(const float* const* dy, const float* c
 int larva_wgrad_cu_share(int cout, int cin) {
   if (cout == 48 && cin == 48) return 1;   // (the pipelined kernel: 159 KB of LDS)
   if (cout == 32 && cin == 32) return (WgPipe<32, 32>::FITS && wgrad_use_pipe()) ? 1 : kWgradPerCu<32, 32>;
-  if (cout == 48 && cin == 16) return kWgradPerCu<48, 16>;
-  if (cout == 32 && cin == 16) return kWgradPerCu<32, 16>;
-  if (cout == 64 && cin == 16) return kWgradPerCu<64, 16>;
+  // (the pipelined kernel, where a shape is on it, owns its CU: two tile buffers)
+  if (cout == 48 && cin == 16) return (WgPipe<48, 16>::FITS && wgrad_use_pipe()) ? 1 : kWgradPerCu<48, 16>;
+  if (cout == 32 && cin == 16) return (WgPipe<32, 16>::FITS && wgrad_use_pipe()) ? 1 : kWgradPerCu<32, 16>;
+  if (cout == 64 && cin == 16) return (WgPipe<64, 16>::FITS && wgrad_use_pipe()) ? 1 : kWgradPerCu<64, 16>;
   return 1;
 }
 
