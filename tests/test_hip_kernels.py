@@ -583,17 +583,20 @@ def test_conv3x3_seeded_shape_fuzz(hip_device):
 
 
 def test_wgrad_seeded_shape_fuzz(hip_device):
-    """20 seeded random weight-gradient problems (batch, height, width aligned and not, 1..5 layers
-    per launch, split counts from 1 to more than there are tiles, 48x48 / 32x32 / 48x16 channels)
-    against the C oracle: both the pipelined kernel and the register-staged one."""
+    """24 seeded random weight-gradient problems (batch, height, width aligned and not, 1..5 layers
+    per launch, split counts from 1 to more than there are tiles; 48x48 / 32x32 / 48x16 channels and, round 4, the
+    shapes of the 32- and 64-filter networks: 64x64 and 48x64 run as two passes over 32 input channels, 64x16 and
+    48x32 on the pipelined kernel's operand runs) against the C oracle: both the pipelined kernel and the
+    register-staged one (unaligned widths)."""
     from larvanet_amd import kernels as K
     from oracle import larva_ref as R
     rng = np.random.default_rng(77001)
-    for case in range(20):
+    for case in range(24):
         N = int(rng.integers(1, 4))
         H = int(rng.integers(1, 20))
         W = int(rng.choice([4, 16, 48, 52, 96, int(rng.integers(1, 60))]))
-        cout, cin, valid = [(48, 48, 48), (48, 48, 48), (32, 32, 32), (48, 16, 3)][case % 4]
+        cout, cin, valid = [(48, 48, 48), (64, 64, 64), (32, 32, 32), (48, 16, 3), (48, 64, 64), (48, 48, 48), (64, 16, 3),
+                            (48, 32, 32)][case % 8]
         njobs = int(rng.integers(1, 6))
         splits = int(rng.choice([1, 2, 5, 16, 400]))
         jobs, refs = [], []
@@ -775,7 +778,10 @@ def test_step_prologue_equals_its_three_launches(hip_device):
                                                 # round 3: the pipelined kernel at (32,32) -- 8-10 MFMAs per k-step, the
                                                 # k-step's fillers dealt two to a gap -- per layer and as the flat grid
                                                 (5, 7, 2, 9, 48, 32), (6, 4, 2, 7, 52, 32), (40, 256, 4, 12, 48, 32),
-                                                (8, 256, 16, 48, 48, 32)])
+                                                (8, 256, 16, 48, 48, 32),
+                                                # round 4: (64, 64) as two (64, 32) passes per workgroup and layer into one
+                                                # partial image
+                                                (5, 7, 2, 9, 48, 64), (6, 4, 2, 7, 52, 64), (8, 256, 16, 48, 48, 64)])
 def test_flat_wgrad_grid_over_all_layers(hip_device, njobs, nwg, N, H, W, C):
     """larva_conv3x3_wgrad_partial_flat: one grid over the tiles of all layers (a workgroup's share may
     cross layer boundaries, more workgroups than tiles, several layers per workgroup) + the fixed-order
