@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the strip kernel's epilogue operands: through LDS (loader wave, round 3: -DLARVA_AUX_LDS=1)
 # against per-lane global loads in the prologue (the product build).
-set -e
+set -euo pipefail
 cd "$(dirname "$0")/.."
 tools/build_variant.sh aux_lds -DLARVA_AUX_LDS=1 > /dev/null
 for round in 1 2; do

@@ -2,7 +2,7 @@
 # DESIGN 9.0, priced before building it: the strip kernel's epilogue writing each workgroup's tile as ONE contiguous
 # run (timing-only build, -DLARVA_DIAG=1024: results land in the wrong places; every load is left as it is) against
 # the product build, same box: two half-batch chains, every link conv+ReLU / +res0 / mask, and the training step.
-set -e
+set -euo pipefail
 cd "$(dirname "$0")/.."
 tools/build_variant.sh blocked_stores -DLARVA_DIAG=1024 > /dev/null
 for round in 1 2; do

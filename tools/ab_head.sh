@@ -1,6 +1,8 @@
+#!/bin/bash
 # A/B of the head conv (LarvaHead, K = 27): direct kernel vs the padded-MFMA launch, same box.
+set -euo pipefail
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 for v in 1 0; do
   LARVA_HEAD_DIRECT=$v LARVA_DUAL_CHAIN=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02_head_$v -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > /dev/null 2>&1
 done

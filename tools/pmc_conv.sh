@@ -1,8 +1,10 @@
+#!/bin/bash
 # PMC passes (one counter set per pass) over `bench.py --roofline-only`: the fused conv+ReLU layer as one
 # whole-batch launch (conv3x3_mfma_kernel<48,true,1>) and as two half-batch strip launches
 # (conv3x3_mfma_strip_kernel<1>).  Output: gpurun_out/r02_pmc_conv/<set>/...
+set -euo pipefail
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02_pmc_conv
 mkdir -p $O
 i=0

@@ -1,7 +1,9 @@
+#!/bin/bash
 # HBM-side traffic of wgrad_reduce_kernel (two separate counter passes, as the guide prescribes), 32 layers x 8 partial images
+set -euo pipefail
 set -x
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02_pmc_reduce
 mkdir -p $O
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/tools/bench_wgrad.py 32 8 3 hot > $O/fetch.log 2>&1 && \

@@ -1,6 +1,8 @@
+#!/bin/bash
+set -euo pipefail
 set -x
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02_pmc
 mkdir -p $O
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/wgrad_fetch -- python3 $R/tools/bench_wgrad.py 32 8 3 hot > $O/wgrad_fetch.log 2>&1 && \
