@@ -264,6 +264,19 @@ int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, f
 /* Measurement only: a one-lane launch that stores the 100 MHz wall clock into *dst in stream order (a capturable
  * marker between the launches of a graph; no reference counterpart). */
 int larva_stamp_clock(unsigned long long* dst, void* stream);
+/* Measurement only (tools/probe_chain_kernel.py; no reference counterpart): `layers` conv3x3 + ReLU layers (48 -> 48
+ * channels, one packed weight image and bias for every layer) over buf0 [N][48][H][pitch] in ONE launch of
+ * N * tiles_per_image <= 256 co-resident workgroups; layer L reads buf[L % 2], writes buf[(L + 1) % 2]; a layer's input
+ * waits on a per-image counter instead of a kernel boundary.  state: N + 1 words (zeroed here in stream order; the last
+ * is set when a workgroup gave up waiting); xcc_out: N * tiles_per_image ints (XCC_ID | image << 8) or NULL; trace:
+ * N * tiles_per_image * layers * 8 stamps of the 100 MHz clock (layer entered, input released, wave 0's stores issued,
+ * barrier passed, wave 0 drained, loader wave done, wave 3 drained, unused) or NULL; naps: 64-clock naps of a waiting workgroup between two looks at its image's counter. */
+int larva_conv3x3_chain_probe(float* buf0, float* buf1, const float* wpk, const float* bias, int N, int H, int W, int pitch,
+                              const unsigned* tile_tab, int tiles_per_image, unsigned* state, int* xcc_out,
+                              unsigned long long* trace, int layers, int naps, void* stream);
+/* Measurement only: a one-wave launch that sleeps until the 100 MHz wall clock has advanced by `ticks` (<= 100000; the
+ * loop is bounded), in stream order: a tunable delay in front of one chain of a captured two-chain graph. */
+int larva_delay_ticks(int ticks, void* stream);
 /* `loss += ...; loss / num_modules` (models/LarvaNet.py:104-109): out = (sum of n <= 8 device scalars) / divisor. */
 int larva_sum_scalars(const float* const* terms, int n, float divisor, float* out, void* stream);
 /* The same loss tail in two launches less per exit: larva_l1_partial leaves the block partial sums

@@ -202,6 +202,7 @@ class DualChain:
                 if cls._stream(k) != cur:
                     cls._stream(k).wait_stream(cur)
             cls._forked = True
+            cls._stagger()
         cls._keep.append(out)
         cls._keep.extend([srcs] if isinstance(srcs, torch.Tensor) else list(srcs))
         cls._keep.extend(t for t in (wpk, kw.get("bias"), kw.get("mask"), kw.get("res0"), kw.get("res1"), kw.get("maskbits"),
@@ -211,6 +212,19 @@ class DualChain:
             with torch.cuda.stream(cls._stream(k)):
                 K.conv3x3(srcs, wpk, cout, out=out, images=rng, strips=2 if k else True, plain_stores=(cls.plain_stores == "all" or (forward and cls.plain_stores == "fwd")), **kw)
         return out
+
+    # Measurement knob (round 4, tools/ab_stagger.sh): LARVA_CHAIN_STAGGER_US = d delays chain 1 (d > 0) or chain 0 (d < 0) by
+    # a |d| us sleeping launch at every fork.  The step's time depends on the phase the two chains start in by up to 4 %.
+    stagger_us = float(os.environ.get("LARVA_CHAIN_STAGGER_US", "0"))
+
+    @classmethod
+    def _stagger(cls):
+        if cls.stagger_us == 0:
+            return
+        from . import hip_lib
+        with torch.cuda.stream(cls._stream(1 if cls.stagger_us > 0 else 0)):
+            hip_lib.check(hip_lib.load().larva_delay_ticks(int(round(abs(cls.stagger_us) * 100)), torch.cuda.current_stream().cuda_stream),
+                          "larva_delay_ticks")
 
     @classmethod
     def join(cls):

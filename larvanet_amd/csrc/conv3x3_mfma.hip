@@ -66,6 +66,9 @@
 // 14.9-15.4 against 14.2-14.6 us per layer, step 1.664-1.672 against 1.653-1.657 ms (same box, tools/ab_variant.sh).
 #define LARVA_TABLE_SCALAR 0
 #endif
+#ifndef LARVA_LOADER_SKIP_TAIL
+#define LARVA_LOADER_SKIP_TAIL 1   // the loader wave streams nothing past the last chunk (see run_loader)
+#endif
 #ifndef LARVA_WIDE_PLAIN
 #define LARVA_WIDE_PLAIN 0     // 1: the 48-column tiles' mode-0 output with plain instead of non-temporal stores (A/B timing)
 #endif
@@ -358,7 +361,7 @@ struct ChunkSrc {
 };
 
 template <int COUT, typename G>
-__device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int n) {
+__device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int n, const float* src_override = nullptr) {
   using C = ConvCfg<COUT, G>;
   const int c0 = chunk * kCh;
   const int s_idx = div_by_magic(chunk, a.magic_cps);
@@ -366,7 +369,7 @@ __device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int 
   ChunkSrc cs;
   // (one source tensor -- every launch of the layer chains: src[0] came with the first batch of arguments; only a
   // concatenated input pays the dependent kernarg load of its pointer, a scalar round trip per chunk)
-  const float* src = a.src[0];
+  const float* src = src_override ? src_override : a.src[0];
   if (s_idx != 0) {
     asm volatile("" ::: "memory");   // (keeps the branch: hipcc otherwise folds it back into one unconditional indexed load)
     src = a.src[s_idx];
@@ -380,7 +383,7 @@ __device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int 
 
 // One 1 KiB piece: lane l's 16 bytes go to LDS byte address stage_addr + 1024 p + 16 l.  Scalar
 // work only: pick the descriptor, form the LDS address, issue.
-template <int COUT, typename G>
+template <int COUT, typename G, bool SC1 = false>
 __device__ __forceinline__ void dma_piece(const DmaPlan<COUT, G>& pl, int i, int wave, const ChunkSrc& cs,
                                           unsigned stage_addr) {
   using C = ConvCfg<COUT, G>;
@@ -389,7 +392,7 @@ __device__ __forceinline__ void dma_piece(const DmaPlan<COUT, G>& pl, int i, int
   i32x4 rsrc;
 #pragma unroll
   for (int k = 0; k < 4; ++k) rsrc[k] = isw ? cs.wgt[k] : cs.img[k];
-  lds_dma16_buf(rsrc, pl.voff[i], 0, stage_addr + 1024u * (unsigned)p);
+  lds_dma16_buf<SC1>(rsrc, pl.voff[i], 0, stage_addr + 1024u * (unsigned)p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,9 +430,10 @@ __device__ __forceinline__ void make_loader_plan(const ConvArgs& a, int lane, in
   }
 }
 
-template <int COUT, typename G, int NAUXL = 0>
+template <int COUT, typename G, int NAUXL = 0, bool SC1 = false>
 __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int lane, int n, int y0, int x0,
-                                           const float* aux0 = nullptr, const float* aux1 = nullptr) {
+                                           const float* aux0 = nullptr, const float* aux1 = nullptr,
+                                           const float* io_src = nullptr) {
   using C = ConvCfg<COUT, G>;
   if constexpr ((LARVA_DIAG & 256) != 0) return;   // (no barriers to meet the MFMA waves at)
   LoaderPlan<COUT, G> pl;
@@ -462,11 +466,23 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
     // operand tile in flight behind chunk 2's pieces (issued in turn 0, see below) turns 1 and 2 leave AUXP more
     // operations outstanding: the counter retires in order, so "chunk 2 has landed" is then <= PIECES + AUXP.
     static_assert(NAUXL == 0 || C::NST == 3, "epilogue operands in LDS: the three-stage ring");
+    // Round 4 (kSkipTail): nothing is streamed past the end any more.  Until then the last two turns re-issued the last
+    // chunk into stages nobody reads, to keep every wait the same counted vmcnt -- 2 x PIECES LDS-DMA issues (~1.2 us of
+    // this wave) and their round trip AFTER the K loop's last barrier: the loader was the last wave of every workgroup
+    // to finish, i.e. it set the end of every launch of the layer chains.  Now the last turn waits for everything
+    // (its chunk is the youngest in flight) and the turns past last - 2 issue nothing.
+    constexpr bool kSkipTail = LARVA_LOADER_SKIP_TAIL && NAUXL == 0 && C::AHEAD == 2;
     if (NAUXL > 0 && (chunk == 1 || chunk == 2))
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PIECES + (NAUXL > 0 ? AUXP : 0)) : "memory");
+    else if (kSkipTail && chunk == last)
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((C::AHEAD - 1) * C::PIECES) : "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if (kSkipTail && chunk + C::AHEAD > last) {
+      stage = stage == C::NST - 1 ? 0 : stage + 1;
+      continue;
+    }
     const int nstage = (stage + C::AHEAD) % C::NST;   // the stage chunk - 1 has just vacated
     const unsigned dst = lds_addr_of(smem + nstage * C::STAGE_FLOATS);
     if (NAUXL > 1 && chunk == last - 1) {
@@ -479,10 +495,10 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
     } else {
       // past the end the last chunk is streamed again into a stage nobody reads: every wait stays
       // the same counted vmcnt(PIECES)
-      const ChunkSrc cs = chunk_src<COUT, G>(a, min(chunk + C::AHEAD, last), n);
+      const ChunkSrc cs = chunk_src<COUT, G>(a, min(chunk + C::AHEAD, last), n, io_src);
 #pragma unroll
       for (int p = 0; p < C::PIECES; ++p)
-        lds_dma16_buf(p < C::IN_PIECES ? cs.img : cs.wgt, pl.voff[p], 0, dst + 1024u * (unsigned)p);
+        lds_dma16_buf<SC1>(p < C::IN_PIECES ? cs.img : cs.wgt, pl.voff[p], 0, dst + 1024u * (unsigned)p);
     }
     if (NAUXL > 0 && chunk == 0) {
       // the epilogue's FIRST operand, into its own tile behind the ring, behind chunk 2's pieces in the queue
@@ -699,14 +715,53 @@ __device__ __forceinline__ void wait_and_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int COUT, typename G, bool VEC, int EPI, int NCT, int PG0, int NPG, bool AUXLDS = false>
+// CHAIN (conv3x3_strip_chain_kernel): the input pieces wait for *a.dep behind the weight pieces, and every LDS-DMA
+// bypasses the vector L1.
+__device__ __forceinline__ void chain_wait(const unsigned* ctr, unsigned target, unsigned* err, int wave, volatile unsigned* lds_flag,
+                                           unsigned layer, int naps) {
+  // wave 0 polls the image's counter (one L2 line that 32 workgroups bump and poll: four pollers per workgroup cost
+  // more than twice the chain's whole time), the other waves the word of LDS it then sets
+  if (wave == 0) {
+    bool ok = false;
+    for (int i = 0; i < 400000 && !ok; ++i) {   // bounded (>= 100 ms): a grid that cannot make progress still drains
+      const unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = (int)(__builtin_amdgcn_readfirstlane(v) - target) >= 0;
+      if (!ok) {
+        for (int j = 0; j < naps; ++j) __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    if (!ok) *err = 1u;
+    *lds_flag = layer;
+  } else {
+    for (int i = 0; i < 4000000; ++i) {
+      if (*lds_flag >= layer) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+}
+
+struct ChainIO {   // CHAIN: this layer's tensors and what its input waits for (the launch's arguments name layer 0's)
+  const float* src;
+  float* out;
+  const unsigned* dep;   // null: nothing to wait for
+  unsigned dep_target;
+  unsigned* err;
+  volatile unsigned* lds_flag;   // a word of LDS behind the ring, 0 at kernel start
+  unsigned layer;
+  unsigned long long* trace;     // this workgroup's and layer's four 100 MHz stamps, or null
+  int naps;                      // 64-clock naps between two looks at the counter
+};
+
+template <int COUT, typename G, bool VEC, int EPI, int NCT, int PG0, int NPG, bool AUXLDS = false, bool CHAIN = false>
 __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0, int wave, int n, int y0,
-                                         int x0, int tid) {
+                                         int x0, int tid, ChainIO io = ChainIO{}) {
   using C = ConvCfg<COUT, G>;
   static_assert(!AUXLDS || (VEC && C::LOADER && LARVA_PIXEL_MAJOR && (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2)),
                 "epilogue operands in LDS: the loader-wave path's mask / residual epilogues");
   const int lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
+  float* const out_ptr = CHAIN ? io.out : a.out;
+  const float* const src_ptr = CHAIN ? io.src : nullptr;
   // The epilogue's scalars, PINNED in SGPRs from here on (round 4).  Left alone hipcc drops them after the prologue and
   // re-loads each from the kernarg segment where the epilogue uses it -- H / pitch / plain_stores after the K loop and
   // W once per (channel group, pixel group) unit, every one an s_load + s_waitcnt lgkmcnt(0) in front of that unit's
@@ -834,26 +889,31 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     DmaPlan<COUT, G> pl;
     const int last = a.n_chunks - 1;
     if constexpr (!(LARVA_DIAG & 2)) {
-      const ChunkSrc cs0 = chunk_src<COUT, G>(a, 0, n);
+      const ChunkSrc cs0 = chunk_src<COUT, G>(a, 0, n, src_ptr);
       const unsigned st0 = lds_addr_of(smem), st1 = lds_addr_of(smem + C::STAGE_FLOATS);
       stamp(6);
       make_plan<COUT, G, true>(a, wave, lane, y0, x0, pl);
 #pragma unroll
       for (int i = 0; i < C::NPW; ++i)
-        if (wave + 4 * i >= C::IN_PIECES) dma_piece<COUT, G>(pl, i, wave, cs0, st0);
+        if (wave + 4 * i >= C::IN_PIECES) dma_piece<COUT, G, CHAIN>(pl, i, wave, cs0, st0);
       __builtin_amdgcn_sched_barrier(0);
       stamp(7);
       load_early();
       stamp(14);
       make_plan<COUT, G, false>(a, wave, lane, y0, x0, pl);
+      if constexpr (CHAIN) {
+        if (io.dep) chain_wait(io.dep, io.dep_target, io.err, wave, io.lds_flag, io.layer, io.naps);
+        if (io.trace && tid == 0) io.trace[1] = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i = 0; i < C::NPW; ++i)
-        if (wave + 4 * i < C::IN_PIECES) dma_piece<COUT, G>(pl, i, wave, cs0, st0);
+        if (wave + 4 * i < C::IN_PIECES) dma_piece<COUT, G, CHAIN>(pl, i, wave, cs0, st0);
       stamp(15);
       if constexpr (C::NST == 3 || !C::LOADER) {   // (two stages: chunk 1 is the loader wave's first turn)
-        const ChunkSrc cs1 = chunk_src<COUT, G>(a, min(1, last), n);
+        const ChunkSrc cs1 = chunk_src<COUT, G>(a, min(1, last), n, src_ptr);
 #pragma unroll
-        for (int i = 0; i < C::NPW; ++i) dma_piece<COUT, G>(pl, i, wave, cs1, st1);
+        for (int i = 0; i < C::NPW; ++i) dma_piece<COUT, G, CHAIN>(pl, i, wave, cs1, st1);
       }
       (void)st1;
       if constexpr (kAuxLate) {   // the youngest vector loads of the wave (see above)
@@ -886,7 +946,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       const int nstage = (stage + C::AHEAD) % C::NST;
       if constexpr (!(LARVA_DIAG & 1)) {
         if constexpr (!(LARVA_DIAG & 2) && !C::LOADER) {
-          const ChunkSrc nxt = chunk_src<COUT, G>(a, min(chunk + 2, last), n);
+          const ChunkSrc nxt = chunk_src<COUT, G>(a, min(chunk + 2, last), n, src_ptr);
           mfma_chunk<COUT, G, NCT, PG0, NPG, true, kPixMajor>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt,
                                                 lds_addr_of(smem + nstage * C::STAGE_FLOATS));
         } else {
@@ -922,7 +982,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     // ---- register staging, 2 stages ------------------------------------------------------------
     RegStaging<COUT, G> st;
     if constexpr (!(LARVA_DIAG & 2)) {
-      reg_load<COUT, G>(a, chunk_src<COUT, G>(a, 0, n), y0, x0, tid, st);
+      reg_load<COUT, G>(a, chunk_src<COUT, G>(a, 0, n, src_ptr), y0, x0, tid, st);
       reg_store<COUT, G>(smem, tid, st);
     }
     __syncthreads();
@@ -972,9 +1032,9 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         const int y = y0 + prow, x = x0 + pcol * 16 + lr;
         const f32x4 v = (acc[c][p] + bias[c]) + aux[0][c][p];
         if (y < k.H && x < k.W) {
-          if (a.out) {
+          if (out_ptr) {
             const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_ptr + idx));
           }
           const f32x4 d = v - aux[1][c][p];
           s += fabsf(d[0]) + fabsf(d[1]) + fabsf(d[2]) + fabsf(d[3]);
@@ -1000,7 +1060,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
         f32x4 v = acc[c][p] + bias[c];
         if constexpr (EPI == kEpiShuffleBase) v += aux[0][c][p];
-        if (y < k.H && x < k.W) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
+        if (y < k.H && x < k.W) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_ptr + idx));
       }
   } else if constexpr (kPixMajor) {
     // Pixel-major accumulators: acc[c][p][r] = output channel (ct0+c)*16 + lr of pixel
@@ -1041,8 +1101,8 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
               }
               v[r] = (xb + r < k.W) ? o : 0.f;   // columns [W, pitch) are kept at zero for the next layer
             }
-            if constexpr (kPlain) *reinterpret_cast<f32x4*>(a.out + idx) = v;
-            else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + idx));
+            if constexpr (kPlain) *reinterpret_cast<f32x4*>(out_ptr + idx) = v;
+            else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_ptr + idx));
             if constexpr (EPI == kEpiRelu)   // the sign bits of what was just stored: `h > 0` of the ReLU backward
               nib[c][p] = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
           }
@@ -1111,8 +1171,8 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
               if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
               if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
               o = real ? o : 0.f;
-              if constexpr (kPlain) a.out[idx0 + r * plane] = o;
-              else __builtin_nontemporal_store(o, &a.out[idx0 + r * plane]);
+              if constexpr (kPlain) out_ptr[idx0 + r * plane] = o;
+              else __builtin_nontemporal_store(o, &out_ptr[idx0 + r * plane]);
             }
           }
         }
@@ -1280,6 +1340,72 @@ constexpr size_t kStripLdsBytes = kStripLdsOf<COUT, GeoS5, EPI> > kStripLdsOf<CO
                                                                                                 : kStripLdsOf<COUT, GeoS4, EPI>;
 static_assert(LARVA_WG_PER_CU * kStripLdsBytes<48, kEpiRes2> <= 160 * 1024 && 2 * kStripLdsBytes<64, kEpiRes2> <= 160 * 1024,
               "strip workgroups per CU");
+
+// ---------------------------------------------------------------------------------------------
+// MEASUREMENT KERNEL (round 4, tools/probe_chain_kernel.py; not on the product path): a whole chain of conv3x3 + ReLU
+// layers of one half batch in ONE launch.  What would the layer chains gain if a kernel boundary (last drain -> next
+// entry 2.0-2.2 us, grid-wide drain skew 1.8-2.6 us, kernarg / table fetch in front of every workgroup) were
+// replaced by an in-launch dependency?  Every workgroup keeps its strip tile for all layers; the activations
+// ping-pong between two buffers; a workgroup that has drained its stores of layer L adds 1 to its IMAGE's counter, and
+// the input pieces of layer L + 1 wait (behind that layer's weight pieces) until the counter says all tiles of the image
+// are done with layer L -- which also covers the write-after-read on the ping-pong buffer.  Visibility: all tiles of an
+// image run on ONE XCD (xcd_remap + the round-robin deal of workgroups, which the probe checks through XCC_ID), whose L2
+// serves plain stores to `sc1` loads (L1 bypassed); the counters are agent-scope atomics in that same L2.  Residency:
+// the grid is 256 workgroups at two per CU -- two such launches fill the chip exactly and nothing else may run.
+// Every spin is bounded.
+// ---------------------------------------------------------------------------------------------
+struct ChainProbeArgs {
+  ConvArgs a;            // layer 0 as a strip launch would get it (src[0] = buf[0], out = buf[1])
+  float* buf[2];         // ping-pong activations [N][COUT][H][pitch]
+  unsigned* counters;    // [N], zero at launch
+  unsigned* err;         // [1]
+  int* xcc_out;          // [nwg] or null: the XCD each workgroup ran on
+  int layers;
+  unsigned long long* trace;   // [nwg][layers][4] or null: layer entered / input released / stores issued / barrier passed
+  int naps;                    // 64-clock naps between two looks at an image's counter
+};
+
+template <int COUT, typename G>
+__device__ __forceinline__ void chain_roles(const ChainProbeArgs& p, float* smem, int wave, int n, int y0, int x0, int tid) {
+  static_assert(COUT == 48, "the chain probe is built for 48 channels");
+  for (int L = 0; L < p.layers; ++L) {
+    const ChainIO io{p.buf[L & 1], p.buf[(L + 1) & 1], L ? p.counters + n : nullptr, (unsigned)(L * p.a.tiles_x), p.err,
+                     reinterpret_cast<volatile unsigned*>(smem + kStripLdsBytes<COUT, kEpiRelu> / sizeof(float)), (unsigned)L,
+                     p.trace ? p.trace + ((size_t)blockIdx.x * p.layers + L) * 8 : nullptr, p.naps};
+    if (io.trace && tid == 0) io.trace[0] = __builtin_amdgcn_s_memrealtime();
+    if (wave == 4) {
+      run_loader<COUT, G, 0, true>(p.a, smem, tid & 63, n, y0, x0, nullptr, nullptr, io.src);
+      if (io.trace && (tid & 63) == 0) io.trace[5] = __builtin_amdgcn_s_memrealtime();
+    } else {
+      if (wave < 3) run_role<COUT, G, true, kEpiRelu, 1, 0, G::ROWS - 1, false, true>(p.a, smem, wave, wave, n, y0, x0, tid, io);
+      else run_role<COUT, G, true, kEpiRelu, 3, G::ROWS - 1, 1, false, true>(p.a, smem, 0, wave, n, y0, x0, tid, io);
+      if (io.trace && tid == 0) io.trace[2] = __builtin_amdgcn_s_memrealtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
+      if (io.trace && (tid & 63) == 0 && (wave == 0 || wave == 3)) io.trace[wave == 0 ? 4 : 6] = __builtin_amdgcn_s_memrealtime();
+    }
+    asm volatile("s_barrier" ::: "memory");             // everybody's have, and nobody reads the ring any more
+    if (io.trace && tid == 0) io.trace[3] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) __hip_atomic_fetch_add(p.counters + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(320, LARVA_WG_PER_CU) void conv3x3_strip_chain_kernel(ChainProbeArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tile = xcd_remap(blockIdx.x, p.a.nwg);
+  const int n = div_by_magic(tile, p.a.magic_tx);
+  const int slot = tile - n * p.a.tiles_x;
+  const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)p.a.tile_tab[slot]);   // (uniform: the layer loop sits under it)
+  const int y0 = (int)(e & 0xfffu), x0 = (int)((e >> 12) & 0xfffu);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) smem[kStripLdsBytes<COUT, kEpiRelu> / sizeof(float)] = 0.f;   // (the layer flag; layer 0 waits for nothing, and
+                                                                               //  every wave meets at a barrier before layer 1)
+  if (p.xcc_out && tid == 0) p.xcc_out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 20) | (n << 8);
+  __builtin_amdgcn_s_setprio(1);
+  if (e >> 31) chain_roles<COUT, GeoS5>(p, smem, wave, n, y0, x0, tid);
+  else chain_roles<COUT, GeoS4>(p, smem, wave, n, y0, x0, tid);
+}
 
 // Several INDEPENDENT convolutions of one shape and one epilogue in one launch (blockIdx.y = job).
 // A single conv launch at the training shape is one workgroup per CU and spends half of its time
@@ -2031,6 +2157,56 @@ int larva_conv3x3_fwd_strips_mb(const float* const* src, int n_src, int cin_per_
   return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu, mode,
                          tile_tab, tiles_per_image, plain_stores, stream, nullptr, MaskBitsArg{maskbits, maskbits_out},
                          tile_tab_host);
+}
+
+// Measurement only (tools/probe_chain_kernel.py): `layers` conv3x3 + ReLU layers (48 -> 48 channels, the same packed
+// weights and bias in every layer) over the N images of buf0 [N][48][H][pitch] in ONE launch of N * tiles_per_image
+// workgroups (conv3x3_strip_chain_kernel): layer L reads buf[L % 2] and writes buf[(L + 1) % 2].  state: N + 1 words
+// (per-image counters, then a give-up flag), zeroed here in stream order; xcc_out: N * tiles_per_image ints or null;
+// trace: N * tiles_per_image * layers * 8 stamps (100 MHz: layer entered, input released, wave 0's stores issued, barrier
+// passed, wave 0 drained, loader wave done, wave 3 drained, unused) or null.
+// The grid must be co-resident (<= 256 workgroups per launch, at most two such launches at a time, nothing else running).
+int larva_conv3x3_chain_probe(float* buf0, float* buf1, const float* wpk, const float* bias, int N, int H, int W, int pitch,
+                              const unsigned* tile_tab, int tiles_per_image, unsigned* state, int* xcc_out,
+                              unsigned long long* trace, int layers, int naps, void* stream) {
+  if (!buf0 || !buf1 || !state || !tile_tab || tiles_per_image < 1 || layers < 1 || N < 1 || N * tiles_per_image > 256)
+    return (int)hipErrorInvalidValue;
+  ChainProbeArgs p{};
+  bool aligned;
+  int epi;
+  const float* src[1] = {buf0};
+  const int rc = conv_build(src, 1, 48, wpk, bias, nullptr, nullptr, nullptr, nullptr, buf1, N, H, W, pitch, 1, 0, p.a, aligned,
+                            epi, MaskBitsArg{});
+  if (rc) return rc;
+  if (!aligned || epi != kEpiRelu || p.a.n_chunks != 6) return (int)hipErrorNotSupported;
+  p.a.tile_tab = tile_tab;
+  p.a.tab_n = 0;
+  p.a.plain_stores = 1;
+  p.a.tiles_x = tiles_per_image;
+  p.a.tiles_y = 1;
+  p.a.magic_tx = div_magic(tiles_per_image);
+  p.a.magic_ty = div_magic(1);
+  p.a.nwg = N * tiles_per_image;
+  p.buf[0] = buf0;
+  p.buf[1] = buf1;
+  p.counters = state;
+  p.err = state + N;
+  p.xcc_out = xcc_out;
+  p.trace = trace;
+  p.naps = naps < 1 ? 1 : naps;
+  p.layers = layers;
+  constexpr size_t lds = kStripLdsBytes<48, kEpiRelu> + 16;   // + the layer flag
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_strip_chain_kernel<48>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipError_t e = hipMemsetAsync(state, 0, sizeof(unsigned) * (size_t)(N + 1), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((conv3x3_strip_chain_kernel<48>), dim3(p.a.nwg), dim3(320), lds, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
 }
 
 #if LARVA_DIAG & 32

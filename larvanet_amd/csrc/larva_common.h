@@ -67,12 +67,22 @@ __device__ __forceinline__ i32x4 dma_rsrc(const void* base) {
   return r;
 }
 
+// SC1: the load bypasses this CU's vector L1 (served by the XCD's L2) -- for bytes another workgroup of the SAME launch
+// has just written (tools/probe_chain_kernel.py); every other caller reads what an earlier launch wrote.
+template <bool SC1 = false>
 __device__ __forceinline__ void lds_dma16_buf(i32x4 rsrc, unsigned voff, int soff_uniform, unsigned lds_addr_uniform) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "s"(lds_addr_uniform), "v"(voff), "s"(rsrc), "s"(soff_uniform)
-               : "memory");
+  if constexpr (SC1) {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen sc1 lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr_uniform), "v"(voff), "s"(rsrc), "s"(soff_uniform)
+                 : "memory");
+  } else {
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr_uniform), "v"(voff), "s"(rsrc), "s"(soff_uniform)
+                 : "memory");
+  }
 }
 
 __device__ __forceinline__ unsigned lds_addr_of(const float* p) {

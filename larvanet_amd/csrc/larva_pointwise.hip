@@ -688,6 +688,23 @@ int larva_stamp_clock(unsigned long long* dst, void* stream) {
   return (int)hipGetLastError();
 }
 
+// Measurement only: one wave that sleeps until the 100 MHz wall clock has advanced by `ticks` (bounded: at most 4096
+// naps of 64 clocks), in stream order -- a capturable, tunable delay in front of one chain of a two-chain graph
+// (tools/ab_stagger.sh: how does the step depend on the phase the two chains start in?).
+__global__ void delay_kernel(int ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < 4096; ++i) {
+    if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) >= (long long)ticks) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+int larva_delay_ticks(int ticks, void* stream) {
+  if (ticks < 0 || ticks > 100000) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
+  return (int)hipGetLastError();
+}
+
 // out[0] = (sum of n <= 8 device scalars, added in index order) / divisor.
 int larva_sum_scalars(const float* const* terms, int n, float divisor, float* out, void* stream) {
   if (!terms || n < 1 || n > 8 || !out) return (int)hipErrorInvalidValue;

@@ -73,7 +73,7 @@ def test_flat_wgrad_partition_covers_every_tile_once_within_the_advertised_image
     cases += [(rnd.randint(1, 64), rnd.randint(1, 600), rnd.randint(1, 400)) for _ in range(60)]
     for njobs, nwg, tiles in cases:
         for with_head in (False, True):
-            hu = (tiles * 7 + 9) // 10 if with_head else 0
+            hu = (tiles * 6 + 9) // 10 if with_head else 0   # (LARVA_HEAD_COST10 = 6: a head tile priced at 0.6 of a 48 -> 48 tile)
             T = njobs * tiles
             G = T + hu
             n = min(nwg, G)
