@@ -270,10 +270,11 @@ int larva_stamp_clock(unsigned long long* dst, void* stream);
  * waits on a per-image counter instead of a kernel boundary.  state: N + 1 words (zeroed here in stream order; the last
  * is set when a workgroup gave up waiting); xcc_out: N * tiles_per_image ints (XCC_ID | image << 8) or NULL; trace:
  * N * tiles_per_image * layers * 8 stamps of the 100 MHz clock (layer entered, input released, wave 0's stores issued,
- * barrier passed, wave 0 drained, loader wave done, wave 3 drained, unused) or NULL; naps: 64-clock naps of a waiting workgroup between two looks at its image's counter. */
+ * barrier passed, wave 0 drained, loader wave done, wave 3 drained, unused) or NULL; naps: 64-clock naps of a waiting workgroup between two looks at its image's counter;
+ * plain_stores: 0 = non-temporal output stores. */
 int larva_conv3x3_chain_probe(float* buf0, float* buf1, const float* wpk, const float* bias, int N, int H, int W, int pitch,
                               const unsigned* tile_tab, int tiles_per_image, unsigned* state, int* xcc_out,
-                              unsigned long long* trace, int layers, int naps, void* stream);
+                              unsigned long long* trace, int layers, int naps, int plain_stores, void* stream);
 /* Measurement only: a one-wave launch that sleeps until the 100 MHz wall clock has advanced by `ticks` (<= 100000; the
  * loop is bounded), in stream order: a tunable delay in front of one chain of a captured two-chain graph. */
 int larva_delay_ticks(int ticks, void* stream);

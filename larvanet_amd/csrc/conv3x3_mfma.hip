@@ -2168,7 +2168,7 @@ int larva_conv3x3_fwd_strips_mb(const float* const* src, int n_src, int cin_per_
 // The grid must be co-resident (<= 256 workgroups per launch, at most two such launches at a time, nothing else running).
 int larva_conv3x3_chain_probe(float* buf0, float* buf1, const float* wpk, const float* bias, int N, int H, int W, int pitch,
                               const unsigned* tile_tab, int tiles_per_image, unsigned* state, int* xcc_out,
-                              unsigned long long* trace, int layers, int naps, void* stream) {
+                              unsigned long long* trace, int layers, int naps, int plain_stores, void* stream) {
   if (!buf0 || !buf1 || !state || !tile_tab || tiles_per_image < 1 || layers < 1 || N < 1 || N * tiles_per_image > 256)
     return (int)hipErrorInvalidValue;
   ChainProbeArgs p{};
@@ -2181,7 +2181,7 @@ int larva_conv3x3_chain_probe(float* buf0, float* buf1, const float* wpk, const 
   if (!aligned || epi != kEpiRelu || p.a.n_chunks != 6) return (int)hipErrorNotSupported;
   p.a.tile_tab = tile_tab;
   p.a.tab_n = 0;
-  p.a.plain_stores = 1;
+  p.a.plain_stores = plain_stores ? 1 : 0;   // (0: non-temporal stores)
   p.a.tiles_x = tiles_per_image;
   p.a.tiles_y = 1;
   p.a.magic_tx = div_magic(tiles_per_image);

@@ -130,7 +130,7 @@ SIGNATURES = {
     "larva_stamp_clock": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "larva_delay_ticks": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "larva_conv3x3_chain_probe": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int,
-                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_sum_scalars": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_void_p]),
     "larva_pixel_unshuffle4": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

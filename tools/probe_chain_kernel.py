@@ -53,11 +53,13 @@ def launch(k, st, with_xcc=False):
     off = parts[k][0] * img_floats * 4
     code = lib.larva_conv3x3_chain_probe(pa.data_ptr() + off, pb.data_ptr() + off, wpk.data_ptr(), b.data_ptr(), half, P, P, P,
                                          tabs[k][0].data_ptr(), tiles, state[k].data_ptr(), xcc[k].data_ptr() if with_xcc else None,
-                                         trace[k].data_ptr() if with_xcc else None, layers, NAPS, st.cuda_stream)
+                                         trace[k].data_ptr() if with_xcc else None, layers, NAPS, PLAIN, st.cuda_stream)
     hip_lib.check(code, "larva_conv3x3_chain_probe")
 
 
 NAPS = int(os.environ.get("CHAIN_PROBE_NAPS", "2"))   # 64-clock naps between two looks at an image's counter
+PLAIN = int(os.environ.get("CHAIN_PROBE_PLAIN", "1"))  # 0: non-temporal output stores
+STAGGER = float(os.environ.get("CHAIN_PROBE_STAGGER_US", "0"))   # a sleeping launch of this many us in front of half 1's launch
 ONLY = os.environ.get("CHAIN_PROBE_ONLY")   # "0" / "1": launch one half batch only (timing; the comparison then fails)
 
 
@@ -68,6 +70,8 @@ def both(with_xcc=False):
             continue
         st.wait_stream(cur)
         with torch.cuda.stream(st):
+            if k == 1 and STAGGER > 0:
+                hip_lib.check(lib.larva_delay_ticks(int(STAGGER * 100), st.cuda_stream), "larva_delay_ticks")
             launch(k, st, with_xcc)
     for st in streams:
         cur.wait_stream(st)
