@@ -67,7 +67,7 @@
 #define LARVA_TABLE_SCALAR 0
 #endif
 #ifndef LARVA_LOADER_SKIP_TAIL
-#define LARVA_LOADER_SKIP_TAIL 1   // the loader wave streams nothing past the last chunk (see run_loader)
+#define LARVA_LOADER_SKIP_TAIL 0   // 1: the loader wave streams nothing past the last chunk (see run_loader; measured, off)
 #endif
 #ifndef LARVA_WIDE_PLAIN
 #define LARVA_WIDE_PLAIN 0     // 1: the 48-column tiles' mode-0 output with plain instead of non-temporal stores (A/B timing)
@@ -466,12 +466,14 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
     // operand tile in flight behind chunk 2's pieces (issued in turn 0, see below) turns 1 and 2 leave AUXP more
     // operations outstanding: the counter retires in order, so "chunk 2 has landed" is then <= PIECES + AUXP.
     static_assert(NAUXL == 0 || C::NST == 3, "epilogue operands in LDS: the three-stage ring");
-    // Round 4 (kSkipTail): nothing is streamed past the end any more.  Until then the last two turns re-issued the last
-    // chunk into stages nobody reads, to keep every wait the same counted vmcnt -- 2 x PIECES LDS-DMA issues (~1.2 us of
-    // this wave) and their round trip AFTER the K loop's last barrier: the loader was the last wave of every workgroup
-    // to finish, i.e. it set the end of every launch of the layer chains.  Now the last turn waits for everything
-    // (its chunk is the youngest in flight) and the turns past last - 2 issue nothing.
-    constexpr bool kSkipTail = LARVA_LOADER_SKIP_TAIL && NAUXL == 0 && C::AHEAD == 2;
+    // kSkipTail (round 4, measured and left OFF in the product kernels): stream nothing past the last chunk -- the last turn
+    // then waits for everything (its chunk is the youngest in flight) and the turns past last - 2 issue nothing.  The
+    // product re-issues the last chunk twice into stages nobody reads, which keeps every wait the same counted vmcnt;
+    // those 2 x PIECES issues and their round trip lie behind the K loop's last barrier, so the loader is the last wave
+    // of a workgroup to finish -- but same box, three alternating rounds, the step is 1.620 / 1.625 / 1.627 ms WITH the
+    // redundant streams and 1.625 / 1.629 / 1.632 without (profiles/r04_ab_loader_tail.txt): not on the critical path.
+    // The one-launch chain probe (SC1) skips them: there the loader's end gates the layer's barrier.
+    constexpr bool kSkipTail = (LARVA_LOADER_SKIP_TAIL || SC1) && NAUXL == 0 && C::AHEAD == 2;
     if (NAUXL > 0 && (chunk == 1 || chunk == 2))
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PIECES + (NAUXL > 0 ? AUXP : 0)) : "memory");
     else if (kSkipTail && chunk == last)

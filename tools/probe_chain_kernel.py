@@ -140,9 +140,10 @@ graph = torch.cuda.CUDAGraph()
 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
     both()
 t = bench.replay_ms(graph, 10)
-flop = bench.conv_flop(C)
-print("ONE launch per half batch:  %.2f us per full-batch layer = %.3f of the fp32 matrix peak  (gave up: %s)"
-      % (t * 1e3 / layers, flop / (t / layers * 1e-3) / 1e12 / bench.FP32_MFMA_PEAK_TFLOPS, [int(s[half]) for s in state]))
+flop = bench.conv_flop(C) * (0.5 if ONLY is not None else 1.0)
+print("ONE launch per half batch:  %.2f us per %s layer = %.3f of the fp32 matrix peak  (gave up: %s)"
+      % (t * 1e3 / layers, "HALF-batch (one launch running alone)" if ONLY is not None else "full-batch",
+         flop / (t / layers * 1e-3) / 1e12 / bench.FP32_MFMA_PEAK_TFLOPS, [int(s[half]) for s in state]))
 if layers == bench.CHAIN_SHORT:
     slope, _, per = bench.dual_chain_time_ms(dev, C)
     print("%d launches per half batch: %.2f us per full-batch layer = %.3f (bench.py's roofline.avg_ms; steady state %.2f us)"
