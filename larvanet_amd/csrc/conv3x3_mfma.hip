@@ -722,8 +722,12 @@ __device__ __forceinline__ void wait_and_barrier() {
 __device__ __forceinline__ void chain_wait(const unsigned* ctr, unsigned target, unsigned* err, int wave, volatile unsigned* lds_flag,
                                            unsigned layer, int naps) {
   // wave 0 polls the image's counter (one L2 line that 32 workgroups bump and poll: four pollers per workgroup cost
-  // more than twice the chain's whole time), the other waves the word of LDS it then sets
+  // more than twice the chain's whole time) at wave priority 0 -- the CU's other workgroup is in its K loop --, the
+  // other waves (the loader too, see chain_roles) sleep at a workgroup barrier meanwhile
+  (void)lds_flag;
+  (void)layer;
   if (wave == 0) {
+    __builtin_amdgcn_s_setprio(0);
     bool ok = false;
     for (int i = 0; i < 400000 && !ok; ++i) {   // bounded (>= 100 ms): a grid that cannot make progress still drains
       const unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -733,13 +737,9 @@ __device__ __forceinline__ void chain_wait(const unsigned* ctr, unsigned target,
       }
     }
     if (!ok) *err = 1u;
-    *lds_flag = layer;
-  } else {
-    for (int i = 0; i < 4000000; ++i) {
-      if (*lds_flag >= layer) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
+    __builtin_amdgcn_s_setprio(1);
   }
+  asm volatile("s_barrier" ::: "memory");
 }
 
 struct ChainIO {   // CHAIN: this layer's tensors and what its input waits for (the launch's arguments name layer 0's)
@@ -1376,6 +1376,7 @@ __device__ __forceinline__ void chain_roles(const ChainProbeArgs& p, float* smem
                      p.trace ? p.trace + ((size_t)blockIdx.x * p.layers + L) * 8 : nullptr, p.naps};
     if (io.trace && tid == 0) io.trace[0] = __builtin_amdgcn_s_memrealtime();
     if (wave == 4) {
+      if (io.dep) asm volatile("s_barrier" ::: "memory");   // (the MFMA waves' meeting point behind the counter poll)
       run_loader<COUT, G, 0, true>(p.a, smem, tid & 63, n, y0, x0, nullptr, nullptr, io.src);
       if (io.trace && (tid & 63) == 0) io.trace[5] = __builtin_amdgcn_s_memrealtime();
     } else {

@@ -27,6 +27,8 @@ x0, wpk, b, bufs, rms = bench.chain_operands(dev, C, layers, False)
 half = B // 2
 parts = ((0, half), (half, B))
 tabs = [K.strip_tile_table(P, P, dev, phase) for phase in (0, 1)]
+if os.environ.get("CHAIN_PROBE_SAME_PHASE"):   # both half batches cut their images the same way (timing only: the reference
+    tabs[1] = tabs[0]                          # chain uses the two phases, so the bit-for-bit line then fails for half 1)
 tiles = tabs[0][1]
 print("%d layers of 16 x %d x %d x %d, %d strip tiles per image, activations RMS %.1f" % (layers, C, P, P, tiles, float(x0.pow(2).mean().sqrt())))
 
