@@ -756,6 +756,94 @@ def timed_rounds(model, args, val, x, truth, steps, rounds, dist_on):
     return secs, loss
 
 
+def dp_probe_child(a, emit):
+    """`bench.py --dp-probe`: one GPU, the data-parallel step's two weight-gradient schedules side by side -- wall ms per
+    step (reference semantics: fresh tensors + loss.item()), HOST microseconds per step (async loss, the host never waits
+    for the GPU: what one rank's Python thread spends enqueueing a step -- eight ranks share one host), and, under
+    LARVA_DIST_FORCE=1, everything the N > 1 line carries (`rccl_ranks`, the timed all-reduce of prepare(), the exposed
+    all-reduce time) measured through a ONE-rank RCCL communicator.  A rehearsal of the code path, not a scaling number."""
+    import importlib
+    import numpy as np
+    import torch
+    import torch.distributed as td
+    from larvanet_amd import dist as ldist
+    rank, world = ldist.init_from_env()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator().manual_seed(1000)
+    x = (torch.rand(BATCH, 3, PATCH, PATCH, generator=g) * 255).to(dev)
+    truth = (torch.rand(BATCH, 3, PATCH * SCALE, PATCH * SCALE, generator=g) * 255).to(dev)
+    args = types.SimpleNamespace(train_path="/tmp")
+    val = TinyValLoader()
+    out = {"communicator": ("%s, %d rank(s)" % (td.get_backend(), world)) if ldist.active() else None,
+           "rccl_ranks": world if ldist.active() and td.get_backend() == "nccl" else 0,
+           "what": dp_probe_child.__doc__.split("\n\n")[0].replace("\n    ", " ")}
+    for name in ("flat", "split"):
+        os.environ["LARVA_OVERLAP_ALLREDUCE"] = "1" if name == "split" else "0"
+        os.environ["LARVA_FORCE_SPLIT"] = "1" if name == "split" else "0"
+        try:
+            m = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
+        finally:
+            os.environ.pop("LARVA_OVERLAP_ALLREDUCE", None)
+            os.environ.pop("LARVA_FORCE_SPLIT", None)
+        m.parse_args(list(FLAGS))
+        torch.manual_seed(0)
+        m.volume_per_step = PATCH * PATCH * BATCH * 3
+        m.prepare(is_training=True, scales=[SCALE])
+        m.time_allreduce = ldist.active()
+        for _ in range(max(a.warmup, 3)):
+            m.train_step_larva(args, val, x, truth)
+        if hasattr(m, "allreduce_events"):
+            m.allreduce_events.clear()
+        secs, _ = timed_rounds(m, args, val, x, truth, a.steps, 3, False)
+        ms = float(np.median([s / a.steps * 1e3 for s in secs]))
+        res = {"ms_per_step": ms, "schedule_ran": m.dp_schedule.get("choice"), "late_graph": getattr(m, "_graph_late", None) is not None,
+               "split_at_float": getattr(m, "_early_lo", None)}
+        if getattr(m, "allreduce_events", None):
+            torch.cuda.synchronize()
+            gaps = sorted(s.elapsed_time(e) * 1e3 for s, e in m.allreduce_events)
+            res["allreduce_exposed_us"] = {"median": gaps[len(gaps) // 2], "min": gaps[0], "max": gaps[-1], "steps": len(gaps)}
+        m.time_allreduce = False
+        # host time: the loss stays on the device, nothing synchronises inside the loop
+        m.sync_loss = False
+        for _ in range(3):
+            m.train_step_larva(args, val, x, truth)
+        host = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                m.train_step_larva(args, val, x, truth)
+            host.append((time.perf_counter() - t0) / 10 * 1e6)
+            torch.cuda.synchronize()
+        res["host_us_per_step"] = float(np.median(host))
+        out[name] = res
+    if ldist.active():
+        # the bucket's isolated all-reduce as prepare() times it when the schedule is left on "auto"
+        m = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
+        m.parse_args(list(FLAGS))
+        m.prepare(is_training=True, scales=[SCALE])
+        out["dp_schedule_auto"] = m.dp_schedule
+    torch.cuda.synchronize()
+    emit(out)
+    if ldist.is_initialized():
+        td.destroy_process_group()
+
+
+def run_dp_probe(a, force_dist):
+    """Start `bench.py --dp-probe` as a child (its communicator must exist before its first GPU call) and parse its line."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "LARVA_DIST_FORCE"):
+        env.pop(k, None)
+    if force_dist:
+        env["LARVA_DIST_FORCE"] = "1"
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dp-probe", "--steps", str(a.steps), "--warmup", str(a.warmup)],
+                       env=env, stdout=subprocess.PIPE, timeout=600)
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("bench.py --dp-probe%s exited with code %d" % (" under LARVA_DIST_FORCE=1" if force_dist else "", r.returncode))
+    return json.loads(lines[-1])
+
+
 def dry_run(a, rank, world, emit):
     """LARVA_BENCH_DRY=1: the launcher / rendezvous / collective / JSON plumbing of a multi-rank run
     with NO kernels (CPU, gloo) -- what the CPU tests drive with 2 and 8 ranks.  Not a measurement."""
@@ -787,6 +875,8 @@ def main():
                     help="only time the dominant kernel (short run for rocprofv3 --pmc passes)")
     ap.add_argument("--wgrad-only", action="store_true",
                     help="only the flat weight-gradient launch + reduction (short run for rocprofv3 --pmc passes)")
+    ap.add_argument("--dp-probe", action="store_true",
+                    help="child mode of the `dp_schedule_1gpu` / `rccl_world1` extras (see dp_probe_child)")
     ap.add_argument("--sync-loss", action="store_true", help="(the default since round 3; kept for old command lines)")
     ap.add_argument("--async-loss", action="store_true",
                     help="headline loop without the reference's per-step loss.item() and with the batch already in the "
@@ -805,6 +895,9 @@ def main():
 
     def emit(obj):
         os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
+    if a.dp_probe:
+        return dp_probe_child(a, emit)
 
     import numpy as np
     import torch
@@ -865,7 +958,8 @@ def main():
         model.allreduce_events.clear()
     rounds = max(1, a.rounds)
     secs, loss = timed_rounds(model, args, val, x, truth, a.steps, rounds, world > 1)
-    per_step = sorted(s / a.steps * 1e3 for s in secs)
+    in_order = [s / a.steps * 1e3 for s in secs]
+    per_step = sorted(in_order)
     ms_per_step = float(np.median(per_step))
     value = world * HR_PIX_PER_BATCH / (ms_per_step * 1e-3) / 1e6
     final_loss = float(loss)
@@ -888,7 +982,11 @@ def main():
     line = {
         "metric": "HR Mpixels/s (LarvaNet x4 multi-exit train step, 48x48 LR patches)",
         "value": value, "unit": "HR Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "ms_per_step_min": per_step[0], "ms_per_step_max": per_step[-1],
+        # every timed round in the order it ran, and which of them sat on the slow plateau (> 1 % over the fastest round:
+        # the two half-batch chains of a step have a fast and a slow phase relation)
+        "ms_per_step_rounds": in_order, "slow_rounds": [bool(v > 1.01 * per_step[0]) for v in in_order],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "48ch batch16 3x48x48->3x192x192 fp32 LarvaNet x4 train_step_larva M4 B4,4,4,4 per GPU "
                                "(BASELINE config 2 at the reference's only channel count)",
@@ -963,29 +1061,25 @@ def main():
         guarded(line, "value_async_resident", async_resident)
 
     if extras:
-        # The weight-gradient schedule a data-parallel rank runs (two launch groups instead of one flat grid, see
-        # DESIGN section 5) on this one GPU, without collectives: the cost of making the all-reduce overlappable.
+        # The weight-gradient schedule a data-parallel rank runs (two launch groups instead of one flat grid, DESIGN
+        # section 5) on this one GPU: wall and HOST time per step of both schedules without a communicator
+        # (`dp_schedule_1gpu`), and the same under a one-rank RCCL communicator (`rccl_world1`: the collectives really
+        # run -- librccl, async all-reduce + Work.wait() between the two captured graphs, the timed all-reduce of
+        # prepare()).  Each in a child process: a communicator must exist before the process's first GPU call.
         def dp_schedule():
-            os.environ["LARVA_FORCE_SPLIT"] = "1"
-            try:
-                m2 = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
-                m2.parse_args(list(FLAGS))
-                torch.manual_seed(0)
-                m2.volume_per_step = PATCH * PATCH * BATCH * 3
-                m2.prepare(is_training=True, scales=[SCALE])
-                m2.sync_loss = ref_semantics
-                for _ in range(max(a.warmup, 1)):
-                    m2.train_step_larva(args, val, x_fresh, truth_fresh)
-                secs3, _ = timed_rounds(m2, args, val, x_fresh, truth_fresh, a.steps, min(rounds, 3), False)
-                ms3 = float(np.median([s / a.steps * 1e3 for s in secs3]))
-                return {"ms_per_step": ms3, "value": HR_PIX_PER_BATCH / (ms3 * 1e-3) / 1e6, "unit": "HR Mpixels/s",
-                        "late_graph": m2._graph_late is not None,
-                        "what": "the same step with the data-parallel weight-gradient schedule (LARVA_FORCE_SPLIT=1: two "
-                                "launch groups + two reductions, the second in a graph of its own), no collectives: what a "
-                                "rank of an N-GPU run computes per step"}
-            finally:
-                os.environ.pop("LARVA_FORCE_SPLIT", None)
+            r = run_dp_probe(a, False)
+            r.update(ms_per_step=r["split"]["ms_per_step"], value=HR_PIX_PER_BATCH / (r["split"]["ms_per_step"] * 1e-3) / 1e6,
+                     unit="HR Mpixels/s", late_graph=r["split"]["late_graph"],
+                     split_costs_us=(r["split"]["ms_per_step"] - r["flat"]["ms_per_step"]) * 1e3)
+            return r
         guarded(line, "dp_schedule_1gpu", dp_schedule)
+
+        def rccl_world1():
+            r = run_dp_probe(a, True)
+            r["note"] = ("ONE rank: a rehearsal of the backend=\"nccl\" code path on the one GPU of this box (every collective is "
+                         "issued and waited for, a sum over one rank is the identity), NOT a scaling measurement")
+            return r
+        guarded(line, "rccl_world1", rccl_world1)
 
     if extras:
         # BASELINE configs 2 / 5 name 32- and 64-channel bodies, which the reference cannot express:

@@ -34,11 +34,36 @@ def is_main():
     return rank() == 0
 
 
+def forced():
+    """LARVA_DIST_FORCE=1: a process without torchrun's environment still builds a ONE-rank communicator (nccl = RCCL on
+    a GPU box) and every helper below runs its real collective through it instead of short-circuiting on "one rank".
+    A rehearsal of the code the driver's multi-GPU launch takes -- librccl loaded beside liblarva_hip.so, Work.wait()
+    ordering a collective against captured graphs, device tensors through all_reduce / broadcast / all_gather --, not
+    a scaling measurement."""
+    return os.environ.get("LARVA_DIST_FORCE", "0") not in ("", "0")
+
+
+def active():
+    """Do the helpers issue collectives?  More than one rank, or a forced one-rank communicator."""
+    return is_initialized() and (world_size() > 1 or forced())
+
+
 def init_from_env(backend=None):
     """Initialise from torchrun's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (no-op if absent or 1)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or is_initialized():
+    if is_initialized() or (ws <= 1 and not forced()):
         return rank(), world_size()
+    if ws <= 1:
+        # forced one-rank communicator (see forced()): a rendezvous of its own on the loopback
+        import socket
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("LOCAL_RANK", "0")
+        os.environ["WORLD_SIZE"] = "1"
+        if "MASTER_PORT" not in os.environ:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     ndev = torch.cuda.device_count()   # (counting devices does not initialise the runtime)
@@ -58,7 +83,7 @@ def init_from_env(backend=None):
 
 def broadcast_parameters(module, src=0):
     """Every rank starts from rank `src`'s weights (the reference seeds nothing)."""
-    if world_size() == 1:
+    if not active():
         return
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     if not tensors:
@@ -71,7 +96,7 @@ def broadcast_parameters(module, src=0):
 
 def allreduce_sum(t, async_op=False):
     """In-place sum over ranks of a (slice of a) flat buffer; async_op -> the Work handle."""
-    if world_size() == 1:
+    if not active():
         return None
     return td.all_reduce(t, op=td.ReduceOp.SUM, async_op=async_op)
 
@@ -80,7 +105,7 @@ def time_allreduce_us(flat, warmup=3, iters=10):
     """Median wall time (us) of an ISOLATED sum all-reduce of `flat` (the gradient bucket), agreed on by all ranks
     (MAX over ranks): what the training step would wait for if it issued ONE collective after backward.  The buffer's
     contents are restored.  Used once at prepare() to choose the data-parallel weight-gradient schedule."""
-    if world_size() == 1:
+    if not active():
         return 0.0
     import time
     keep = flat.clone()
@@ -107,7 +132,7 @@ def allreduce_gradients(module, bucket=None):
     """Mean of the gradients over ranks as ONE collective.  With a GradBucket the gradients already
     live in one flat buffer (no flatten / unflatten copies); otherwise they are flattened here."""
     ws = world_size()
-    if ws == 1:
+    if not active():
         return
     if bucket is not None and bucket.intact(module):
         td.all_reduce(bucket.flat, op=td.ReduceOp.SUM)
@@ -124,7 +149,7 @@ def allreduce_gradients(module, bucket=None):
 
 
 def allreduce_scalar_sum(value, device):
-    if world_size() == 1:
+    if not active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if td.get_backend() == "nccl" else "cpu")
     td.all_reduce(t, op=td.ReduceOp.SUM)
@@ -137,7 +162,7 @@ def all_gather_tensor(t):
     no host round trip."""
     ws = world_size()
     t = t.contiguous()
-    if ws == 1:
+    if not active():
         return t.unsqueeze(0)
     out = torch.empty((ws,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     try:
@@ -155,7 +180,7 @@ def seed_for_rank(base_seed):
 
 def gather_objects(obj):
     """All ranks' python objects, in rank order, on every rank."""
-    if world_size() == 1:
+    if not active():
         return [obj]
     out = [None] * world_size()
     td.all_gather_object(out, obj)

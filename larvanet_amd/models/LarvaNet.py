@@ -281,10 +281,6 @@ class LarvaNet(BaseModel):
         # measurement: run the data-parallel step's weight-gradient schedule (two launch groups, so that the first
         # group's slice of the bucket can be all-reduced beside the second) on ONE GPU, without collectives
         self.force_split_backward = os.environ.get("LARVA_FORCE_SPLIT", "0") != "0"
-        # the next batch copied into the captured step's inputs beside the previous step's backward (_stage_inputs):
-        # measured in round 4 and LEFT OFF -- step 1.669-1.672 ms with, 1.657-1.660 without (same box, alternating): the
-        # two cross-stream waits cost more than the two 5 us copies they hide
-        self.overlap_input_copies = os.environ.get("LARVA_OVERLAP_INPUT_COPIES", "0") != "0"
 
     # ------------------------------------------------------------------ flags
     def _add_args(self, parser):
@@ -355,6 +351,9 @@ class LarvaNet(BaseModel):
             else:
                 self.grad_bucket = None
                 self.optim = torch.optim.AdamW(params, lr=self.args.lr)
+                if self.overlap_allreduce == "auto":   # (no flat bucket on the CPU: nothing to overlap)
+                    self.overlap_allreduce = False
+                self.dp_schedule = {"choice": "flat", "why": "CPU tensors: one collective over flattened gradients"}
             self.scheduler = self._make_scheduler()
 
     # Splitting the weight gradients into two launch groups so that the first group's slice of the bucket (its upper
@@ -367,24 +366,28 @@ class LarvaNet(BaseModel):
     DP_SPLIT_ABOVE_US = 90.0
 
     def _choose_dp_schedule(self):
-        """LARVA_OVERLAP_ALLREDUCE=auto: time the bucket's all-reduce once and pick the schedule."""
+        """LARVA_OVERLAP_ALLREDUCE=auto: time the bucket's all-reduce once and pick the schedule.
+        `dp_schedule["choice"]` names the schedule the step really runs (LARVA_FORCE_SPLIT included), and
+        `overlap_allreduce` is a bool on every path out of here."""
         ws = ldist.world_size()
         if self.overlap_allreduce != "auto":
-            self.dp_schedule = {"choice": "split" if self.overlap_allreduce else "flat", "why": "LARVA_OVERLAP_ALLREDUCE"}
-            return
-        if ws == 1:
+            self.overlap_allreduce = bool(self.overlap_allreduce)
+            self.dp_schedule = {"why": "LARVA_OVERLAP_ALLREDUCE"}
+        elif not ldist.active():
             self.overlap_allreduce = True     # (only consulted with more than one rank, or by LARVA_FORCE_SPLIT)
-            self.dp_schedule = {"choice": "flat", "why": "one rank"}
-            return
-        t_us = ldist.time_allreduce_us(self.grad_bucket.flat)
-        self.overlap_allreduce = t_us > self.DP_SPLIT_ABOVE_US
-        self.dp_schedule = {"choice": "split" if self.overlap_allreduce else "flat", "allreduce_isolated_us": t_us,
-                            "bucket_bytes": int(self.grad_bucket.flat.numel()) * 4, "ranks": ws,
-                            "rule": "split (two weight-gradient launch groups, the first slice all-reduced beside the second) "
-                                    "when the isolated all-reduce of the bucket takes more than %.0f us" % self.DP_SPLIT_ABOVE_US}
-        if ldist.is_main():
+            self.dp_schedule = {"why": "one rank, no communicator"}
+        else:
+            t_us = ldist.time_allreduce_us(self.grad_bucket.flat)
+            self.overlap_allreduce = t_us > self.DP_SPLIT_ABOVE_US
+            self.dp_schedule = {"allreduce_isolated_us": t_us, "bucket_bytes": int(self.grad_bucket.flat.numel()) * 4, "ranks": ws,
+                                "rule": "split (two weight-gradient launch groups, the first slice all-reduced beside the second) "
+                                        "when the isolated all-reduce of the bucket takes more than %.0f us" % self.DP_SPLIT_ABOVE_US}
+        self.dp_schedule["choice"] = "split" if self._split_backward() else "flat"
+        if self.force_split_backward:
+            self.dp_schedule["forced"] = "LARVA_FORCE_SPLIT"
+        if ldist.active() and ldist.is_main() and "allreduce_isolated_us" in self.dp_schedule:
             print("data-parallel weight-gradient schedule: %s (isolated all-reduce of the %.2f MB bucket over %d ranks: %.1f us)"
-                  % (self.dp_schedule["choice"], self.dp_schedule["bucket_bytes"] / 1e6, ws, t_us))
+                  % (self.dp_schedule["choice"], self.dp_schedule["bucket_bytes"] / 1e6, ws, self.dp_schedule["allreduce_isolated_us"]))
 
     # ------------------------------------------------------------------ training
     def _grad_one(self, loss):
@@ -508,7 +511,7 @@ class LarvaNet(BaseModel):
         """Data parallel with in-place gradients: backward ends in two halves so that the
         all-reduce of the first overlaps the weight-gradient kernels of the second."""
         bucket = getattr(self, "grad_bucket", None)
-        return (self.overlap_allreduce and self.defer_wgrad and (ldist.world_size() > 1 or self.force_split_backward)
+        return (self.overlap_allreduce is True and self.defer_wgrad and (ldist.active() or self.force_split_backward)
                 and bucket is not None and bucket.intact(self.model))
 
     def _note_early(self, scope):
@@ -598,35 +601,12 @@ class LarvaNet(BaseModel):
 
     def _stage_inputs(self, input_tensor, truth_tensor):
         """The batch into the captured step's input buffers (train_larva.py:123-128 hands over fresh device tensors every
-        step).  The buffers are read by the step's FORWARD only (prologue, head, the exits' L1), so once the host has
-        seen the previous step's loss -- which the launch behind the exits stores (early-loss captures) -- they are free
-        while that step's backward, weight gradients and AdamW still run: with overlap_input_copies the two copies go to a
-        stream of their own and overlap that tail instead of standing in front of this step's graph (round 4, VERDICT r3
-        item 3; measured slower -- see __init__ -- and off by default).  Without that knowledge (no per-step loss
-        read-back, first step) they stay on the current stream."""
-        pairs = [(dst, src) for dst, src in ((self._static_in, input_tensor), (self._static_truth, truth_tensor))
-                 if src.data_ptr() != dst.data_ptr()]
-        if not pairs:
-            return
-        free, self._inputs_free = getattr(self, "_inputs_free", False), False
-        if free and self.overlap_input_copies and self._inputs_dead_after_forward():
-            if getattr(self, "_copy_stream", None) is None:
-                self._copy_stream = torch.cuda.Stream()
-            with torch.cuda.stream(self._copy_stream):
-                for dst, src in pairs:
-                    dst.copy_(src, non_blocking=True)
-            # (the sources stay valid: the current stream, on which the caller may free them, waits for the copies here)
-            torch.cuda.current_stream().wait_stream(self._copy_stream)
-        else:
-            for dst, src in pairs:
+        step), on the current stream, i.e. ordered behind whatever produced them.  (Round 4 also copied them on a stream
+        of its own beside the previous step's backward: 1.669-1.672 against 1.657-1.660 ms -- two cross-stream waits cost
+        more than the two 5 us copies they hide -- and, without an edge from the producer's stream, a race; removed.)"""
+        for dst, src in ((self._static_in, input_tensor), (self._static_truth, truth_tensor)):
+            if src.data_ptr() != dst.data_ptr():
                 dst.copy_(src)
-
-    def _inputs_dead_after_forward(self):
-        """Does nothing behind the forward read the step's input / truth buffers?  True for the stock L1 exits whose
-        gradient is written by the forward sweep (ExitFn / ExitsFn keep sign(out - truth), not the truth); any other
-        loss keeps the truth for its backward."""
-        return (isinstance(self.loss_fn, L1Loss) and self.l1_grad_in_forward
-                and all(isinstance(getattr(self.model, "body_%d" % i).leg, LarvaLeg) for i in range(self.args.num_modules)))
 
     def _zero_grad(self):
         """optim.zero_grad() of the reference (models/LarvaNet.py:112).  With the flat gradient
@@ -691,7 +671,7 @@ class LarvaNet(BaseModel):
         late, self._late = getattr(self, "_late", None), None
         ws = ldist.world_size()
         bucket = getattr(self, "grad_bucket", None)
-        if ws == 1 or bucket is None or not bucket.intact(self.model):
+        if not ldist.active() or bucket is None or not bucket.intact(self.model):
             if late is not None:
                 late()
             ldist.allreduce_gradients(self.model, None)   # already the mean: no second 1/world in the optimizer
@@ -769,15 +749,10 @@ class LarvaNet(BaseModel):
             how, self._loss_in_flight = getattr(self, "_loss_in_flight", False), False
             if how == "event":   # (early-loss captures: see _forward_backward)
                 self._loss_done.synchronize()
-                self._inputs_free = True   # the forward has finished: nothing reads the step's input buffers any more
                 return self._loss_host.item()
             if how == "poll":
-                value = self._poll_loss()
-                self._inputs_free = True
-                return value
-            value = loss.item()
-            self._inputs_free = True
-            return value
+                return self._poll_loss()
+            return loss.item()
         self._loss_in_flight = False
         return loss_copy if loss_copy is not None else loss.detach().clone()
 

@@ -98,9 +98,6 @@ class LarvaNet(V1.LarvaNet):
     def _num_loss_terms(self):
         return self.args.num_modules + 1
 
-    def _inputs_dead_after_forward(self):
-        return False   # the tail's loss is nn.L1Loss through L1LossFn, whose backward reads the truth
-
     def _single_consumer_features(self):
         return False   # the tail's merge conv reads every body output: autograd adds its gradient on the main stream
 

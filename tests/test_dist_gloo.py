@@ -134,3 +134,57 @@ def test_two_rank_gloo():
     assert seen0 == [0, 2, 4] and seen1 == [1, 3]        # image i -> rank i mod world
     assert avg0 == avg1                                  # identical scheduler input on every rank
     assert patch0 != patch1                              # per-rank patch streams
+
+
+def _forced_worker(q):
+    os.environ.update({"LARVA_DIST_FORCE": "1", "LARVA_DIST_BACKEND": "gloo"})
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    import torch.distributed as td
+    from larvanet_amd import dist as ldist
+    assert not ldist.active()
+    r, w = ldist.init_from_env()
+    ok = (r, w) == (0, 1) and ldist.is_initialized() and ldist.active() and td.get_backend() == "gloo"
+    calls = []
+    real = td.all_reduce
+    td.all_reduce = lambda *a, **k: (calls.append("all_reduce"), real(*a, **k))[1]
+    net = torch.nn.Conv2d(3, 4, 3)
+    ldist.broadcast_parameters(net)
+    for p in net.parameters():
+        p.grad = torch.full_like(p, 3.0)
+    ldist.allreduce_gradients(net)
+    grads = [float(p.grad.flatten()[0]) for p in net.parameters()]
+    flat = torch.arange(8, dtype=torch.float32)
+    work = ldist.allreduce_sum(flat[4:], async_op=True)
+    ldist.allreduce_sum(flat[:4])
+    work.wait()
+    t_us = ldist.time_allreduce_us(flat)
+    s = ldist.allreduce_scalar_sum(2.5, torch.device("cpu"))
+    gathered = ldist.all_gather_tensor(torch.full((2, 3), 7.0))
+    objs = ldist.gather_objects("x")
+    q.put((ok, grads, flat.tolist(), t_us > 0, s, tuple(gathered.shape), objs, len(calls)))
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_forced_one_rank_communicator_issues_real_collectives():
+    """LARVA_DIST_FORCE=1 (round 5: the rehearsal of the RCCL path on a one-GPU box, here over gloo): a process
+    without torchrun's environment builds a one-rank group and the helpers stop short-circuiting on "one rank"."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(q,))
+    p.start()
+    ok, grads, flat, timed, s, shape, objs, ncalls = q.get(timeout=100)
+    p.join(timeout=30)
+    assert p.exitcode == 0
+    assert ok and grads == [3.0, 3.0] and flat == list(map(float, range(8))) and timed and s == 2.5
+    assert shape == (1, 2, 3) and objs == ["x"]
+    assert ncalls >= 5   # the gradients, two slices, the timed loop, the scalar: none was skipped
+
+
+def test_helpers_stay_inert_without_a_communicator():
+    from larvanet_amd import dist as ldist
+    assert not ldist.active() and ldist.world_size() == 1
+    t = torch.ones(3)
+    assert ldist.allreduce_sum(t) is None and ldist.time_allreduce_us(t) == 0.0
+    assert ldist.all_gather_tensor(t).shape == (1, 3) and ldist.gather_objects(1) == [1]

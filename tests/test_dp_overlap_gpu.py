@@ -149,3 +149,98 @@ def test_validate_with_one_row_band_per_rank_scores_like_one_gpu(hip_device):
     banded = res[0][2]
     assert [r[:2] for r in banded[4]["per_image"]] == [r[:2] for r in plain[4]["per_image"]]
     assert res[1][2][4]["per_image"] == banded[4]["per_image"]  # gathered on every rank
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RCCL on the ONE GPU of the test box (round 5): LARVA_DIST_FORCE=1 builds a one-rank "nccl" communicator and every helper
+# of larvanet_amd.dist runs its real collective through it.  Not a scaling measurement: a rehearsal of the code path the
+# driver's multi-GPU launch takes (librccl beside liblarva_hip.so, Work.wait() between the two captured graphs of the
+# split schedule, the timed all-reduce, broadcast, PSNR all-reduce, the banded all-gather).
+# ---------------------------------------------------------------------------------------------------------------------
+def _train_three_steps(dev, mode):
+    from larvanet_amd.autograd import DeferredWgrad
+    from larvanet_amd.models import LarvaNet as L
+    keep, DeferredWgrad.jobs_per_launch = DeferredWgrad.jobs_per_launch, 4   # several launches even for a small network
+    try:
+        g = torch.Generator().manual_seed(50)
+        x = (torch.rand(2, 3, 12, 16, generator=g) * 255).to(dev)
+        t = (torch.rand(2, 3, 48, 64, generator=g) * 255).to(dev)
+        args = types.SimpleNamespace(train_path="/tmp")
+        m = L.create_model()
+        m.parse_args(["--num_modules=2", "--num_blocks=2,1"])
+        torch.manual_seed(7)
+        m.prepare(is_training=True, scales=[4])
+        if mode != "plain":
+            m.overlap_allreduce = mode != "whole"
+            m.use_hip_graph = mode == "overlap_graph"
+        losses = [m.train_step_larva(args, _Val(), x, t) for _ in range(3)]
+        torch.cuda.synchronize()
+    finally:
+        DeferredWgrad.jobs_per_launch = keep
+    return m, {"losses": losses, "split_at": getattr(m, "_early_lo", None), "graph": bool(m.use_hip_graph),
+               "sd": {k: v.cpu().numpy().copy() for k, v in m.model.state_dict().items()}}
+
+
+def _rccl_world1_worker(q):
+    os.environ.update({"LARVA_DIST_FORCE": "1", "LARVA_DIST_BACKEND": "nccl"})
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    try:
+        import torch.distributed as td
+        from larvanet_amd import dist as ldist, image_utils, validate
+        rank, world = ldist.init_from_env()
+        assert (rank, world) == (0, 1) and td.get_backend() == "nccl" and ldist.active()
+        dev = torch.device("cuda", 0)
+        out = {}
+        for mode in ("whole", "overlap_eager", "overlap_graph"):
+            m, out[mode] = _train_three_steps(dev, mode)
+            # prepare() timed a device tensor through RCCL and chose from it
+            out[mode]["dp_schedule"] = dict(m.dp_schedule)
+        # the banded all-gather: one band = the whole image, through all_gather_into_tensor on the device
+        lr = np.random.RandomState(5).randint(0, 256, size=(3, 9, 12)).astype(np.float32)
+        m.model.eval()
+        with torch.no_grad():
+            banded = image_utils.upscale_banded_device(m, lr, 4, 0, 1, ldist.all_gather_tensor)
+            whole = m.upscale_tensor(input_list=[lr])[0]
+        out["band_equal"] = bool(torch.equal(banded, whole))
+        out["psnr_sum"] = ldist.allreduce_scalar_sum(12.5, dev)
+        torch.manual_seed(0)
+        out["validate"] = validate.main(_VALIDATE_ARGS + ["--band_gpus"])[4]["per_image"]
+        torch.cuda.synchronize()
+        q.put((None, out))
+        td.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put(("%s\n%s" % (e, traceback.format_exc()), None))
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_rccl_communicator_runs_every_collective_of_the_data_parallel_step(hip_device):
+    """The "nccl" backend has no other GPU to talk to on this box, but a one-rank communicator still goes through
+    librccl: the split schedule (async all-reduce of the bucket's upper slice + Work.wait() between the two captured
+    graphs), the single collective, broadcast_parameters, the timed all-reduce of prepare(), the PSNR all-reduce and the
+    banded all-gather all execute, and train exactly like the step without a communicator (a sum over one rank and a
+    mean scale of 1/1 are the identity, bit for bit)."""
+    from larvanet_amd import validate
+    _, plain = _train_three_steps(hip_device, "plain")
+    torch.manual_seed(0)
+    plain_val = validate.main(list(_VALIDATE_ARGS))[4]["per_image"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(q,))
+    p.start()
+    err, out = q.get(timeout=500)
+    p.join(timeout=60)
+    assert err is None, err
+    assert out["whole"]["split_at"] is None
+    for mode in ("overlap_eager", "overlap_graph"):
+        assert out[mode]["split_at"] and out[mode]["split_at"] > 0, "backward was not split: nothing overlapped"
+    assert out["overlap_graph"]["graph"], "hipGraph capture of the split backward fell back to eager launches"
+    for mode in ("whole", "overlap_eager", "overlap_graph"):
+        sched = out[mode]["dp_schedule"]
+        assert sched["ranks"] == 1 and sched["allreduce_isolated_us"] > 0 and sched["choice"] in ("flat", "split")
+        assert out[mode]["losses"] == plain["losses"], mode
+        for k in plain["sd"]:
+            assert np.array_equal(out[mode]["sd"][k], plain["sd"][k]), (mode, k)
+    assert out["band_equal"] and out["psnr_sum"] == 12.5
+    assert [r[:2] for r in out["validate"]] == [r[:2] for r in plain_val]

@@ -607,26 +607,3 @@ def test_relu_backward_from_sign_bits_trains_exactly_like_the_fp32_mask(hip_devi
     assert results[0][0] == results[1][0]
     for k in results[0][1]:
         assert np.array_equal(results[0][1][k], results[1][1][k]), k
-
-
-def test_input_copies_beside_the_previous_backward_change_nothing(hip_device):
-    """Round 4: with the reference's per-step loss read-back the next batch is copied into the captured step's input
-    buffers on a stream of its own, beside the previous step's backward (LarvaNet._stage_inputs).  Different batches
-    every step, graph replay: losses and weights identical to copies on the main stream."""
-    args = types.SimpleNamespace(train_path="/tmp")
-    g = torch.Generator().manual_seed(53)
-    batches = [((torch.rand(4, 3, 16, 20, generator=g) * 255).to(hip_device), (torch.rand(4, 3, 64, 80, generator=g) * 255).to(hip_device))
-               for _ in range(5)]
-    results = []
-    for overlap in (False, True):
-        m = _model("LarvaNet", ["--num_modules=2", "--num_blocks=2,1"], training=True, seed=3)
-        m.overlap_input_copies = overlap
-        assert m.use_hip_graph and m.sync_loss
-        losses = [m.train_step_larva(args, FakeValLoader(7), x.clone(), t.clone()) for x, t in batches]
-        assert m.use_hip_graph
-        if overlap:
-            assert getattr(m, "_copy_stream", None) is not None   # the side stream was really used
-        results.append((losses, {k: v.cpu().numpy().copy() for k, v in m.model.state_dict().items()}))
-    assert results[0][0] == results[1][0] and len(set(results[0][0])) == 5
-    for k in results[0][1]:
-        assert np.array_equal(results[0][1][k], results[1][1][k]), k
