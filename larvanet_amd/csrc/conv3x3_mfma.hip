@@ -627,12 +627,15 @@ __device__ __forceinline__ void shadow_groups() {
 // SWAP: the MFMA's A operand = activations (M = 16 pixels), B = weights (N = 16 output channels), so
 // that a lane ends up with 4 CONSECUTIVE PIXELS of one output channel (see run_role's epilogue) instead
 // of 4 consecutive output channels of one pixel.  Same products, same k order: identical results.
+// wstage: the chunk's weight rows when they do not sit behind the input planes of `stage` (a weight image kept apart
+// from the input ring: the pair-chain measurement kernel), else null.
 template <int COUT, typename G, int NCT, int PG0, int NPG, bool PREFETCH, bool SWAP>
 __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave, int lane,
                                            f32x4 (&acc)[NCT][NPG], const DmaPlan<COUT, G>& pl, const ChunkSrc& nxt,
-                                           unsigned nxt_stage) {
+                                           unsigned nxt_stage, const float* wstage = nullptr) {
   using C = ConvCfg<COUT, G>;
   const int lr = lane & 15, lq = lane >> 4;
+  const float* const wrows = wstage ? wstage : stage + C::IN_FLOATS;
   // Weight rows: lane (lr, lq) reads row (tap, k = 4 kk + lq), channel 16 (ct0 + c) + lr.  At 32 / 64 output channels
   // the rows are unpadded and odd rows (lq odd) are stored with their 16-channel groups swapped in pairs (column
   // c ^ 16, cout_swizzled): the group index becomes (ct0 + c) ^ (lq & 1) -- a per-lane base per output-channel
@@ -640,7 +643,7 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
   const float* a_base[NCT];
 #pragma unroll
   for (int c = 0; c < NCT; ++c)
-    a_base[c] = stage + C::IN_FLOATS + lq * C::CS + lr + (cout_swizzled(COUT) ? (((ct0 + c) ^ (lq & 1)) * 16) : (ct0 + c) * 16);
+    a_base[c] = wrows + lq * C::CS + lr + (cout_swizzled(COUT) ? (((ct0 + c) ^ (lq & 1)) * 16) : (ct0 + c) * 16);
   const float* b_base = stage + lq * C::PS + lr + 3;
   constexpr int kEvery = C::STEPS / C::NPW > 0 ? C::STEPS / C::NPW : 1;
 #if LARVA_SHADOW
@@ -2278,3 +2281,8 @@ int larva_conv3x3_fwd_strips_timed(const float* const* src, int n_src, int cin_p
 }
 
 }  // extern "C"
+
+#ifdef LARVA_DIAG_API
+// measurement kernels that are NOT part of liblarva_hip.so (tools/build_variant.sh diag -DLARVA_DIAG_API=1)
+#include "conv3x3_pair_chain.inc"
+#endif
