@@ -737,16 +737,22 @@ class HeadFn(torch.autograd.Function):
     which reads the 16-channel padded image -- so that copy is made whenever a backward will follow."""
 
     # rocprofv3 A/B at 16 x 3 x 48 x 48 (profiles/README.md, r02_head_*): padded-MFMA launch 7.2 us, direct
-    # kernel 9.0 us (LDS-broadcast weights; 12.8 us with scalar-loaded weights) -> MFMA is the default
-    direct = os.environ.get("LARVA_HEAD_DIRECT", "0") != "0"
+    # kernel 9.0 us (LDS-broadcast weights; 12.8 us with scalar-loaded weights) -> MFMA at the training size.  A whole
+    # validation image is another matter: 33 MB of output, the padded MFMA launch 31.6 us = 1.05 TB/s against the direct
+    # kernel's 4-pixel x 8-channel threads with 16-byte stores (round 5, profiles/r05_infer_*): "auto" = direct for
+    # inference on more than DIRECT_ABOVE_PIXELS LR pixels; 0 / 1 = never / always.
+    direct = {"0": False, "1": True}.get(os.environ.get("LARVA_HEAD_DIRECT", "auto"), "auto")
+    DIRECT_ABOVE_PIXELS = 100000
 
     @staticmethod
     def forward(ctx, x, weight, bias, pc, x16=None):
         N, C, H, W = x.shape
         P = PaddedWidth.pitch_of(W) if _lw() is not None else W
         cout = int(weight.shape[0])
-        training = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])   # a weight gradient will be asked for
-        use_direct = HeadFn.direct and C == 3 and cout % 16 == 0
+        # a weight gradient will be asked for (needs_input_grad reports the parameters' requires_grad even under no_grad)
+        training = torch.is_grad_enabled() and bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        want = HeadFn.direct if HeadFn.direct != "auto" else (not training and N * H * P > HeadFn.DIRECT_ABOVE_PIXELS)
+        use_direct = want and C == 3 and cout % 16 == 0
         if x16 is not None:      # prepared by the step's prologue launch (step_prologue)
             pass
         elif training or not use_direct:

@@ -27,6 +27,7 @@
 #include "larva_common.h"
 #include "larva_bicubic.h"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 #include <type_traits>
 
 // Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
@@ -757,10 +758,27 @@ struct ChainIO {   // CHAIN: this layer's tensors and what its input waits for (
   int naps;                      // 64-clock naps between two looks at the counter
 };
 
-template <int COUT, typename G, bool VEC, int EPI, int NCT, int PG0, int NPG, bool AUXLDS = false, bool CHAIN = false>
+// virtual block index -> (image, tile origin) of a whole-tensor launch (a.nwg tiles of G::ROWS x G::COLS pixels)
+template <typename G>
+__device__ __forceinline__ void decode_tile(const ConvArgs& a, int vb, int& n, int& y0, int& x0) {
+  const int tile = xcd_remap(vb, a.nwg);
+  const int t2 = div_by_magic(tile, a.magic_tx);
+  const int tx = tile - t2 * a.tiles_x;
+  n = div_by_magic(t2, a.magic_ty);
+  const int ty = t2 - n * a.tiles_y;
+  x0 = tx * G::COLS;
+  y0 = ty * G::ROWS;
+}
+
+// PERSIST (conv3x3_mfma_persist_kernel): the workgroup walks tiles blockIdx.x, + gridDim.x, ... of the launch; the loader
+// wave streams EVERY chunk (run_loader_persist), the ring runs on across the tiles, and this wave only meets the loader
+// at one barrier per chunk, multiplies, and stores its tile while the next tile's first chunks are already in LDS.
+template <int COUT, typename G, bool VEC, int EPI, int NCT, int PG0, int NPG, bool AUXLDS = false, bool CHAIN = false,
+          bool PERSIST = false>
 __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0, int wave, int n, int y0,
                                          int x0, int tid, ChainIO io = ChainIO{}) {
   using C = ConvCfg<COUT, G>;
+  static_assert(!PERSIST || (VEC && C::LOADER && C::NST == 3 && !AUXLDS && !CHAIN), "persistent tiles: the loader-wave path");
   static_assert(!AUXLDS || (VEC && C::LOADER && LARVA_PIXEL_MAJOR && (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2)),
                 "epilogue operands in LDS: the loader-wave path's mask / residual epilogues");
   const int lane = tid & 63;
@@ -813,7 +831,11 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   auto bits_at = [&](int c, int y, int xcol) {   // byte offset of this lane's nibble of unit (channel group ct0 + c, row y, column xcol)
     return ((((size_t)n * C::CT + (ct0 + c)) * k.H + y) * nxg + (xcol >> 4)) * 64 + lane;
   };
-  auto load_aux = [&]() {
+  // part >= 0: only the units u = c * NPG + p with u % 4 == part (PERSIST: a tile's operands are requested a quarter at a
+  // time in front of its first four K chunks -- as one burst at the tile's start, on every CU at once, they stood in the
+  // memory pipeline in front of the loader wave's next chunks: +14 us per layer with two residual operands; the last
+  // quarter still has the rest of the K loop to arrive)
+  auto load_aux = [&](int part = -1) {
     if constexpr (EPI == kEpiMaskBits) {
 #pragma unroll
       for (int c = 0; c < NCT; ++c)
@@ -827,6 +849,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
       for (int p = 0; p < NPG; ++p) {
+        if (part >= 0 && (c * NPG + p) % 4 != part) continue;   // (wave-uniform)
         const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
         const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
         if constexpr (kShuffleEpi) {
@@ -868,12 +891,18 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   // images, and requested late the batched L1 launch got SLOWER -- 66 against 58 us under rocprofv3, the exits' forward
   // 120 against 112 us in the stamped step: they then queue in front of the loader wave's chunk-2 pieces)
   constexpr bool kAuxLate = LARVA_AUX_LATE && VEC && C::LOADER && C::NST == 3 && LARVA_AUX_EARLY && LARVA_PIXEL_MAJOR && !AUXLDS &&
-                            (!kShuffleEpi || LARVA_AUX_LATE_EXITS) && !(LARVA_DIAG & 6) && (NAUX > 0 || EPI == kEpiMaskBits);
+                            (!kShuffleEpi || LARVA_AUX_LATE_EXITS) && !(LARVA_DIAG & 6) && (NAUX > 0 || EPI == kEpiMaskBits) && !PERSIST;
   constexpr int kAuxLoads = kAuxLate ? (EPI == kEpiMaskBits ? 1 : NAUX) * NCT * NPG : 0;
   auto load_early = [&]() {
     load_bias();
     if constexpr ((NAUX > 0 || EPI == kEpiMaskBits) && LARVA_AUX_EARLY && !kAuxLate && !(LARVA_DIAG & 4)) load_aux();
   };
+  int pstage = 0;   // PERSIST: the ring's stage, running on across the workgroup's tiles
+  for (int vb = blockIdx.x;; vb += gridDim.x) {   // (one trip unless PERSIST)
+  if constexpr (PERSIST) {
+    if (vb >= a.nwg) break;
+    decode_tile<G>(a, vb, n, y0, x0);
+  }
   if constexpr (!VEC || (LARVA_DIAG & 2)) load_early();
 
   f32x4 acc[NCT][NPG];
@@ -883,7 +912,28 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     for (int p = 0; p < NPG; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 auxl[AUXLDS ? NAUX : 1][AUXLDS ? NCT : 1][AUXLDS ? NPG : 1];   // (filled after the K loop, from LDS)
 
-  if constexpr (VEC) {
+  if constexpr (PERSIST) {
+    // bias and the epilogue's operands of THIS tile: requested now, they have the whole K loop to arrive (the vmcnt(0) behind
+    // it also covers the previous tile's stores, long drained)
+    load_bias();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+      asm volatile("s_barrier" ::: "memory");   // the loader has seen the chunk land; everybody is done with the stage before it
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NAUX > 0) {
+        if (chunk < 4) load_aux(chunk);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfma_chunk<COUT, G, NCT, PG0, NPG, false, kPixMajor>(smem + pstage * C::STAGE_FLOATS, ct0, wave, lane, acc, DmaPlan<COUT, G>{},
+                                                           ChunkSrc{}, 0u);
+      pstage = pstage == C::NST - 1 ? 0 : pstage + 1;
+    }
+    if constexpr (NAUX > 0) {
+      for (int part = a.n_chunks; part < 4; ++part) load_aux(part);   // (fewer than four chunks: the rest now)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  } else if constexpr (VEC) {
     // ---- LDS-DMA ring: chunk c lives in stage c % 3; chunks c+1 and c+2 are in flight --------
     // Prologue: the weight pieces of chunk 0 go out first (their offsets need no arithmetic), then
     // bias and epilogue operands, then the input pieces of chunk 0, then all of chunk 1 -- so that
@@ -1196,6 +1246,8 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   stamp(5);
 #endif
+  if constexpr (!PERSIST) break;
+  }
 }
 
 // Fetch every kernel argument NOW, in one batch of scalar loads.  Left alone the compiler loads
@@ -1268,6 +1320,89 @@ __global__ __launch_bounds__((ConvCfg<COUT, GeoWide4>::THREADS_DMA), LARVA_WG_PE
   conv_tile<COUT, true, EPI, GeoWide4>(a, smem);
 }
 static_assert(2 * ConvCfg<48, GeoWide4>::LDS_BYTES_DMA <= 160 * 1024, "two 4 x 48 workgroups per CU");
+
+// ---------------------------------------------------------------------------------------------
+// Persistent whole-tensor launch (round 5): more tiles than the chip has workgroup slots -- a 339 x 510 image is 1243 tiles
+// for 512 slots.  As one workgroup per tile the slots turn over in lockstep: in-kernel stamps of such a launch
+// (tools/diag_wide.py, profiles/r05_infer_wide_layer_stamps.txt) show three synchronized rounds -- 512 workgroups enter within
+// a microsecond, share the matrix pipes two by two through a 21 us K loop, store, and the next 512 all sit in their
+// prologues (kernarg fetch, tile decode, first LDS-DMA round trip: 3.4 us; 6.5 us with a residual operand to fetch) while
+// NO K loop runs -- then 219 workgroups on half-empty CUs.  Here every slot is one workgroup that walks its tiles: the
+// loader wave streams the flattened (tile, chunk) sequence through the same three-stage ring, so the next tile's first
+// two chunks are in LDS before this tile's K loop ends, the MFMA waves' stores drain under the next K loop, and kernarg
+// fetch / role set-up happen once per slot.  Results are bit-identical (a pixel's K loop does not depend on who runs it).
+// ---------------------------------------------------------------------------------------------
+template <int COUT, typename G>
+__device__ __forceinline__ void run_loader_persist(const ConvArgs& a, float* smem, int lane) {
+  using C = ConvCfg<COUT, G>;
+  static_assert(C::NST == 3 && 2 * C::PIECES <= 63, "three stages, two chunks in flight");
+  LoaderPlan<COUT, G> pl;
+  // issue cursor: tile vb_i (image n_i), chunk c_i, stage s_i; it runs two chunks ahead of the chunk being multiplied
+  int vb_i = blockIdx.x, n_i, y0, x0, c_i = 0, s_i = 0;
+  decode_tile<G>(a, vb_i, n_i, y0, x0);
+  make_loader_plan<COUT, G>(a, lane, y0, x0, pl);
+  bool more = true;
+  auto issue = [&]() {
+    const ChunkSrc cs = chunk_src<COUT, G>(a, c_i, n_i);
+    const unsigned dst = lds_addr_of(smem + s_i * C::STAGE_FLOATS);
+#pragma unroll
+    for (int p = 0; p < C::PIECES; ++p)
+      lds_dma16_buf(p < C::IN_PIECES ? cs.img : cs.wgt, pl.voff[p], 0, dst + 1024u * (unsigned)p);
+    s_i = s_i == C::NST - 1 ? 0 : s_i + 1;
+    if (++c_i == a.n_chunks) {
+      c_i = 0;
+      vb_i += gridDim.x;
+      more = vb_i < a.nwg;
+      if (more) {
+        decode_tile<G>(a, vb_i, n_i, y0, x0);
+        make_loader_plan<COUT, G>(a, lane, y0, x0, pl);
+      }
+    }
+  };
+  int ahead = 0;   // chunks issued and not yet handed over
+  issue();
+  ++ahead;
+  if (more) {
+    issue();
+    ++ahead;
+  }
+  while (ahead > 0) {
+    // the oldest chunk in flight has landed once all but the younger one's pieces are done
+    if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");   // hand-over; and everybody has left the stage of the chunk before it
+    __builtin_amdgcn_sched_barrier(0);
+    --ahead;
+    if (more) {
+      issue();
+      ++ahead;
+    }
+  }
+}
+
+template <int COUT, int EPI>
+__global__ __launch_bounds__((ConvCfg<COUT>::THREADS_DMA), LARVA_WG_PER_CU) void conv3x3_mfma_persist_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using G = GeoWide;
+  fetch_args(a);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_amdgcn_s_setprio(1);
+  if (wave == 4) {
+    run_loader_persist<COUT, G>(a, smem, tid & 63);
+    return;
+  }
+  if constexpr (COUT == 48) {   // 27 units -> 7,7,7,6 (as conv_tile)
+    if (wave < 3) run_role<COUT, G, true, EPI, 1, 0, 7, false, false, true>(a, smem, wave, wave, 0, 0, 0, tid);
+    else run_role<COUT, G, true, EPI, 3, 7, 2, false, false, true>(a, smem, 0, wave, 0, 0, 0, tid);
+  } else if constexpr (COUT == 32) {   // 18 -> 5,5,4,4
+    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 5, false, false, true>(a, smem, wave, wave, 0, 0, 0, tid);
+    else run_role<COUT, G, true, EPI, 1, 5, 4, false, false, true>(a, smem, wave - 2, wave, 0, 0, 0, tid);
+  } else {   // 64: 36 -> 9,9,9,9
+    static_assert(COUT == 64, "unsupported channel count");
+    run_role<COUT, G, true, EPI, 1, 0, 9, false, false, true>(a, smem, wave, wave, 0, 0, 0, tid);
+  }
+}
 
 // Strip tiles (48 output channels, LDS-DMA path): every workgroup looks its tile up in a table of
 // ONE image's tiles -- 5 x 16 or 4 x 16 pixels -- and runs the matching instantiation.  ROWS pixel
@@ -1596,6 +1731,52 @@ static hipError_t launch_rows4_e(const ConvArgs& a, hipStream_t stream, const La
   return hipGetLastError();
 }
 
+// workgroup slots of the device for the 16-byte-path kernels (LARVA_WG_PER_CU per CU)
+static int conv_slots() {
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    slots = LARVA_WG_PER_CU * cus;
+  }
+  return slots;
+}
+
+template <int COUT, int EPI>
+static hipError_t launch_persist_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
+  using C = ConvCfg<COUT>;
+  constexpr size_t lds = C::LDS_BYTES_DMA;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_persist_kernel<COUT, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = a.nwg < conv_slots() ? a.nwg : conv_slots();
+  if (tm)
+    hipExtLaunchKernelGGL((conv3x3_mfma_persist_kernel<COUT, EPI>), dim3(grid), dim3(C::THREADS_DMA), lds, stream, tm->start, tm->stop, 0, a);
+  else
+    hipLaunchKernelGGL((conv3x3_mfma_persist_kernel<COUT, EPI>), dim3(grid), dim3(C::THREADS_DMA), lds, stream, a);
+  return hipGetLastError();
+}
+
+// persistent tiles exist for the epilogues of an inference forward; anything else: hipErrorNotSupported
+template <int COUT>
+static hipError_t launch_persist(const ConvArgs& a, int epi, hipStream_t stream, const LaunchTiming* tm) {
+  if constexpr (!ConvCfg<COUT>::LOADER || !LARVA_PIXEL_MAJOR) return hipErrorNotSupported;
+  else switch (epi) {
+    case kEpiPlain: return launch_persist_e<COUT, kEpiPlain>(a, stream, tm);
+    case kEpiRelu: return launch_persist_e<COUT, kEpiRelu>(a, stream, tm);
+    case kEpiRes1: return launch_persist_e<COUT, kEpiRes1>(a, stream, tm);
+    case kEpiRes2: return launch_persist_e<COUT, kEpiRes2>(a, stream, tm);
+    case kEpiShuffle: return launch_persist_e<COUT, kEpiShuffle>(a, stream, tm);
+    case kEpiShuffleBase: return launch_persist_e<COUT, kEpiShuffleBase>(a, stream, tm);
+    default: return hipErrorNotSupported;
+  }
+}
+
 // 4 x 48 tiles exist for the epilogues of an inference forward (head, conv + ReLU, the two residual forms, the
 // pixel-shuffle exits); anything else: hipErrorNotSupported, the caller launches the 3 x 48 tiles
 template <int COUT>
@@ -1897,6 +2078,22 @@ static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, co
     return (int)launch_rows4<48>(a, epi, s, tm);
   }
   if (tile_rows == 4) return (int)hipErrorNotSupported;
+  // more tiles than workgroup slots (a full image): one persistent workgroup per slot (conv3x3_mfma_persist_kernel)
+  // (LARVA_PERSIST=0: one workgroup per tile as before -- read per call, the tests compare the two)
+  const char* pe = getenv("LARVA_PERSIST");
+  const bool persist_on = !(pe && pe[0] == '0');
+  if (persist_on && aligned && !mb.in && !mb.out && a.nwg > conv_slots() && a.n_chunks >= 1) {
+    hipError_t e = hipErrorNotSupported;
+    switch (cout) {
+#if !LARVA_DIAG_ONLY48
+      case 32: e = launch_persist<32>(a, epi, s, tm); break;
+      case 64: e = launch_persist<64>(a, epi, s, tm); break;
+#endif
+      case 48: e = launch_persist<48>(a, epi, s, tm); break;
+      default: break;
+    }
+    if (e != hipErrorNotSupported) return (int)e;
+  }
   switch (cout) {
 #if !LARVA_DIAG_ONLY48
     case 32: return (int)launch_conv<32>(a, aligned, epi, s, tm);

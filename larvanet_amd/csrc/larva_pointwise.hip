@@ -19,6 +19,63 @@ __global__ void bicubic4_kernel(const float* __restrict__ in, float* __restrict_
                 (long long)gridDim.x * blockDim.x);
 }
 
+// The same arithmetic, one thread per LR pixel = its 4 x 4 block of HR pixels (round 5, the stand-alone launch of the
+// inference forward: a 339 x 510 image is 33 MB of base image).  The 16 outputs of a block read the same 5 x 5 window of
+// LR pixels -- 25 loads instead of 4 x 20 --, the row / column weights are computed once per block, the index is decoded
+// once with 32-bit divisions, and a wave stores four 1 KiB runs.  bicubic4_kernel took 23.1 us for that image (1.44 TB/s).
+__global__ __launch_bounds__(256) void bicubic4_block_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              unsigned planes, unsigned H, unsigned W) {
+  const unsigned total = planes * H * W;   // (< 2^31: checked by the launcher)
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  const unsigned x = i % W, t2 = i / W, y = t2 % H, p = t2 / H;
+  const float* src = in + (size_t)p * H * W;
+  float v[5][5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int yy = min(max((int)y - 2 + r, 0), (int)H - 1);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) v[r][c] = src[(size_t)yy * W + min(max((int)x - 2 + c, 0), (int)W - 1)];
+  }
+  float wx[4][4];
+  int c0[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int X = 4 * (int)x + jj;
+    const float sx = 0.25f * ((float)X + 0.5f) - 0.5f;
+    const float fx = floorf(sx);
+    cubic_coeffs(sx - fx, wx[jj]);
+    c0[jj] = (int)fx - 1 - ((int)x - 2);   // 0 for jj < 2, 1 for jj >= 2
+  }
+  float* o = out + ((size_t)p * (4 * H) + 4 * y) * (4 * W) + 4 * x;
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    const int Y = 4 * (int)y + ii;
+    const float sy = 0.25f * ((float)Y + 0.5f) - 0.5f;
+    const float fy = floorf(sy);
+    float wy[4];
+    cubic_coeffs(sy - fy, wy);
+    const int r0 = (int)fy - 1 - ((int)y - 2);   // 0 for ii < 2, 1 for ii >= 2
+    f32x4 q;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float rowv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float a = r0 == 0 ? (c0[jj] == 0 ? v[r][c] : v[r][c + 1]) : (c0[jj] == 0 ? v[r + 1][c] : v[r + 1][c + 1]);
+          rowv += wx[jj][c] * a;
+        }
+        acc += wy[r] * rowv;
+      }
+      q[jj] = acc;
+    }
+    *reinterpret_cast<f32x4*>(o + (size_t)ii * (4 * W)) = q;
+  }
+}
+
 // The other F.interpolate mode the reference's --interpolate flag can reach (models/LarvaNet.py:57,283-285 always
 // passes align_corners=False, which F.interpolate refuses for nearest / area with a ValueError; 'linear' and
 // 'trilinear' do not take 4-D input): BILINEAR x4.  src = max(0.25 (dst + 0.5) - 0.5, 0), i0 = floor(src),
@@ -132,6 +189,74 @@ __global__ __launch_bounds__(256) void head_conv3_direct_kernel(const float* __r
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc = fmaf(v[k], wj[k], acc);
     o[j * plane] = real ? acc : 0.f;
+  }
+}
+
+// The same layer for LARGE images (round 5: the head of a 339 x 510 validation image writes 33 MB; on the padded MFMA launch
+// it took 31.6 us = 1.05 TB/s): one thread = 4 consecutive pixels of a row x 8 output channels -- 54 inputs in registers,
+// the block's 8 x 27 weights broadcast from LDS, every output channel's 4 pixels leave as ONE 16-byte store (a wave
+// writes 1 KiB runs instead of 256-byte ones).  Same fma chain per output as head_conv3_direct_kernel.  pitch % 4 == 0.
+constexpr int kHead4Couts = 8;
+
+__global__ __launch_bounds__(256) void head_conv3_direct4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int N, int cout, int H, int W, int pitch) {
+  __shared__ __attribute__((aligned(16))) float wl[kHead4Couts][28];
+  const int co0 = blockIdx.y * kHead4Couts;
+  for (int i = threadIdx.x; i < kHead4Couts * 28; i += 256) {
+    const int j = i / 28, k = i - j * 28;
+    wl[j][k] = k < 27 ? w[(co0 + j) * 27 + k] : (bias ? bias[co0 + j] : 0.f);   // slot 27 = the bias
+  }
+  __syncthreads();
+  const unsigned q4 = (unsigned)pitch >> 2;
+  const unsigned total = (unsigned)N * H * q4;          // groups of 4 pixels (< 2^31: checked by the launcher)
+  const unsigned gidx = blockIdx.x * 256u + threadIdx.x;
+  if (gidx >= total) return;
+  const int xq = (int)(gidx % q4), t = (int)(gidx / q4), y = t % H, n = t / H;
+  const int x0 = 4 * xq;
+  const float* xb = x + (size_t)n * 3 * H * W;
+  const int cplane = H * W;
+  float v[3][3][6];   // [channel][row y-1..y+1][column x0-1..x0+4], zero outside the image
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = y + ky - 1;
+    const bool rok = yy >= 0 && yy < H;
+    const int roff = min(max(yy, 0), H - 1) * W;
+#pragma unroll
+    for (int kx = 0; kx < 6; ++kx) {
+      const int xc = x0 + kx - 1;
+      const bool ok = rok && xc >= 0 && xc < W;
+      const int off = roff + min(max(xc, 0), W - 1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float val = xb[c * cplane + off];
+        v[c][ky][kx] = ok ? val : 0.f;
+      }
+    }
+  }
+  const size_t plane = (size_t)H * pitch;
+  float* o = out + ((size_t)n * cout + co0) * plane + (size_t)y * pitch + x0;
+#pragma unroll
+  for (int j = 0; j < kHead4Couts; ++j) {
+    float wj[28];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wl[j][4 * q]);
+      wj[4 * q] = w4[0]; wj[4 * q + 1] = w4[1]; wj[4 * q + 2] = w4[2]; wj[4 * q + 3] = w4[3];
+    }
+    f32x4 r;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      float acc = wj[27];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc = fmaf(v[c][ky][px + kx], wj[(c * 3 + ky) * 3 + kx], acc);
+      r[px] = (x0 + px < W) ? acc : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(o + (size_t)j * plane) = r;
   }
 }
 
@@ -509,6 +634,12 @@ extern "C" {
 
 int larva_bicubic4_fwd(const float* in, float* out, int N, int C, int H, int W, void* stream) {
   if (!in || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+  const long long px = (long long)N * C * H * W;
+  if (px < (1ll << 31) - 256 && !(reinterpret_cast<uintptr_t>(out) & 15)) {   // one thread per LR pixel = a 4 x 4 block of HR pixels
+    hipLaunchKernelGGL(bicubic4_block_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       (unsigned)(N * C), (unsigned)H, (unsigned)W);
+    return (int)hipGetLastError();
+  }
   const long long work = (long long)N * C * 4 * H * W;
   hipLaunchKernelGGL(bicubic4_kernel, dim3(grid_for(work, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
                      N * C, H, W);
@@ -536,6 +667,12 @@ int larva_head_conv3_direct(const float* x, const float* w, const float* bias, f
     return (int)hipErrorInvalidValue;
   const long long total = (long long)N * H * pitch;
   if (total >= (1ll << 31) - 256 || (long long)N * 3 * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
+  if (pitch % 4 == 0 && cout % kHead4Couts == 0 && !(reinterpret_cast<uintptr_t>(out) & 15)) {
+    // 4 pixels x 8 output channels per thread, 16-byte stores
+    hipLaunchKernelGGL(head_conv3_direct4_kernel, dim3((unsigned)((total / 4 + 255) / 256), cout / kHead4Couts), dim3(256), 0,
+                       (hipStream_t)stream, x, w, bias, out, N, cout, H, W, pitch);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(head_conv3_direct_kernel, dim3((unsigned)((total + 255) / 256), cout / kHeadCoutsPerThread), dim3(256),
                      0, (hipStream_t)stream, x, w, bias, out, N, cout, H, W, pitch);
   return (int)hipGetLastError();

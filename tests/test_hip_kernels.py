@@ -1236,3 +1236,48 @@ def test_four_row_tiles_are_refused_where_they_do_not_exist(hip_device):
     x13 = torch.zeros(1, 48, 5, 13, device=hip_device)                   # register-staged path
     with pytest.raises(RuntimeError, match="hip error 801"):
         K.conv3x3(x13, fwd, 48, tile_rows=4)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(1, 48, 339, 510), (5, 64, 100, 150), (2, 32, 200, 200), (3, 48, 120, 196)])
+@pytest.mark.parametrize("epi", ["plain", "relu", "res1", "res2", "shuffle", "shuffle_base", "two_sources"])
+def test_persistent_tiles_equal_one_workgroup_per_tile_bit_for_bit(hip_device, monkeypatch, N, C, H, W, epi):
+    """Round 5: a whole-tensor launch with more tiles than the chip has workgroup slots (a full validation image:
+    validate.py:94-102 / models/LarvaNet.py:283-293 of the reference) runs as ONE persistent workgroup per slot that walks
+    its tiles behind a loader wave streaming the flattened (tile, chunk) sequence (conv3x3_mfma_persist_kernel).  Same
+    bits as one workgroup per tile (LARVA_PERSIST=0) for every epilogue of the inference forward, 32 / 48 / 64 channels,
+    row-padded widths, several images and concatenated sources."""
+    from larvanet_amd import kernels as K
+    if epi.startswith("shuffle") and C != 48:
+        pytest.skip("pixel-shuffle exits have 48 output channels")
+    P = (W + 3) // 4 * 4
+    assert N * ((H + 2) // 3) * ((P + 47) // 48) > 512, "the case must exceed the 512 workgroup slots"
+    rng = np.random.default_rng(N * 31 + C + H * 7 + W + len(epi))
+    two = epi == "two_sources"
+
+    def padded(shape, scale):
+        t = torch.zeros(shape[:-1] + (P,), device=hip_device)
+        t[..., :W] = _dev(_rand(rng, shape, scale), hip_device)
+        return t
+
+    x, x2 = padded((N, C, H, W), 20.0), padded((N, C, H, W), 20.0)
+    w = _rand(rng, (C, 2 * C if two else C, 3, 3), 0.05)
+    kw = {"bias": _dev(_rand(rng, (C,), 1.0), hip_device), "logical_w": W, "tile_rows": 3}
+    if epi == "relu":
+        kw["relu"] = True
+    if epi in ("res1", "res2"):
+        kw["res0"] = padded((N, C, H, W), 20.0)
+    if epi == "res2":
+        kw["res1"] = padded((N, C, H, W), 20.0)
+    if epi.startswith("shuffle"):
+        kw["shuffle"] = True
+    if epi == "shuffle_base":
+        kw["base"] = _dev(_rand(rng, (N, 3, 4 * H, 4 * W), 50.0), hip_device)
+    fwd, _ = K.pack_weights(_dev(w, hip_device))
+    srcs = [x, x2] if two else x
+    monkeypatch.delenv("LARVA_PERSIST", raising=False)
+    persistent = K.conv3x3(srcs, fwd, C, **kw)
+    monkeypatch.setenv("LARVA_PERSIST", "0")
+    per_tile = K.conv3x3(srcs, fwd, C, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(persistent, per_tile)
+    assert float(persistent.abs().max()) > 1.0   # (something was computed)
