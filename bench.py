@@ -318,13 +318,24 @@ def dual_chain_time_ms(dev, c=CH, chain=40, reps=10, decaying=False):
     return (times[CHAIN_LONG] - times[CHAIN_SHORT]) / (CHAIN_LONG - CHAIN_SHORT), rms, times[CHAIN_SHORT] / CHAIN_SHORT
 
 
+def diag_lib():
+    """tools/diag_lib.py (the measurement library tools/build_diag.sh builds: kernel-attached launch timing lives there,
+    not in the product's C ABI), or None when it has not been built."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("diag_lib", os.path.join(ROOT, "tools", "diag_lib.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod if mod.available() else None
+
+
 def time_dominant_kernel(dev, iters=50):
     """Isolated launches of the same kernel, two ways: kernel-attached HIP events
-    (hipExtLaunchKernelGGL start/stop = the kernel's own begin/end) and a plain event pair around
-    each launch (includes the launch gap).  Extra information beside the in-graph chain."""
+    (hipExtLaunchKernelGGL start/stop = the kernel's own begin/end; measurement library only) and a plain event pair
+    around each launch (includes the launch gap).  Extra information beside the in-graph chain."""
     import numpy as np
     import torch
     from larvanet_amd import kernels as K
+    D = diag_lib()
     g = torch.Generator().manual_seed(5)
     x = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 20).to(dev)
     w = (torch.randn(CH, CH, 3, 3, generator=g) * 0.05).to(dev)
@@ -334,7 +345,7 @@ def time_dominant_kernel(dev, iters=50):
     for _ in range(5):
         K.conv3x3(x, fwd, CH, bias=b, relu=True, out=out)
     torch.cuda.synchronize()
-    k_mean, k_min = K.conv3x3_relu_timed(x, fwd, CH, b, out, iters)
+    k_mean, k_min = D.conv3x3_relu_timed(x, fwd, CH, b, out, iters) if D is not None else (None, None)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for s, e in evs:
         s.record()
@@ -355,9 +366,12 @@ def strip_launch_alone_ms(dev, c, iters=50):
     b = torch.zeros(c, device=dev)
     fwd, _ = K.pack_weights(w)
     out = torch.empty_like(x)
+    D = diag_lib()
+    if D is None:
+        return None
     try:
-        K.conv3x3_relu_strips_timed(x, fwd, c, b, out, 5, images=(0, BATCH // 2))
-        return K.conv3x3_relu_strips_timed(x, fwd, c, b, out, iters, images=(0, BATCH // 2))
+        D.conv3x3_strips_timed(x, fwd, c, b, out, 5, images=(0, BATCH // 2), relu=True)
+        return D.conv3x3_strips_timed(x, fwd, c, b, out, iters, images=(0, BATCH // 2), relu=True)
     except RuntimeError:
         return None
 

@@ -122,66 +122,31 @@ int larva_conv3x3_exit_l1_batch(int njobs, const float* const* src, int n_src, i
  * five_rows << 31; the two heights alternate along the table, `phase` 0 / 1 = it starts with a
  * 5-row / 4-row tile), returns the tile count (> cap: table truncated) or < 0 when H cannot be cut
  * into 5s and 4s.  larva_conv3x3_fwd_strips: larva_conv3x3_fwd_pitched with `tile_tab` = a DEVICE
- * copy of larva_strip_tile_table(H, pitch), plain_stores = write the output with plain instead of
- * non-temporal stores (the forward chain's policy); cout 48 or 32 and the 16-byte staging path only
- * (hipErrorNotSupported otherwise).  An image sub-range of a batch is addressed by offsetting the
- * operand pointers and passing its image count as N. */
+ * copy of larva_strip_tile_table(H, pitch) and `tile_tab_host` = the HOST array it filled, or NULL (given, and small
+ * enough -- <= 64 tiles per image, H <= 256, pitch <= 2048 --, the table travels inside the kernel arguments and a
+ * workgroup finds its tile without a dependent memory round trip); plain_stores = write the output with plain instead
+ * of non-temporal stores; cout 32, 48 or 64 and the 16-byte staging path only (hipErrorNotSupported otherwise).  An
+ * image sub-range of a batch is addressed by offsetting the operand pointers and passing its image count as N.
+ * (ABI version 5: the host table joined the signature; the `_mb` variants of version 4 are gone with the ReLU sign-bit
+ * masks they carried -- built, exact and measured no faster in round 4, profiles/r04_ab_maskbits_*.txt.) */
 int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap);
 int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                              const float* bias, const float* res0, const float* res1, const float* mask,
                              const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                             int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
-                             void* stream);
+                             int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
+                             int tiles_per_image, int plain_stores, void* stream);
 
-/* ReLU sign bits (round 4).  The reference's autograd keeps h = relu(conv1(x)) and multiplies the incoming gradient
- * by [h > 0] (models/LarvaNet.py:211, 257: nn.ReLU inside ResidualBlock / recon_block).  The ReLU-backward launch
- * used to read h (fp32, 7.08 MB at the training shape) as its `mask` operand only to test its sign; the conv + ReLU
- * launch that produces h can write that sign once, 4 bits per lane:
- *   maskbits [N][cout / 16][H][ceil(pitch / 16)][64] bytes, byte index within a (16 channels x 16 pixels) unit =
- *   ((x % 16) / 4) * 16 + (c % 16), bit r = (h[n][c][y][x - x % 4 + r] > 0)    (larva_maskbits_bytes = its size)
- * The *_mb entry points are their namesakes with two more operands: `maskbits_out` (relu = 1, mode 0, no other
- * fusion: the launch also writes the bits of its output) and `maskbits` (relu = 0, mask = res0 = res1 = NULL: the
- * ReLU-backward mask given as bits); both NULL = the namesake.  Same predicate, bit-identical results.  16-byte
- * staging path only (hipErrorNotSupported otherwise: the caller then passes the fp32 mask). */
-/* tile_rows (larva_conv3x3_fwd_pitched_mb): 0 = the library picks the height of the 48-column tiles -- 3 rows, or 4
- * for large 32-channel launches (339 x 510: 32.9 instead of 39.1 us per layer; 16-byte path, the epilogues of an
- * inference forward; at 48 channels the two heights measure the same and 3 stays) -- as every other entry point
- * does; 3 / 4 = that height (4 where it does not exist: hipErrorNotSupported).  Same results bit for bit. */
-long long larva_maskbits_bytes(int N, int cout, int H, int pitch);
-int larva_conv3x3_fwd_pitched_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                                 const float* bias, const float* res0, const float* res1, const float* mask,
-                                 const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                                 int relu, int mode, const unsigned char* maskbits, unsigned char* maskbits_out,
-                                 int tile_rows, void* stream);
-int larva_conv3x3_fwd_batch_mb(int njobs, const float* const* src, int n_src, int cin_per_src,
-                               const float* const* wpk, const float* const* bias, const float* const* res0,
-                               const float* const* res1, const float* const* mask, const float* const* base,
-                               float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
-                               const unsigned char* const* maskbits, unsigned char* const* maskbits_out, void* stream);
-/* larva_conv3x3_fwd_strips_mb also takes `tile_tab_host`: the HOST array larva_strip_tile_table filled (the entries of
- * the device copy `tile_tab`), or NULL.  Given, and small enough (<= 64 tiles per image, H <= 256, pitch <= 2048), the
- * table travels inside the kernel arguments and a workgroup finds its tile without a dependent memory round trip. */
-int larva_conv3x3_fwd_strips_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                                const float* bias, const float* res0, const float* res1, const float* mask,
-                                const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                                int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
-                                int tiles_per_image, int plain_stores,
-                                const unsigned char* maskbits, unsigned char* maskbits_out, void* stream);
-
-/* Measurement only: the same launch `iters` times with kernel-attached events
- * (hipExtLaunchKernelGGL); mean/min kernel duration in ms.  Synchronises the stream. */
-int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+/* larva_conv3x3_fwd_pitched with the tile height of the whole-tensor launch chosen by the caller.  tile_rows 0 = the
+ * library's choice, as every other entry point makes it: 3 x 48-pixel tiles; 4 x 48 for 32-channel launches of more
+ * tiles than the chip has workgroup slots (339 x 510: 32.9 instead of 39.1 us per layer); and a launch of more tiles
+ * than slots -- a whole validation image, validate.py:94-102 -- runs as one PERSISTENT workgroup per slot that walks its
+ * tiles (round 5; LARVA_PERSIST=0 in the environment: one workgroup per tile).  3 / 4 = that height (4 exists on the
+ * 16-byte path at 48 / 32 channels for the epilogues of an inference forward: hipErrorNotSupported otherwise).  The
+ * results do not depend on the tiling, bit for bit. */
+int larva_conv3x3_fwd_tiled(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                             const float* bias, const float* res0, const float* res1, const float* mask,
-                            const float* base, float* out, int N, int cout, int H, int W, int relu,
-                            int mode, void* stream, int iters, float* mean_ms, float* min_ms);
-/* The same for a strip-tile launch (larva_conv3x3_fwd_strips + the host table of larva_conv3x3_fwd_strips_mb): what a profiler reports for
- * one half-batch launch running alone, beside bench.py's time per layer with two of them running concurrently. */
-int larva_conv3x3_fwd_strips_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                                   const float* bias, const float* res0, const float* res1, const float* mask,
-                                   const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                                   int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
-                                   int tiles_per_image, int plain_stores, void* stream, int iters, float* mean_ms,
-                                   float* min_ms);
+                            const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                            int relu, int mode, int tile_rows, void* stream);
 
 /* ---- weight / bias gradient ---------------------------------------------------------------
  * Replaces autograd's conv weight/bias gradient for the call sites above (loss.backward(),
@@ -261,23 +226,6 @@ int larva_l1_bwd(const float* a, const float* b, const float* gout, long long nu
  * exits (models/LarvaNet.py:109) so that no separate scaling pass is needed. */
 int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, float gscale, float* ga, int N,
                             int C, int H, int W, void* stream);
-/* Measurement only: a one-lane launch that stores the 100 MHz wall clock into *dst in stream order (a capturable
- * marker between the launches of a graph; no reference counterpart). */
-int larva_stamp_clock(unsigned long long* dst, void* stream);
-/* Measurement only (tools/probe_chain_kernel.py; no reference counterpart): `layers` conv3x3 + ReLU layers (48 -> 48
- * channels, one packed weight image and bias for every layer) over buf0 [N][48][H][pitch] in ONE launch of
- * N * tiles_per_image <= 256 co-resident workgroups; layer L reads buf[L % 2], writes buf[(L + 1) % 2]; a layer's input
- * waits on a per-image counter instead of a kernel boundary.  state: N + 1 words (zeroed here in stream order; the last
- * is set when a workgroup gave up waiting); xcc_out: N * tiles_per_image ints (XCC_ID | image << 8) or NULL; trace:
- * N * tiles_per_image * layers * 8 stamps of the 100 MHz clock (layer entered, input released, wave 0's stores issued,
- * barrier passed, wave 0 drained, loader wave done, wave 3 drained, unused) or NULL; naps: 64-clock naps of a waiting workgroup between two looks at its image's counter;
- * plain_stores: 0 = non-temporal output stores. */
-int larva_conv3x3_chain_probe(float* buf0, float* buf1, const float* wpk, const float* bias, int N, int H, int W, int pitch,
-                              const unsigned* tile_tab, int tiles_per_image, unsigned* state, int* xcc_out,
-                              unsigned long long* trace, int layers, int naps, int plain_stores, void* stream);
-/* Measurement only: a one-wave launch that sleeps until the 100 MHz wall clock has advanced by `ticks` (<= 100000; the
- * loop is bounded), in stream order: a tunable delay in front of one chain of a captured two-chain graph. */
-int larva_delay_ticks(int ticks, void* stream);
 /* `loss += ...; loss / num_modules` (models/LarvaNet.py:104-109): out = (sum of n <= 8 device scalars) / divisor. */
 int larva_sum_scalars(const float* const* terms, int n, float divisor, float* out, void* stream);
 /* The same loss tail in two launches less per exit: larva_l1_partial leaves the block partial sums

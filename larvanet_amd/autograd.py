@@ -52,32 +52,6 @@ def _lw():
     return PaddedWidth.current
 
 
-class MaskBits:
-    """ReLU backward from sign bits (round 4).  The reference's autograd keeps h = relu(conv(x)) and multiplies the
-    incoming gradient by [h > 0] (models/LarvaNet.py:211, 257); the ReLU-backward conv launch read the whole fp32 h
-    (7 MB per layer at the training shape, 15 KiB per strip tile held in 16-20 registers through the K loop) only for
-    its sign.  When a backward will follow, the conv + ReLU launch also writes the sign of what it stores -- one byte per
-    lane and (16 channels x 16 pixels) unit, 1/16 of h -- and the backward launch reads that instead
-    (include/larva_hip.h: larva_conv3x3_fwd_*_mb).  h itself is still kept: the next conv and the weight gradient read it.
-    LARVA_MASK_BITS=0: the fp32 mask operand (A/B timing; same results bit for bit, tested)."""
-
-    enabled = os.environ.get("LARVA_MASK_BITS", "0") != "0"
-
-    @classmethod
-    def new(cls, like, *operands):
-        """Sign-bit tensor for an activation shaped like `like`, or None where the launches cannot carry one."""
-        if not cls.enabled or PaddedWidth.current is not None or not K.maskbits_ok(like, *operands):
-            return None
-        return K.new_maskbits(like)
-
-    @staticmethod
-    def mask_kw(bits, h, *operands):
-        """Keyword of the ReLU-backward launch: the bits when they exist and the launch can read them, else h."""
-        if bits is not None and K.maskbits_ok(*operands):
-            return {"maskbits": bits}
-        return {"mask": h}
-
-
 class SideStreams:
     """Concurrency inside one training step.  A conv launch keeps the matrix pipes busy only
     about half of its duration (tile staging, the store burst and the launch floor are exposed),
@@ -202,29 +176,14 @@ class DualChain:
                 if cls._stream(k) != cur:
                     cls._stream(k).wait_stream(cur)
             cls._forked = True
-            cls._stagger()
         cls._keep.append(out)
         cls._keep.extend([srcs] if isinstance(srcs, torch.Tensor) else list(srcs))
-        cls._keep.extend(t for t in (wpk, kw.get("bias"), kw.get("mask"), kw.get("res0"), kw.get("res1"), kw.get("maskbits"),
-                                     kw.get("maskbits_out")) if t is not None)
+        cls._keep.extend(t for t in (wpk, kw.get("bias"), kw.get("mask"), kw.get("res0"), kw.get("res1")) if t is not None)
         half = n // 2
         for k, rng in enumerate(((0, half), (half, n))):
             with torch.cuda.stream(cls._stream(k)):
                 K.conv3x3(srcs, wpk, cout, out=out, images=rng, strips=2 if k else True, plain_stores=(cls.plain_stores == "all" or (forward and cls.plain_stores == "fwd")), **kw)
         return out
-
-    # Measurement knob (round 4, tools/ab_stagger.sh): LARVA_CHAIN_STAGGER_US = d delays chain 1 (d > 0) or chain 0 (d < 0) by
-    # a |d| us sleeping launch at every fork.  The step's time depends on the phase the two chains start in by up to 4 %.
-    stagger_us = float(os.environ.get("LARVA_CHAIN_STAGGER_US", "0"))
-
-    @classmethod
-    def _stagger(cls):
-        if cls.stagger_us == 0:
-            return
-        from . import hip_lib
-        with torch.cuda.stream(cls._stream(1 if cls.stagger_us > 0 else 0)):
-            hip_lib.check(hip_lib.load().larva_delay_ticks(int(round(abs(cls.stagger_us) * 100)), torch.cuda.current_stream().cuda_stream),
-                          "larva_delay_ticks")
 
     @classmethod
     def join(cls):
@@ -738,8 +697,8 @@ class HeadFn(torch.autograd.Function):
 
     # rocprofv3 A/B at 16 x 3 x 48 x 48 (profiles/README.md, r02_head_*): padded-MFMA launch 7.2 us, direct
     # kernel 9.0 us (LDS-broadcast weights; 12.8 us with scalar-loaded weights) -> MFMA at the training size.  A whole
-    # validation image is another matter: 33 MB of output, the padded MFMA launch 31.6 us = 1.05 TB/s against the direct
-    # kernel's 4-pixel x 8-channel threads with 16-byte stores (round 5, profiles/r05_infer_*): "auto" = direct for
+    # validation image is another matter: 33 MB of output, the padded MFMA launch 26-31 us against 20 us for the direct
+    # kernel's 4-pixel x 8-channel threads with 16-byte stores (round 5, tools/bench_head_bicubic.py): "auto" = direct for
     # inference on more than DIRECT_ABOVE_PIXELS LR pixels; 0 / 1 = never / always.
     direct = {"0": False, "1": True}.get(os.environ.get("LARVA_HEAD_DIRECT", "auto"), "auto")
     DIRECT_ABOVE_PIXELS = 100000
@@ -794,15 +753,12 @@ class BodyFn(torch.autograd.Function):
         nb = len(params) // 4
         keep = [x]
         fea = x
-        training = any(ctx.needs_input_grad)
-        bits = []
         for j in range(nb):
             w1, b1, w2, b2 = params[4 * j:4 * j + 4]
             (f1, _), = pcs[2 * j].get()
             (f2, _), = pcs[2 * j + 1].get()
             c = int(w1.shape[0])
-            bits.append(MaskBits.new(fea) if training else None)
-            h = DualChain.conv(fea, f1, c, forward=True, bias=b1.detach(), relu=True, logical_w=_lw(), maskbits_out=bits[-1])
+            h = DualChain.conv(fea, f1, c, forward=True, bias=b1.detach(), relu=True, logical_w=_lw())
             if j == nb - 1:
                 nxt = DualChain.conv(h, f2, c, forward=True, bias=b2.detach(), res0=fea, res1=x, logical_w=_lw())
             else:
@@ -812,8 +768,7 @@ class BodyFn(torch.autograd.Function):
                 keep.append(nxt)
             fea = nxt
         DualChain.end_of_node(False)
-        ctx.have_bits = all(b is not None for b in bits)
-        ctx.save_for_backward(*keep, *(bits if ctx.have_bits else []))
+        ctx.save_for_backward(*keep)
         ctx.pcs = pcs
         ctx.nb = nb
         ctx.wshape = tuple(params[0].shape)
@@ -823,7 +778,6 @@ class BodyFn(torch.autograd.Function):
     def backward(ctx, dy):
         nb, pcs = ctx.nb, ctx.pcs
         keep = ctx.saved_tensors[:2 * nb]
-        bits = ctx.saved_tensors[2 * nb:] if ctx.have_bits else [None] * nb
         dy = dy.contiguous()
         c = ctx.wshape[0]
         # keep = [x, h0, fea1, h1, fea2, ..., h_{nb-1}]
@@ -835,7 +789,7 @@ class BodyFn(torch.autograd.Function):
             h_j = keep[2 * j + 1]
             (_, bw1), = pcs[2 * j].get()
             (_, bw2), = pcs[2 * j + 1].get()
-            dh = DualChain.conv(g, bw2, c, **MaskBits.mask_kw(bits[j], h_j, g))
+            dh = DualChain.conv(g, bw2, c, mask=h_j)
             jobs[2 * j + 1] = (g, h_j, ctx.wshape, 0, c) + _targets(pcs[2 * j + 1])
             jobs[2 * j] = (dh, fea_j, ctx.wshape, 0, c) + _targets(pcs[2 * j])
             if j > 0:
@@ -869,11 +823,9 @@ class LegFn(torch.autograd.Function):
         (f1, _), = pcs[0].get()
         (f2, _), = pcs[1].get()
         c = int(w1.shape[0])
-        bits = MaskBits.new(fea) if any(ctx.needs_input_grad) else None
-        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True, logical_w=_lw(), maskbits_out=bits)
+        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True, logical_w=_lw())
         out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base, logical_w=_lw())
-        ctx.have_bits = bits is not None
-        ctx.save_for_backward(fea, h, *([bits] if bits is not None else []))
+        ctx.save_for_backward(fea, h)
         ctx.pcs = pcs
         ctx.wshape, ctx.wshape2 = tuple(w1.shape), tuple(w2.shape)
         return out
@@ -881,13 +833,12 @@ class LegFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         fea, h = ctx.saved_tensors[:2]
-        bits = ctx.saved_tensors[2] if ctx.have_bits else None
         pcs = ctx.pcs
         c, c2 = ctx.wshape[0], ctx.wshape2[0]
         (_, bw1), = pcs[0].get()
         (_, bw2), = pcs[1].get()
         dyl = K.pixel_unshuffle4(dout.contiguous())
-        dh = K.conv3x3(dyl, bw2, c, **MaskBits.mask_kw(bits, h, dyl))
+        dh = K.conv3x3(dyl, bw2, c, mask=h)
         dfea = K.conv3x3(dh, bw1, c)
         ((dw1, db1),), ((dw2, db2),) = _leg_wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0])],
                                                     [(dyl, h, ctx.wshape2, 0, c) + _targets(pcs[1])], c, c2)
@@ -922,8 +873,7 @@ class ExitFn(torch.autograd.Function):
         (f1, _), = pcs[0].get()
         (f2, _), = pcs[1].get()
         c = int(w1.shape[0])
-        bits = MaskBits.new(fea)
-        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True, maskbits_out=bits)
+        h = K.conv3x3(fea, f1, c, bias=b1.detach(), relu=True)
         out = K.conv3x3(h, f2, int(w2.shape[0]), bias=b2.detach(), shuffle=True, base=base)
         dyl = None
         if divisor is None:
@@ -939,12 +889,10 @@ class ExitFn(torch.autograd.Function):
             else:
                 term, _ = K.l1_partial(out, truth)
         ctx.have_dyl = dyl is not None
-        ctx.have_bits = bits is not None
-        tail = [bits] if bits is not None else []
         if dyl is not None:
-            ctx.save_for_backward(fea, h, dyl, *tail)
+            ctx.save_for_backward(fea, h, dyl)
         else:
-            ctx.save_for_backward(fea, h, out, truth, *tail)
+            ctx.save_for_backward(fea, h, out, truth)
         ctx.pcs = pcs
         ctx.wshape, ctx.wshape2 = tuple(w1.shape), tuple(w2.shape)
         ctx.mark_non_differentiable(out)
@@ -953,7 +901,6 @@ class ExitFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _dout, gterm):
-        bits = ctx.saved_tensors[-1] if ctx.have_bits else None
         if ctx.have_dyl:
             fea, h, dyl = ctx.saved_tensors[:3]
         else:
@@ -968,7 +915,7 @@ class ExitFn(torch.autograd.Function):
             # (a partial-sum term receives its scalar gradient broadcast to its shape: element 0)
             g0 = gterm.as_strided((), ()) if gterm.dim() else gterm.contiguous()
             dyl = K.l1_bwd_unshuffle4(out, truth, g0, ctx.gscale)
-        dh = K.conv3x3(dyl, bw2, c, **MaskBits.mask_kw(bits, h, dyl))
+        dh = K.conv3x3(dyl, bw2, c, mask=h)
         dfea = K.conv3x3(dh, bw1, c)
         ((dw1, db1),), ((dw2, db2),) = _leg_wgrad([(dh, fea, ctx.wshape, 0, c) + _targets(pcs[0])],
                                                     [(dyl, h, ctx.wshape2, 0, c) + _targets(pcs[1])], c, ctx.wshape2[0])
@@ -987,8 +934,7 @@ def _conv_group(jobs, cout, **kw):
         if len(chunk) == 1:
             j = chunk[0]
             outs.append(K.conv3x3(j["srcs"], j["wpk"], cout, bias=j.get("bias"), mask=j.get("mask"), base=j.get("base"),
-                                  res0=j.get("res0"), res1=j.get("res1"), maskbits=j.get("maskbits"),
-                                  maskbits_out=j.get("maskbits_out"), **kw))
+                                  res0=j.get("res0"), res1=j.get("res1"), **kw))
         else:
             outs += K.conv3x3_batch(chunk, cout, **kw)
     return outs
@@ -1013,11 +959,8 @@ class ExitsFn(torch.autograd.Function):
         feas, params = args[:M], args[M:]   # params: (w1, b1, w2, b2) per exit
         c = int(params[0].shape[0])
         c2 = int(params[2].shape[0])
-        bits = [MaskBits.new(feas[i]) for i in range(M)]
-        if any(b is None for b in bits):
-            bits = [None] * M   # (a batched launch carries the operand for every job or for none)
-        hs = _conv_group([{"srcs": feas[i], "wpk": legs[i][0].get()[0][0], "bias": params[4 * i + 1].detach(),
-                           "maskbits_out": bits[i]} for i in range(M)], c, relu=True)
+        hs = _conv_group([{"srcs": feas[i], "wpk": legs[i][0].get()[0][0], "bias": params[4 * i + 1].detach()}
+                          for i in range(M)], c, relu=True)
         ctx.gscale = float(np.float32(1.0) / np.float32(divisor))
         ctx.have_dyl = StepScope.seed_grad is not None
         shuffle_jobs = [{"srcs": hs[i], "wpk": legs[i][1].get()[0][0], "bias": params[4 * i + 3].detach(), "base": base}
@@ -1051,8 +994,7 @@ class ExitsFn(torch.autograd.Function):
                     part, _ = K.l1_partial(out, truth)
                     parts.append(part)
                     third.append(out)
-        ctx.have_bits = bits[0] is not None
-        ctx.save_for_backward(truth, *feas, *hs, *third, *(bits if ctx.have_bits else []))
+        ctx.save_for_backward(truth, *feas, *hs, *third)
         ctx.legs, ctx.M = legs, M
         ctx.wshape, ctx.wshape2 = tuple(params[0].shape), tuple(params[2].shape)
         ctx.mark_non_differentiable(outs[-1])
@@ -1064,7 +1006,6 @@ class ExitsFn(torch.autograd.Function):
         M, legs = ctx.M, ctx.legs
         saved = ctx.saved_tensors
         truth, feas, hs, third = saved[0], saved[1:1 + M], saved[1 + M:1 + 2 * M], saved[1 + 2 * M:1 + 3 * M]
-        bits = saved[1 + 3 * M:1 + 4 * M] if ctx.have_bits else [None] * M
         c = ctx.wshape[0]
         live = [i for i in range(M) if gterms[i] is not None]
         dyls = {}
@@ -1074,10 +1015,7 @@ class ExitsFn(torch.autograd.Function):
             else:
                 g0 = gterms[i].as_strided((), ())  # the scalar gradient arrives broadcast to the term's shape
                 dyls[i] = K.l1_bwd_unshuffle4(third[i], truth, g0, ctx.gscale)
-        use_bits = ctx.have_bits and all(K.maskbits_ok(dyls[i]) for i in live)
-        dhs = dict(zip(live, _conv_group([dict({"srcs": dyls[i], "wpk": legs[i][1].get()[0][1]},
-                                               **({"maskbits": bits[i]} if use_bits else {"mask": hs[i]}))
-                                          for i in live], c))) if live else {}
+        dhs = dict(zip(live, _conv_group([{"srcs": dyls[i], "wpk": legs[i][1].get()[0][1], "mask": hs[i]} for i in live], c))) if live else {}
         dfeas = [None] * M
         grads = [None] * (4 * M)
         jobs1, jobs2 = [], []

@@ -22,6 +22,32 @@ def _hipcc():
     return exe
 
 
+TEMPS = os.path.join(CSRC, "build")   # (git-ignored) -save-temps output of the conv kernel's compile
+
+
+def _check_ring_waits(verbose):
+    """The conv kernel's counted waits (`s_waitcnt vmcnt(NPW + kAuxLoads)`: run_role, kAuxLate) are only correct if the
+    compiler emits exactly the vector loads the constant counts between chunk 1's LDS-DMA pieces and the wait; one load
+    fewer and a wait can pass with a piece still in flight -- silently wrong results after a compiler bump or a new
+    instantiation.  tools/check_aux_loads.py reads the device assembly of THIS build and fails it on a mismatch."""
+    import glob
+    import shutil
+    asm = glob.glob(os.path.join(TEMPS, "conv3x3_mfma-hip-amdgcn-*.s"))
+    obj = os.path.join(TEMPS, "conv3x3_mfma.o")
+    if not asm or not os.path.exists(obj):
+        raise RuntimeError("larvanet_amd.build: no device assembly from the conv kernel's compile (-save-temps)")
+    checker = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "tools", "check_aux_loads.py")
+    r = subprocess.run([sys.executable, checker, asm[0]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    tail = r.stdout.decode(errors="replace").strip().splitlines()[-1:]
+    if verbose:
+        print("[larvanet_amd.build] ring waits vs emitted loads (tools/check_aux_loads.py):", " ".join(tail), flush=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout.decode(errors="replace"))
+        raise RuntimeError("larvanet_amd.build: a counted vmcnt wait of conv3x3_mfma.hip does not match the loads hipcc emitted")
+    shutil.copyfile(obj, os.path.join(CSRC, "conv3x3_mfma.o"))
+    shutil.rmtree(TEMPS, ignore_errors=True)
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -41,6 +67,9 @@ def build_extension(force=False, verbose=True):
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
             cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if src == "conv3x3_mfma.hip":   # keep the device assembly for _check_ring_waits
+                os.makedirs(TEMPS, exist_ok=True)
+                cmd = [hipcc] + FLAGS + ["-save-temps=obj", "-c", s, "-o", os.path.join(TEMPS, "conv3x3_mfma.o")]
             if verbose:
                 print("[larvanet_amd.build]", " ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -49,6 +78,8 @@ def build_extension(force=False, verbose=True):
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors="replace"))
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    if any("conv3x3_mfma.hip" in " ".join(cmd) for cmd, _ in procs):
+        _check_ring_waits(verbose)
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -30,73 +30,26 @@
 #include <cstdlib>
 #include <type_traits>
 
-// Timing-only ablation switches for tools/diag_conv.py (never defined in the product build):
-// bit 0 = skip the MFMA blocks, bit 1 = skip the global->LDS staging, bit 2 = skip the
-// epilogue's global traffic, bit 3 = return at kernel entry, bit 4 = plain (not non-temporal) output stores.
-#ifndef LARVA_LOADER_WAVE
-#define LARVA_LOADER_WAVE 1   // 0: the four MFMA waves issue the LDS-DMA pieces themselves (A/B timing)
-#endif
-#ifndef LARVA_AUX_EARLY
-#define LARVA_AUX_EARLY 1   // 0: mask / residual / base operands loaded in the epilogue (A/B timing)
-#endif
-#ifndef LARVA_SHADOW
-#define LARVA_SHADOW 1   // 0: operand reads in a block in front of each k-step's MFMAs (A/B timing)
-#endif
+// LARVA_DIAG (never defined in the product build; tools/diag_conv.py, diag_overlap.py, diag_step.py, diag_wide.py build
+// their own libraries with it): timing-only ablations and in-kernel stamps.  bit 0 = skip the MFMA blocks, bit 1 = skip
+// the global->LDS staging, bit 2 = skip the epilogue's global traffic, bit 3 = return at kernel entry, bit 4 = plain (not
+// non-temporal) output stores, bits 5 / 6 / 9 / 11 = stamps (below), bit 7 = operands from registers instead of LDS,
+// bit 8 = no chunk barriers (with bit 1).
+// What earlier rounds measured through compile-time switches and settled (the losing sides are gone from this file; the
+// numbers are in DESIGN_HISTORY.md and profiles/): MFMA waves issuing the LDS-DMA themselves (r1), epilogue operands
+// fetched after the K loop / in front of chunk 0 / through LDS (r1, r3, r4: profiles/r03_ab_epilogue_operands_lds_v2.txt,
+// r04_ab_aux_late.txt), operand reads in a block in front of each k-step (r1), channel-major accumulators in every
+// epilogue (r2), prologue / epilogue at wave priority 3 (r3), the tile table through a scalar load (r3) or always
+// from memory (r4), a loader wave that streams nothing past the last chunk (r4: r04_ab_loader_tail.txt), plain stores
+// from the 48-column tiles (r4: r04_ab_wide_plain.txt), the exits' operands requested late (r4: r04_ab_aux_late_exits.txt),
+// un-pinned epilogue scalars (r4), a ring of two stages with three workgroups per CU (r3), operands one or three
+// k-steps ahead (r2, r3), ReLU-backward masks as sign bits (r4: r04_ab_maskbits_*.txt), eight MFMA waves per strip
+// workgroup (r5: r05_ab_strip8.txt).
 #ifndef LARVA_DIAG
 #define LARVA_DIAG 0
 #endif
-#ifndef LARVA_PIXEL_MAJOR
-#define LARVA_PIXEL_MAJOR 1   // 0: channel-major accumulators in every epilogue (A/B timing)
-#endif
-#ifndef LARVA_AUX_LDS
-// 1: the strip kernel's mask / residual operands reach the epilogue through LDS (streamed by the loader wave, see
-// AuxTile) instead of per-lane global loads in the prologue.  Built, bit-exact, measured twice in round 3 and LEFT OFF:
-// same-box step 1.72 ms (both operands into the ring stages the last two chunks free) / 1.78 ms (first operand early
-// into a tile of its own) against 1.66 ms with the register path; a launch alone 11.0-11.5 us against 10.0-10.9
-// (tools/ab_aux_lds.sh).
-#define LARVA_AUX_LDS 0
-#endif
-#ifndef LARVA_PRIO_BOOST
-// 1: a strip workgroup runs its prologue (until its first K chunk has landed) and its epilogue at wave priority 3 and
-// only its K loop at 1: with two workgroups per CU, the one that is not multiplying is the one its chain waits for.
-#define LARVA_PRIO_BOOST 0
-#endif
-#ifndef LARVA_TABLE_SCALAR
-// 1: the strip kernel's tile-table entry through the constant address space = a scalar load (s_load_dword, tile origin in
-// SGPRs) instead of the vector global load the generic pointer gives.  Measured in round 3 and LEFT OFF: two chains
-// 14.9-15.4 against 14.2-14.6 us per layer, step 1.664-1.672 against 1.653-1.657 ms (same box, tools/ab_variant.sh).
-#define LARVA_TABLE_SCALAR 0
-#endif
-#ifndef LARVA_LOADER_SKIP_TAIL
-#define LARVA_LOADER_SKIP_TAIL 0   // 1: the loader wave streams nothing past the last chunk (see run_loader; measured, off)
-#endif
-#ifndef LARVA_WIDE_PLAIN
-#define LARVA_WIDE_PLAIN 0     // 1: the 48-column tiles' mode-0 output with plain instead of non-temporal stores (A/B timing)
-#endif
-#ifndef LARVA_AUX_LATE
-#define LARVA_AUX_LATE 1       // 0: the epilogue's operands requested in front of chunk 0's input pieces (rounds 1-3; A/B timing)
-#endif
-#ifndef LARVA_AUX_LATE_EXITS
-#define LARVA_AUX_LATE_EXITS 0 // 1: also the pixel-shuffle exits' base / truth operands behind chunk 1's pieces (measured slower)
-#endif
-#ifndef LARVA_PIN_SCALARS
-#define LARVA_PIN_SCALARS 1    // 0: the epilogue's H / W / pitch / plain_stores re-loaded from the kernarg segment (A/B timing)
-#endif
-#ifndef LARVA_INLINE_TABLE
-#define LARVA_INLINE_TABLE 1   // 0: the strip kernel always looks its tile up in the device table (A/B timing)
-#endif
-#ifndef LARVA_RING_STAGES
-// Stages of the LDS-DMA ring (loader-wave path).  3 (the product): chunks c + 1 and c + 2 in flight while chunk c
-// multiplies, two workgroups per CU.  2 (experiment, with -DLARVA_WG_PER_CU=3): one chunk in flight, 40 instead of 60 KiB
-// per strip workgroup, so that three workgroups share a CU and hide each other's waits by occupancy instead.
-#define LARVA_RING_STAGES 3
-#endif
-#ifndef LARVA_WG_PER_CU
-#define LARVA_WG_PER_CU 2
-#endif
-#ifndef LARVA_OPERAND_DEPTH
-#define LARVA_OPERAND_DEPTH 2   // k-steps between an operand's LDS read and the MFMAs that use it (A/B: 1)
-#endif
+constexpr int kWgPerCu = 2;          // workgroups per CU the 16-byte-path kernels are sized for (72 KiB of LDS, <= 128 VGPRs)
+constexpr int kOperandDepth = 2;     // k-steps between an operand's LDS read and the MFMAs that use it
 
 
 // LARVA_DIAG bit 5 (32): in-kernel timeline.  Wave 0 of every workgroup writes 100 MHz wall-clock
@@ -207,13 +160,6 @@ struct ConvArgs {
   float* grad;                // [N][COUT][H][pitch]: sign(out - truth) * gval, pixel-unshuffled
   float* partial;             // [4 * nwg]: sum |out - truth| of every MFMA wave's share of its tile
   int plain_stores;           // strip kernel, mode-0 output: plain instead of non-temporal stores (see the epilogue)
-  // ReLU sign bits (round 4): the 16-byte-path conv+ReLU launch also writes, and the ReLU-backward launch (kEpiMaskBits)
-  // reads, ONE BYTE per lane and (16 channels x 16 pixels) unit instead of a 16-byte fp32 mask operand:
-  //   byte [n][c / 16][y][x / 16][lane],  lane = ((x % 16) / 4) * 16 + c % 16,  bit r = relu output of pixel x - x % 4 + r > 0
-  // (the pixel-major accumulator layout, see run_role) -- 1/16 of the fp32 tensor the reference's autograd keeps
-  // for `ReLU` backward (models/LarvaNet.py:211); the predicate is the same `h > 0`.
-  const unsigned char* maskbits;   // kEpiMaskBits
-  unsigned char* maskbits_out;     // kEpiRelu, or null
   // Strip kernel, round 4: ONE image's tile table inline, 16 bits per tile (y0 | (x0 / 16) << 8 | (5-row tile ? 1 << 15 : 0)),
   // when it fits (tab_n = its entry count <= 64, H <= 256, pitch <= 2048; else tab_n = 0 and the workgroup looks its
   // tile up in tile_tab).  It then arrives with the kernel's other arguments in the first batch of scalar loads and
@@ -249,14 +195,8 @@ enum Epi : int {
   kEpiShuffleBase = 6,  // pixel-shuffle(4) store, + base
   kEpiShuffleL1 = 7,    // + base, then L1 against `truth`: partial sums of |out - truth| and the sign
                         // gradient in pixel-unshuffled layout from the registers (image store optional)
-  kEpiMaskBits = 8,     // kEpiMask with the mask given as sign bits (ConvArgs::maskbits); 16-byte path only
-  kEpiCount = 9
+  kEpiCount = 8
 };
-
-// bytes of one image's sign-bit tensor: [cout / 16][H][ceil(pitch / 16)][64]
-__host__ __device__ __forceinline__ size_t maskbits_image_bytes(int cout, int H, int pitch) {
-  return (size_t)(cout / 16) * (size_t)H * (size_t)((pitch + 15) / 16) * 64;
-}
 
 template <int COUT, typename G = GeoWide>
 struct ConvCfg {
@@ -275,13 +215,12 @@ struct ConvCfg {
   static constexpr int NPW = (PIECES + 3) / 4;                              // pieces per wave per chunk
   static constexpr int STAGE_FLOATS = IN_FLOATS + W_FLOATS;
   static constexpr int STEPS = 9 * (kCh / 4);                               // 18 k-steps per chunk
-  static constexpr int NST = LARVA_RING_STAGES;                              // ring stages
+  static constexpr int NST = 3;                                              // ring stages (loader-wave path)
   static constexpr int AHEAD = NST - 1;                                      // chunks in flight beside the one multiplying
-  static_assert(NST == 2 || NST == 3, "ring of two or three stages");
   static constexpr size_t LDS_BYTES_DMA = NST * STAGE_FLOATS * sizeof(float);
   // LDS-DMA path: a fifth wave issues the pieces of chunks >= 2 (see run_loader); it keeps two
   // chunks in flight, and vmcnt counts 63 operations at most.
-  static constexpr bool LOADER = LARVA_LOADER_WAVE && 2 * PIECES <= 63;
+  static constexpr bool LOADER = 2 * PIECES <= 63;
   static constexpr int THREADS_DMA = LOADER ? 320 : 256;
   static constexpr size_t LDS_BYTES_REG = 2 * STAGE_FLOATS * sizeof(float);
   // register-staged path
@@ -290,27 +229,6 @@ struct ConvCfg {
   static constexpr int RW_SLOTS = W_USED / 4;
   static constexpr int RW_ITERS = (RW_SLOTS + 255) / 256;
   static_assert(kCh * PS <= IN_FLOATS, "input planes must fit their pieces");
-};
-
-// Epilogue operands through LDS (strip tiles, round 3).  The mask / residual operands of a tile -- COUT channels x
-// ROWS rows x 16 pixels, 15 KiB at 48 channels x 5 rows -- used to be per-lane global loads in the MFMA waves'
-// prologue: older than the first chunk's pieces, so the K loop could not start before they had come in from HBM,
-// and held in up to 32 VGPRs through the whole loop.  Now the loader wave streams them by LDS-DMA and the epilogue
-// reads them from LDS.  Where to: the FIRST operand (mask / res0) into a tile of its own behind the three ring stages
-// (16 KiB: two workgroups still fit a CU's 160 KiB), issued right behind chunk 2's pieces, so it has the whole K loop
-// to arrive; the SECOND operand of the two-residual epilogue into the ring stage the last-but-one chunk's turn would
-// otherwise fill with filler.  (First version of this round: both operands into the freed stages during the last
-// two chunks -- issued 1-2 us before the epilogue they were still in flight when the K loop ended: +0.9 us per
-// launch alone, step 1.72 against 1.66 ms.)  Layout: [channel][row][16] floats, channels CHS = ROWS * 16 + 4 floats
-// apart (the 16 lanes of a ds_read_b128 group read 16 different channels).
-template <int COUT, typename G>
-struct AuxTile {
-  static constexpr int CHS = G::ROWS * 16 + 4;
-  static constexpr int SLOTS = COUT * CHS / 4;                 // 16-byte slots
-  static constexpr int PIECES = (SLOTS + 63) / 64;
-  static constexpr int FLOATS = PIECES * 256;                  // whole pieces
-  static_assert(G::COLS == 16, "epilogue operands in LDS: strip tiles only");
-  static_assert(PIECES <= ConvCfg<COUT, G>::PIECES, "an operand tile must fit the pieces of one ring stage");
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -384,7 +302,7 @@ __device__ __forceinline__ ChunkSrc chunk_src(const ConvArgs& a, int chunk, int 
 
 // One 1 KiB piece: lane l's 16 bytes go to LDS byte address stage_addr + 1024 p + 16 l.  Scalar
 // work only: pick the descriptor, form the LDS address, issue.
-template <int COUT, typename G, bool SC1 = false>
+template <int COUT, typename G>
 __device__ __forceinline__ void dma_piece(const DmaPlan<COUT, G>& pl, int i, int wave, const ChunkSrc& cs,
                                           unsigned stage_addr) {
   using C = ConvCfg<COUT, G>;
@@ -393,7 +311,7 @@ __device__ __forceinline__ void dma_piece(const DmaPlan<COUT, G>& pl, int i, int
   i32x4 rsrc;
 #pragma unroll
   for (int k = 0; k < 4; ++k) rsrc[k] = isw ? cs.wgt[k] : cs.img[k];
-  lds_dma16_buf<SC1>(rsrc, pl.voff[i], 0, stage_addr + 1024u * (unsigned)p);
+  lds_dma16_buf(rsrc, pl.voff[i], 0, stage_addr + 1024u * (unsigned)p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -431,93 +349,32 @@ __device__ __forceinline__ void make_loader_plan(const ConvArgs& a, int lane, in
   }
 }
 
-template <int COUT, typename G, int NAUXL = 0, bool SC1 = false>
-__device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int lane, int n, int y0, int x0,
-                                           const float* aux0 = nullptr, const float* aux1 = nullptr,
-                                           const float* io_src = nullptr) {
+template <int COUT, typename G>
+__device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int lane, int n, int y0, int x0) {
   using C = ConvCfg<COUT, G>;
   if constexpr ((LARVA_DIAG & 256) != 0) return;   // (no barriers to meet the MFMA waves at)
   LoaderPlan<COUT, G> pl;
   make_loader_plan<COUT, G>(a, lane, y0, x0, pl);
-  // NAUXL > 0: this lane's source offsets of the epilogue operands' tile (AuxTile; the same for every operand)
-  constexpr int AUXP = NAUXL > 0 ? (COUT * (G::ROWS * 16 + 4) / 4 + 63) / 64 : 1;
-  static_assert(NAUXL == 0 || 2 * C::PIECES + AUXP <= 63, "vmcnt counts 63 operations at most");
-  unsigned aoff[AUXP];
-  i32x4 arsrc[NAUXL > 0 ? NAUXL : 1];
-  if constexpr (NAUXL > 0) {
-    using T = AuxTile<COUT, G>;
-#pragma unroll
-    for (int p = 0; p < T::PIECES; ++p) {
-      const int f = 4 * (p * 64 + lane);                      // float offset of the slot in the LDS tile
-      const int ch = f / T::CHS, within = f - ch * T::CHS;
-      const int row = within >> 4, q = (within & 15) >> 2;
-      const int gy = y0 + row, gx = x0 + 4 * q;
-      const bool ok = ch < COUT && within < G::ROWS * 16 && gy < a.H && gx < a.pitch;
-      aoff[p] = ok ? 4u * (unsigned)((ch * a.H + gy) * a.pitch + gx) : kDmaZero;
-    }
-    const size_t img = (size_t)n * COUT * ((size_t)a.H * a.pitch);
-    arsrc[0] = dma_rsrc(aux0 + img);
-    if constexpr (NAUXL > 1) arsrc[1] = dma_rsrc(aux1 + img);
-  }
   const int last = a.n_chunks - 1;
   int stage = 0;
   for (int chunk = 0; chunk <= last; ++chunk) {
-    // everything but the youngest chunk's pieces has landed: for chunk >= 2 that is chunk `chunk`
-    // itself (chunks 0 and 1 come from the MFMA waves, which wait for them on their side).  With an early
-    // operand tile in flight behind chunk 2's pieces (issued in turn 0, see below) turns 1 and 2 leave AUXP more
-    // operations outstanding: the counter retires in order, so "chunk 2 has landed" is then <= PIECES + AUXP.
-    static_assert(NAUXL == 0 || C::NST == 3, "epilogue operands in LDS: the three-stage ring");
-    // kSkipTail (round 4, measured and left OFF in the product kernels): stream nothing past the last chunk -- the last turn
-    // then waits for everything (its chunk is the youngest in flight) and the turns past last - 2 issue nothing.  The
-    // product re-issues the last chunk twice into stages nobody reads, which keeps every wait the same counted vmcnt;
-    // those 2 x PIECES issues and their round trip lie behind the K loop's last barrier, so the loader is the last wave
-    // of a workgroup to finish -- but same box, three alternating rounds, the step is 1.620 / 1.625 / 1.627 ms WITH the
-    // redundant streams and 1.625 / 1.629 / 1.632 without (profiles/r04_ab_loader_tail.txt): not on the critical path.
-    // The one-launch chain probe (SC1) skips them: there the loader's end gates the layer's barrier.
-    constexpr bool kSkipTail = (LARVA_LOADER_SKIP_TAIL || SC1) && NAUXL == 0 && C::AHEAD == 2;
-    if (NAUXL > 0 && (chunk == 1 || chunk == 2))
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(C::PIECES + (NAUXL > 0 ? AUXP : 0)) : "memory");
-    else if (kSkipTail && chunk == last)
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((C::AHEAD - 1) * C::PIECES) : "memory");
+    // everything but the youngest chunk's pieces has landed: for chunk >= 2 that is chunk `chunk` itself (chunks 0 and
+    // 1 come from the MFMA waves, which wait for them on their side)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((C::AHEAD - 1) * C::PIECES) : "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (kSkipTail && chunk + C::AHEAD > last) {
-      stage = stage == C::NST - 1 ? 0 : stage + 1;
-      continue;
-    }
     const int nstage = (stage + C::AHEAD) % C::NST;   // the stage chunk - 1 has just vacated
     const unsigned dst = lds_addr_of(smem + nstage * C::STAGE_FLOATS);
-    if (NAUXL > 1 && chunk == last - 1) {
-      // the first past-the-end turn: the stage chunk - 1 has vacated takes the epilogue's SECOND operand (two
-      // chunks of K before it is read).  Exactly PIECES operations like every other turn (the counted waits stay
-      // the same): the surplus pieces are all-zero writes, which fetch nothing.
+    // Past the end the last chunk is streamed again into a stage nobody reads: every wait stays the same counted
+    // vmcnt(PIECES).  (Those 2 x PIECES issues lie behind the K loop's last barrier, so the loader is the last wave of a
+    // workgroup to finish -- not on the critical path: without them the step was 4-5 us SLOWER, profiles/r04_ab_loader_tail.txt.)
+    const ChunkSrc cs = chunk_src<COUT, G>(a, min(chunk + C::AHEAD, last), n);
 #pragma unroll
-      for (int p = 0; p < C::PIECES; ++p)
-        lds_dma16_buf(arsrc[NAUXL > 1 ? 1 : 0], p < AUXP ? aoff[p < AUXP ? p : 0] : kDmaZero, 0, dst + 1024u * (unsigned)p);
-    } else {
-      // past the end the last chunk is streamed again into a stage nobody reads: every wait stays
-      // the same counted vmcnt(PIECES)
-      const ChunkSrc cs = chunk_src<COUT, G>(a, min(chunk + C::AHEAD, last), n, io_src);
-#pragma unroll
-      for (int p = 0; p < C::PIECES; ++p)
-        lds_dma16_buf<SC1>(p < C::IN_PIECES ? cs.img : cs.wgt, pl.voff[p], 0, dst + 1024u * (unsigned)p);
-    }
-    if (NAUXL > 0 && chunk == 0) {
-      // the epilogue's FIRST operand, into its own tile behind the ring, behind chunk 2's pieces in the queue
-      const unsigned adst = lds_addr_of(smem + 3 * C::STAGE_FLOATS);
-#pragma unroll
-      for (int p = 0; p < AUXP; ++p) lds_dma16_buf(arsrc[0], aoff[p], 0, adst + 1024u * (unsigned)p);
-    }
+    for (int p = 0; p < C::PIECES; ++p)
+      lds_dma16_buf(p < C::IN_PIECES ? cs.img : cs.wgt, pl.voff[p], 0, dst + 1024u * (unsigned)p);
     stage = stage == C::NST - 1 ? 0 : stage + 1;
   }
-  // no LDS-DMA may be in flight when the workgroup's LDS is released -- and where the operands may still be in
-  // flight when the K loop ends (a second operand; or fewer than four chunks: the first operand is only known to
-  // have landed at turn 3's wait) the MFMA waves wait at one more barrier
+  // no LDS-DMA may be in flight when the workgroup's LDS is released
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (NAUXL > 0) {
-    if (NAUXL > 1 || a.n_chunks < 4) asm volatile("s_barrier" ::: "memory");
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -624,16 +481,14 @@ __device__ __forceinline__ void shadow_groups() {
 // else hides the LDS latency, so the operands of step s+1 are read while step s multiplies
 // (hipcc otherwise sinks every ds_read to just above its first use, lgkmcnt(0) per pair of
 // MFMAs; the sched_barriers pin "reads of s+1, [one LDS-DMA piece], MFMAs of s").
-// PREFETCH: the wave's NPW LDS-DMA pieces of the chunk two ahead are issued between k-steps.
 // SWAP: the MFMA's A operand = activations (M = 16 pixels), B = weights (N = 16 output channels), so
 // that a lane ends up with 4 CONSECUTIVE PIXELS of one output channel (see run_role's epilogue) instead
 // of 4 consecutive output channels of one pixel.  Same products, same k order: identical results.
 // wstage: the chunk's weight rows when they do not sit behind the input planes of `stage` (a weight image kept apart
 // from the input ring: the pair-chain measurement kernel), else null.
-template <int COUT, typename G, int NCT, int PG0, int NPG, bool PREFETCH, bool SWAP>
-__device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave, int lane,
-                                           f32x4 (&acc)[NCT][NPG], const DmaPlan<COUT, G>& pl, const ChunkSrc& nxt,
-                                           unsigned nxt_stage, const float* wstage = nullptr) {
+template <int COUT, typename G, int NCT, int PG0, int NPG, bool SWAP>
+__device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int lane, f32x4 (&acc)[NCT][NPG],
+                                           const float* wstage = nullptr) {
   using C = ConvCfg<COUT, G>;
   const int lr = lane & 15, lq = lane >> 4;
   const float* const wrows = wstage ? wstage : stage + C::IN_FLOATS;
@@ -646,8 +501,6 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
   for (int c = 0; c < NCT; ++c)
     a_base[c] = wrows + lq * C::CS + lr + (cout_swizzled(COUT) ? (((ct0 + c) ^ (lq & 1)) * 16) : (ct0 + c) * 16);
   const float* b_base = stage + lq * C::PS + lr + 3;
-  constexpr int kEvery = C::STEPS / C::NPW > 0 ? C::STEPS / C::NPW : 1;
-#if LARVA_SHADOW
   // (Tried and dropped: scheduling regions of TWO k-steps.  tools/probe_mfma_rate.hip shows that a wave
   // streaming MFMAs beside LDS reads loses a fixed ~28 cycles per region -- 36.98 ticks per MFMA with 7
   // MFMAs per region against 33.44 with 14 -- but in this kernel both two-k-step layouts (a tap's 16
@@ -655,11 +508,11 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
   // slower: the two-chain layer 15.6 / 13.9 us against 13.8, the step 1.726 / 1.712 ms against 1.669; so
   // was the probe's exact layout with inline-asm MFMAs, accumulators tied in place and one read behind
   // every MFMA (single chain 16.2 us against 15.5).)
-  // Operands are read LARVA_OPERAND_DEPTH k-steps ahead of the MFMAs that use them (ring of DEPTH + 1
-  // register sets).  With depth 1 the wait in front of a k-step's first MFMA was lgkmcnt(0) on reads
-  // issued only 3-4 MFMAs earlier; with depth 2 the compiler's wait is a COUNTED one that leaves the
-  // newest k-step's reads in flight.
-  constexpr int D = LARVA_OPERAND_DEPTH;
+  // Operands are read kOperandDepth k-steps ahead of the MFMAs that use them (ring of D + 1 register sets).
+  // With depth 1 the wait in front of a k-step's first MFMA was lgkmcnt(0) on reads issued only 3-4 MFMAs
+  // earlier; with depth 2 the compiler's wait is a COUNTED one that leaves the newest k-step's reads in flight
+  // (depth 3: step 1.675-1.677 against 1.659-1.661 ms).
+  constexpr int D = kOperandDepth;
   float av[D + 1][NCT], bv[D + 1][NPG];
 #pragma unroll
   for (int d = 0; d < D; ++d)
@@ -670,7 +523,7 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
     // 32 cycles but the wave's issue port for only 8 of them: ~24 cycles of other instructions
     // per MFMA are free, everything issued OUTSIDE such a shadow idles the pipe (one wave per
     // SIMD).  So the operand reads of a later step are dealt out one or two per MFMA of step s
-    // instead of in a block in front of them, and the LDS-DMA piece follows the first MFMA.
+    // instead of in a block in front of them (hipcc left alone sinks every ds_read under an lgkmcnt(0)).
     __builtin_amdgcn_sched_barrier(0);
     if (step + D < C::STEPS)
       read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, step + D, av[(step + D) % (D + 1)], bv[(step + D) % (D + 1)]);
@@ -680,37 +533,10 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int wave
     for (int m = 0; m < NMF; ++m) {
       const float wv = av[step % (D + 1)][m / NPG], xv = bv[step % (D + 1)][m % NPG];
       acc[m / NPG][m % NPG] = __builtin_amdgcn_mfma_f32_16x16x4f32(SWAP ? xv : wv, SWAP ? wv : xv, acc[m / NPG][m % NPG], 0, 0, 0);
-      if constexpr (PREFETCH) {
-        if (m == 0 && step % kEvery == 0 && step / kEvery < C::NPW)
-          dma_piece<COUT, G>(pl, step / kEvery, wave, nxt, nxt_stage);
-      }
     }
     shadow_groups<NMF, NRD, 0>();
     __builtin_amdgcn_sched_barrier(0);
   }
-#else
-  float av[2][NCT], bv[2][NPG];
-  read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, 0, av[0], bv[0]);
-#pragma unroll
-  for (int step = 0; step < C::STEPS; ++step) {
-    if (step + 1 < C::STEPS)
-      read_operands<COUT, G, NCT, PG0, NPG>(a_base, b_base, step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
-    if constexpr (PREFETCH) {
-      // unconditional (no branch inside the unrolled loop: a control-flow join makes hipcc wait
-      // lgkmcnt(0), i.e. for the operand reads it has just issued)
-      if (step % kEvery == 0 && step / kEvery < C::NPW)
-        dma_piece<COUT, G>(pl, step / kEvery, wave, nxt, nxt_stage);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < NCT; ++c)
-#pragma unroll
-      for (int p = 0; p < NPG; ++p)
-        acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(SWAP ? bv[step & 1][p] : av[step & 1][c],
-                                                         SWAP ? av[step & 1][c] : bv[step & 1][p], acc[c][p], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#endif
 }
 
 // Wait until all but the `KEEP` youngest vector-memory operations of this wave are done, then
@@ -720,43 +546,6 @@ __device__ __forceinline__ void wait_and_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KEEP) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
-
-// CHAIN (conv3x3_strip_chain_kernel): the input pieces wait for *a.dep behind the weight pieces, and every LDS-DMA
-// bypasses the vector L1.
-__device__ __forceinline__ void chain_wait(const unsigned* ctr, unsigned target, unsigned* err, int wave, volatile unsigned* lds_flag,
-                                           unsigned layer, int naps) {
-  // wave 0 polls the image's counter (one L2 line that 32 workgroups bump and poll: four pollers per workgroup cost
-  // more than twice the chain's whole time) at wave priority 0 -- the CU's other workgroup is in its K loop --, the
-  // other waves (the loader too, see chain_roles) sleep at a workgroup barrier meanwhile
-  (void)lds_flag;
-  (void)layer;
-  if (wave == 0) {
-    __builtin_amdgcn_s_setprio(0);
-    bool ok = false;
-    for (int i = 0; i < 400000 && !ok; ++i) {   // bounded (>= 100 ms): a grid that cannot make progress still drains
-      const unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ok = (int)(__builtin_amdgcn_readfirstlane(v) - target) >= 0;
-      if (!ok) {
-        for (int j = 0; j < naps; ++j) __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    if (!ok) *err = 1u;
-    __builtin_amdgcn_s_setprio(1);
-  }
-  asm volatile("s_barrier" ::: "memory");
-}
-
-struct ChainIO {   // CHAIN: this layer's tensors and what its input waits for (the launch's arguments name layer 0's)
-  const float* src;
-  float* out;
-  const unsigned* dep;   // null: nothing to wait for
-  unsigned dep_target;
-  unsigned* err;
-  volatile unsigned* lds_flag;   // a word of LDS behind the ring, 0 at kernel start
-  unsigned layer;
-  unsigned long long* trace;     // this workgroup's and layer's four 100 MHz stamps, or null
-  int naps;                      // 64-clock naps between two looks at the counter
-};
 
 // virtual block index -> (image, tile origin) of a whole-tensor launch (a.nwg tiles of G::ROWS x G::COLS pixels)
 template <typename G>
@@ -770,42 +559,35 @@ __device__ __forceinline__ void decode_tile(const ConvArgs& a, int vb, int& n, i
   y0 = ty * G::ROWS;
 }
 
+// One MFMA wave's share of a tile: cout groups [ct0, ct0 + NCT) x pixel groups [PG0, PG0 + NPG).
 // PERSIST (conv3x3_mfma_persist_kernel): the workgroup walks tiles blockIdx.x, + gridDim.x, ... of the launch; the loader
 // wave streams EVERY chunk (run_loader_persist), the ring runs on across the tiles, and this wave only meets the loader
 // at one barrier per chunk, multiplies, and stores its tile while the next tile's first chunks are already in LDS.
-template <int COUT, typename G, bool VEC, int EPI, int NCT, int PG0, int NPG, bool AUXLDS = false, bool CHAIN = false,
-          bool PERSIST = false>
-__device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0, int wave, int n, int y0,
-                                         int x0, int tid, ChainIO io = ChainIO{}) {
+template <int COUT, typename G, bool VEC, int EPI, int NCT, int PG0, int NPG, bool PERSIST = false>
+__device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0, int wave, int n, int y0, int x0, int tid) {
   using C = ConvCfg<COUT, G>;
-  static_assert(!PERSIST || (VEC && C::LOADER && C::NST == 3 && !AUXLDS && !CHAIN), "persistent tiles: the loader-wave path");
-  static_assert(!AUXLDS || (VEC && C::LOADER && LARVA_PIXEL_MAJOR && (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2)),
-                "epilogue operands in LDS: the loader-wave path's mask / residual epilogues");
+  static_assert(!VEC || C::LOADER, "the 16-byte path runs with a loader wave (2 * PIECES <= 63 for every instantiated shape)");
+  static_assert(!PERSIST || VEC, "persistent tiles: the loader-wave path");
   const int lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
-  float* const out_ptr = CHAIN ? io.out : a.out;
-  const float* const src_ptr = CHAIN ? io.src : nullptr;
+  float* const out_ptr = a.out;
   // The epilogue's scalars, PINNED in SGPRs from here on (round 4).  Left alone hipcc drops them after the prologue and
   // re-loads each from the kernarg segment where the epilogue uses it -- H / pitch / plain_stores after the K loop and
   // W once per (channel group, pixel group) unit, every one an s_load + s_waitcnt lgkmcnt(0) in front of that unit's
   // stores: five dependent scalar round trips at the tail of every workgroup's life (read off the ISA of round 3's
   // binary).  An opaque asm operand cannot be rematerialised from memory.
   struct { int H, W, pitch, plain; } k = {a.H, a.W, a.pitch, a.plain_stores};
-#if LARVA_PIN_SCALARS
   asm volatile("" : "+s"(k.H), "+s"(k.W), "+s"(k.pitch), "+s"(k.plain));
-#endif
 
-  // Bias (added in the epilogue) and the epilogue's other operands are fetched inside the DMA
-  // prologue, older than chunk 1's pieces, so the first counted wait of the ring covers them.
   // Orientation of the accumulators.  Channel-major (the MFMA's A operand = weights): lane (lr, lq)
   // holds output channels 4 lq .. 4 lq + 3 of pixel lr of its group -- what the pixel-shuffle store wants
-  // (4 sub-pixels of one HR row = 16 contiguous bytes).  Pixel-major (A = activations, LARVA_PIXEL_MAJOR):
-  // lane (lr, lq) holds pixels 4 lq .. 4 lq + 3 of output channel lr -- 16 contiguous bytes of an NCHW
+  // (4 sub-pixels of one HR row = 16 contiguous bytes).  Pixel-major (A = activations; every other epilogue of the
+  // 16-byte path): lane (lr, lq) holds pixels 4 lq .. 4 lq + 3 of output channel lr -- 16 contiguous bytes of an NCHW
   // row, so the ordinary epilogues store (and fetch their mask / residual operands) with ONE 16-byte
   // access per (channel group, pixel group) instead of four 4-byte ones: in the batched launch the
   // store phase was 1.3 us of a conv's 12.7 us (un-instrumented ablation, tools/bench_conv_batch.py).
   constexpr bool kShuffleEpi = (EPI == kEpiShuffle || EPI == kEpiShuffleBase || EPI == kEpiShuffleL1);
-  constexpr bool kPixMajor = LARVA_PIXEL_MAJOR && VEC && !kShuffleEpi;
+  constexpr bool kPixMajor = VEC && !kShuffleEpi;
   f32x4 bias[NCT];
 #pragma unroll
   for (int c = 0; c < NCT; ++c) bias[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -818,33 +600,16 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     }
   };
 
-  // So are the epilogue's other operands (ReLU mask, residuals, bicubic base): issued here, they
-  // land under the whole K loop instead of being waited for after it (the mask / residual
-  // variants ran 1-1.3 us longer than plain ReLU).  They are older than every LDS-DMA piece, so
-  // the first counted wait of the ring covers them too.
+  // The epilogue's other operands (ReLU mask, residuals, bicubic base, truth) are fetched BEFORE the K loop so that
+  // they land under it instead of being waited for after it (the mask / residual variants ran 1-1.3 us longer).
   constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiShuffleBase)
                            ? 1 : ((EPI == kEpiRes2 || EPI == kEpiShuffleL1) ? 2 : 0);
-  f32x4 aux[(NAUX > 0 && !AUXLDS) ? NAUX : 1][(NAUX > 0 && !AUXLDS) ? NCT : 1][(NAUX > 0 && !AUXLDS) ? NPG : 1];
-  static_assert(EPI != kEpiMaskBits || kPixMajor, "sign-bit masks: pixel-major accumulators (16-byte path) only");
-  unsigned mbits[EPI == kEpiMaskBits ? NCT : 1][EPI == kEpiMaskBits ? NPG : 1];   // one byte per (c, p) unit
-  const int nxg = (k.pitch + 15) >> 4;   // 16-pixel groups per row of the sign-bit tensor
-  auto bits_at = [&](int c, int y, int xcol) {   // byte offset of this lane's nibble of unit (channel group ct0 + c, row y, column xcol)
-    return ((((size_t)n * C::CT + (ct0 + c)) * k.H + y) * nxg + (xcol >> 4)) * 64 + lane;
-  };
+  f32x4 aux[NAUX > 0 ? NAUX : 1][NAUX > 0 ? NCT : 1][NAUX > 0 ? NPG : 1];
   // part >= 0: only the units u = c * NPG + p with u % 4 == part (PERSIST: a tile's operands are requested a quarter at a
   // time in front of its first four K chunks -- as one burst at the tile's start, on every CU at once, they stood in the
   // memory pipeline in front of the loader wave's next chunks: +14 us per layer with two residual operands; the last
   // quarter still has the rest of the K loop to arrive)
   auto load_aux = [&](int part = -1) {
-    if constexpr (EPI == kEpiMaskBits) {
-#pragma unroll
-      for (int c = 0; c < NCT; ++c)
-#pragma unroll
-        for (int p = 0; p < NPG; ++p) {
-          const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
-          mbits[c][p] = a.maskbits[bits_at(c, min(y0 + prow, a.H - 1), min(x0 + pcol * 16, a.pitch - 1))];
-        }
-    } else if constexpr (!AUXLDS)   // (else the loader wave streams them into LDS)
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -876,26 +641,25 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         }
       }
   };
-  // Round 4: on the loader-wave path the epilogue's operands are requested BEHIND chunk 1's pieces, not in front of
+  // Round 4: on the loader-wave path the mask / residual operands are requested BEHIND chunk 1's pieces, not in front of
   // chunk 0's.  vmcnt retires in order: requested first (rounds 1-3), the first counted wait of the ring -- "chunk 0 has
   // landed" -- also waited for them, and in a training step they are COLD (the ReLU mask is an activation the forward
   // pass wrote a millisecond ago, the residuals come from two layers back): the K loop of every mask / residual link
   // started ~1.3 us later than a conv + ReLU link's (in-kernel stamps of the captured step, profiles/r04_step_timeline_
   // stamped.txt: workgroup life 10.4-11.5 against 9.0-10.0 us at the same 5.8-5.9 us of K loop).  Requested last, every
   // wait of the ring leaves exactly these kAuxLoads vector loads in flight (one 16-byte load per operand and (channel
-  // group, pixel group) unit with pixel-major or pixel-shuffle accumulators; one byte load for the sign bits) and the
-  // vmcnt(0) behind the K loop collects them.  kAuxLoads must not EXCEED the loads the compiler really emits between
-  // chunk 1's pieces and the first wait (a smaller real count would let a wait pass with a piece still in flight):
-  // tools/check_aux_loads.py counts them in the ISA of every instantiation.
+  // group, pixel group) unit with pixel-major accumulators) and the vmcnt(0) behind the K loop collects them.
+  // kAuxLoads must not EXCEED the loads the compiler really emits between chunk 1's pieces and the first wait (a
+  // smaller real count would let a wait pass with a piece still in flight): tools/check_aux_loads.py counts them in
+  // the ISA of every instantiation, and larvanet_amd/build.py runs it on every build.
   // (not for the pixel-shuffle exits: their base / truth operands are 2 x 7 sixteen-byte loads per wave from the HR
   // images, and requested late the batched L1 launch got SLOWER -- 66 against 58 us under rocprofv3, the exits' forward
   // 120 against 112 us in the stamped step: they then queue in front of the loader wave's chunk-2 pieces)
-  constexpr bool kAuxLate = LARVA_AUX_LATE && VEC && C::LOADER && C::NST == 3 && LARVA_AUX_EARLY && LARVA_PIXEL_MAJOR && !AUXLDS &&
-                            (!kShuffleEpi || LARVA_AUX_LATE_EXITS) && !(LARVA_DIAG & 6) && (NAUX > 0 || EPI == kEpiMaskBits) && !PERSIST;
-  constexpr int kAuxLoads = kAuxLate ? (EPI == kEpiMaskBits ? 1 : NAUX) * NCT * NPG : 0;
+  constexpr bool kAuxLate = VEC && !kShuffleEpi && !(LARVA_DIAG & 6) && NAUX > 0 && !PERSIST;
+  constexpr int kAuxLoads = kAuxLate ? NAUX * NCT * NPG : 0;
   auto load_early = [&]() {
     load_bias();
-    if constexpr ((NAUX > 0 || EPI == kEpiMaskBits) && LARVA_AUX_EARLY && !kAuxLate && !(LARVA_DIAG & 4)) load_aux();
+    if constexpr (NAUX > 0 && !kAuxLate && !(LARVA_DIAG & 4)) load_aux();
   };
   int pstage = 0;   // PERSIST: the ring's stage, running on across the workgroup's tiles
   for (int vb = blockIdx.x;; vb += gridDim.x) {   // (one trip unless PERSIST)
@@ -910,11 +674,10 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   for (int c = 0; c < NCT; ++c)
 #pragma unroll
     for (int p = 0; p < NPG; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 auxl[AUXLDS ? NAUX : 1][AUXLDS ? NCT : 1][AUXLDS ? NPG : 1];   // (filled after the K loop, from LDS)
 
   if constexpr (PERSIST) {
-    // bias and the epilogue's operands of THIS tile: requested now, they have the whole K loop to arrive (the vmcnt(0) behind
-    // it also covers the previous tile's stores, long drained)
+    // bias and the epilogue's operands of THIS tile have the K loop to arrive (the vmcnt(0) behind it also covers the
+    // previous tile's stores, long drained)
     load_bias();
     __builtin_amdgcn_sched_barrier(0);
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
@@ -924,8 +687,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         if (chunk < 4) load_aux(chunk);
         __builtin_amdgcn_sched_barrier(0);
       }
-      mfma_chunk<COUT, G, NCT, PG0, NPG, false, kPixMajor>(smem + pstage * C::STAGE_FLOATS, ct0, wave, lane, acc, DmaPlan<COUT, G>{},
-                                                           ChunkSrc{}, 0u);
+      mfma_chunk<COUT, G, NCT, PG0, NPG, kPixMajor>(smem + pstage * C::STAGE_FLOATS, ct0, lane, acc);
       pstage = pstage == C::NST - 1 ? 0 : pstage + 1;
     }
     if constexpr (NAUX > 0) {
@@ -935,42 +697,32 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     __builtin_amdgcn_sched_barrier(0);
   } else if constexpr (VEC) {
     // ---- LDS-DMA ring: chunk c lives in stage c % 3; chunks c+1 and c+2 are in flight --------
-    // Prologue: the weight pieces of chunk 0 go out first (their offsets need no arithmetic), then
-    // bias and epilogue operands, then the input pieces of chunk 0, then all of chunk 1 -- so that
-    // the youngest NPW operations are chunk 1's, which is what the first counted wait leaves in
-    // flight.  Chunk c is followed in the ring by chunk c+1 and c+2; past the end the last chunk is
-    // simply streamed again into a stage nobody reads any more, which keeps every wait the same
-    // counted vmcnt and the MFMA loop free of branches.
+    // Prologue: the weight pieces of chunk 0 go out first (their offsets need no arithmetic), then bias (and the
+    // pixel-shuffle exits' operands), then the input pieces of chunk 0, then all of chunk 1, then the mask / residual
+    // operands -- so that the first counted wait leaves chunk 1's NPW pieces and those loads in flight.  From chunk 2 on
+    // the loader wave issues (run_loader), and this wave's later waits find only its operand loads outstanding.
     DmaPlan<COUT, G> pl;
     const int last = a.n_chunks - 1;
     if constexpr (!(LARVA_DIAG & 2)) {
-      const ChunkSrc cs0 = chunk_src<COUT, G>(a, 0, n, src_ptr);
+      const ChunkSrc cs0 = chunk_src<COUT, G>(a, 0, n);
       const unsigned st0 = lds_addr_of(smem), st1 = lds_addr_of(smem + C::STAGE_FLOATS);
       stamp(6);
       make_plan<COUT, G, true>(a, wave, lane, y0, x0, pl);
 #pragma unroll
       for (int i = 0; i < C::NPW; ++i)
-        if (wave + 4 * i >= C::IN_PIECES) dma_piece<COUT, G, CHAIN>(pl, i, wave, cs0, st0);
+        if (wave + 4 * i >= C::IN_PIECES) dma_piece<COUT, G>(pl, i, wave, cs0, st0);
       __builtin_amdgcn_sched_barrier(0);
       stamp(7);
       load_early();
       stamp(14);
       make_plan<COUT, G, false>(a, wave, lane, y0, x0, pl);
-      if constexpr (CHAIN) {
-        if (io.dep) chain_wait(io.dep, io.dep_target, io.err, wave, io.lds_flag, io.layer, io.naps);
-        if (io.trace && tid == 0) io.trace[1] = __builtin_amdgcn_s_memrealtime();
-        __builtin_amdgcn_sched_barrier(0);
-      }
 #pragma unroll
       for (int i = 0; i < C::NPW; ++i)
-        if (wave + 4 * i < C::IN_PIECES) dma_piece<COUT, G, CHAIN>(pl, i, wave, cs0, st0);
+        if (wave + 4 * i < C::IN_PIECES) dma_piece<COUT, G>(pl, i, wave, cs0, st0);
       stamp(15);
-      if constexpr (C::NST == 3 || !C::LOADER) {   // (two stages: chunk 1 is the loader wave's first turn)
-        const ChunkSrc cs1 = chunk_src<COUT, G>(a, min(1, last), n, src_ptr);
+      const ChunkSrc cs1 = chunk_src<COUT, G>(a, min(1, last), n);
 #pragma unroll
-        for (int i = 0; i < C::NPW; ++i) dma_piece<COUT, G, CHAIN>(pl, i, wave, cs1, st1);
-      }
-      (void)st1;
+      for (int i = 0; i < C::NPW; ++i) dma_piece<COUT, G>(pl, i, wave, cs1, st1);
       if constexpr (kAuxLate) {   // the youngest vector loads of the wave (see above)
         __builtin_amdgcn_sched_barrier(0);
         load_aux();
@@ -980,64 +732,25 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     stamp(1);
     int stage = 0;
     for (int chunk = 0; chunk <= last; ++chunk) {
-      // The chunk's own pieces have landed and, after the barrier, everybody's have, and
-      // everybody is done with the stage that chunk+2 is about to overwrite.
-      if constexpr (C::LOADER) {
-        // this wave only issued its share of chunks 0 and 1: the first wait leaves chunk 1's
-        // pieces in flight, every later one finds nothing outstanding
-        if constexpr ((LARVA_DIAG & 256) != 0) {
-          // timing ablation (with bit 1: nothing is staged): no barrier between the chunks
-        } else if (chunk == 0) wait_and_barrier<(((LARVA_DIAG & 2) || C::NST == 2) ? 0 : C::NPW) + kAuxLoads>();
-        else wait_and_barrier<kAuxLoads>();
-      } else {
-        // (the NPW youngest operations belong to chunk+1)
-        wait_and_barrier<(LARVA_DIAG & 2) ? 0 : C::NPW>();
-      }
+      // The chunk's own pieces have landed and, after the barrier, everybody's have, and everybody is done with the
+      // stage that chunk + 2 is about to overwrite.
+      if constexpr ((LARVA_DIAG & 256) != 0) {
+        // timing ablation (with bit 1: nothing is staged): no barrier between the chunks
+      } else if (chunk == 0) wait_and_barrier<((LARVA_DIAG & 2) ? 0 : C::NPW) + kAuxLoads>();
+      else wait_and_barrier<kAuxLoads>();
       if (chunk == 0) stamp(2);
-      if constexpr (LARVA_PRIO_BOOST && G::COLS == 16) {
-        if (chunk == 0) __builtin_amdgcn_s_setprio(1);
-      }
       stamp(8 + (chunk < 7 ? chunk : 7));
-      const int nstage = (stage + C::AHEAD) % C::NST;
-      if constexpr (!(LARVA_DIAG & 1)) {
-        if constexpr (!(LARVA_DIAG & 2) && !C::LOADER) {
-          const ChunkSrc nxt = chunk_src<COUT, G>(a, min(chunk + 2, last), n, src_ptr);
-          mfma_chunk<COUT, G, NCT, PG0, NPG, true, kPixMajor>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, nxt,
-                                                lds_addr_of(smem + nstage * C::STAGE_FLOATS));
-        } else {
-          mfma_chunk<COUT, G, NCT, PG0, NPG, false, kPixMajor>(smem + stage * C::STAGE_FLOATS, ct0, wave, lane, acc, pl, ChunkSrc{},
-                                                 0u);
-        }
-      }
+      if constexpr (!(LARVA_DIAG & 1)) mfma_chunk<COUT, G, NCT, PG0, NPG, kPixMajor>(smem + stage * C::STAGE_FLOATS, ct0, lane, acc);
       stage = stage == C::NST - 1 ? 0 : stage + 1;
     }
-    // no LDS-DMA may be in flight when the workgroup's LDS is released
+    // no LDS-DMA may be in flight when the workgroup's LDS is released (and the operand loads have arrived)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (LARVA_PRIO_BOOST && G::COLS == 16) __builtin_amdgcn_s_setprio(3);
-    if constexpr (AUXLDS) {
-      // the epilogue's operands, streamed by the loader wave: the first into the tile behind the ring (landed by
-      // the barrier of chunk 3; with fewer chunks, or with a second operand -- in stage `stage`, issued two chunks
-      // ago --, complete once the loader has passed one more barrier)
-      if (NAUX > 1 || a.n_chunks < 4) asm volatile("s_barrier" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      using T = AuxTile<COUT, G>;
-      const float* t0 = smem + 3 * C::STAGE_FLOATS;
-      const float* t1 = smem + stage * C::STAGE_FLOATS;
-#pragma unroll
-      for (int c = 0; c < NCT; ++c)
-#pragma unroll
-        for (int p = 0; p < NPG; ++p) {
-          const int off = ((ct0 + c) * 16 + lr) * T::CHS + (PG0 + p) * 16 + lq * 4;   // (strip tiles: pixel group = row)
-          auxl[0][c][p] = *reinterpret_cast<const f32x4*>(t0 + off);
-          if constexpr (NAUX > 1) auxl[1][c][p] = *reinterpret_cast<const f32x4*>(t1 + off);
-        }
-    }
     stamp(3);
   } else {
     // ---- register staging, 2 stages ------------------------------------------------------------
     RegStaging<COUT, G> st;
     if constexpr (!(LARVA_DIAG & 2)) {
-      reg_load<COUT, G>(a, chunk_src<COUT, G>(a, 0, n, src_ptr), y0, x0, tid, st);
+      reg_load<COUT, G>(a, chunk_src<COUT, G>(a, 0, n), y0, x0, tid, st);
       reg_store<COUT, G>(smem, tid, st);
     }
     __syncthreads();
@@ -1048,8 +761,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       if constexpr (!(LARVA_DIAG & 2)) {
         if (more) reg_load<COUT, G>(a, chunk_src<COUT, G>(a, chunk + 1, n), y0, x0, tid, st);
       }
-      if constexpr (!(LARVA_DIAG & 1))
-        mfma_chunk<COUT, G, NCT, PG0, NPG, false, kPixMajor>(cur, ct0, wave, lane, acc, DmaPlan<COUT, G>{}, ChunkSrc{}, 0u);
+      if constexpr (!(LARVA_DIAG & 1)) mfma_chunk<COUT, G, NCT, PG0, NPG, kPixMajor>(cur, ct0, lane, acc);
       if constexpr (!(LARVA_DIAG & 2)) {
         if (more) reg_store<COUT, G>(nxt, tid, st);
       }
@@ -1065,10 +777,8 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     return;
   }
 
-  if constexpr ((NAUX > 0 || EPI == kEpiMaskBits) && !LARVA_AUX_EARLY && !AUXLDS) load_aux();
-
-  // Epilogue.  Lane (lr, lq) holds, in acc[c][p][r], output channel (ct0+c)*16 + lq*4 + r of
-  // pixel (y0 + pg/3, x0 + (pg%3)*16 + lr).
+  // Epilogue.  Channel-major: lane (lr, lq) holds, in acc[c][p][r], output channel (ct0+c)*16 + lq*4 + r of
+  // pixel (y0 + pg / PC, x0 + (pg % PC) * 16 + lr).
   if constexpr (EPI == kEpiShuffleL1) {
     // The exit's image never has to reach memory to be scored: out = shuffle(conv) + base sits in
     // the accumulators in exactly the (16C + 4i + j) channel order its L1 gradient is consumed in
@@ -1119,105 +829,24 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       }
   } else if constexpr (kPixMajor) {
     // Pixel-major accumulators: acc[c][p][r] = output channel (ct0+c)*16 + lr of pixel
-    // (y0 + pg / PC, x0 + (pg % PC) * 16 + 4 lq + r): one 16-byte store per (c, p).  Store policy as below.
+    // (y0 + pg / PC, x0 + (pg % PC) * 16 + 4 lq + r): one 16-byte store per (c, p).
+    // Store policy.  Non-temporal for the 48-column tiles: the 7 MB store burst of the 256 workgroups drains faster
+    // (-0.7 us per launch in a chain of whole-batch launches that writes a tensor per layer: 15.3 vs 16.1 us;
+    // re-measured in round 4, profiles/r04_ab_wide_plain.txt).  The strip kernel takes the policy per launch (k.plain):
+    // with two half-batch chains sharing the CUs plain stores are faster in both chains (step 1.634-1.641 ms all-plain,
+    // 1.648-1.650 forward only, 1.657-1.660 all-non-temporal: profiles/r04_ab_strip_plain.txt).
     const size_t plane = (size_t)k.H * k.pitch;
     auto store_all = [&](auto plain_tag) {
       constexpr bool kPlain = decltype(plain_tag)::value;
-      unsigned nib[EPI == kEpiRelu ? NCT : 1][EPI == kEpiRelu ? NPG : 1] = {};   // sign nibbles (maskbits_out)
 #pragma unroll
       for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int p = 0; p < NPG; ++p) {
           const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
           const int y = y0 + prow, xb = x0 + pcol * 16 + lq * 4;
-          size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * k.pitch + xb;
-          if constexpr ((LARVA_DIAG & 1024) != 0 && G::COLS == 16) {
-            // timing-only ablation (results land in the wrong places): the tile's COUT x ROWS x 16 floats as ONE
-            // contiguous run per workgroup -- a workgroup-contiguous ("blocked") activation layout's store side,
-            // with every load left as it is: what would DESIGN 9.0 buy in the two-chain regime?  tools/ab_blocked_stores.sh
-            idx = (((size_t)n * (k.pitch / 16) + x0 / 16) * k.H + y0) * 16 * COUT +
-                  (size_t)(((ct0 + c) * 16 + lr) * G::ROWS + prow) * 16 + lq * 4;
-          }
+          const size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * k.pitch + xb;
           f32x4 v = acc[c][p] + bias[c];
           if (y < k.H && xb < k.pitch) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float o = v[r];
-              if constexpr (EPI == kEpiRelu) o = fmaxf(o, 0.f);
-              if constexpr (AUXLDS) {
-                if constexpr (EPI == kEpiMask) o = (auxl[0][c][p][r] > 0.f) ? o : 0.f;
-                if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += auxl[0][c][p][r];
-                if constexpr (EPI == kEpiRes2) o += auxl[1][c][p][r];
-              } else {
-                if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
-                if constexpr (EPI == kEpiMaskBits) o = ((mbits[c][p] >> r) & 1u) ? o : 0.f;
-                if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
-                if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
-              }
-              v[r] = (xb + r < k.W) ? o : 0.f;   // columns [W, pitch) are kept at zero for the next layer
-            }
-            if constexpr (kPlain) *reinterpret_cast<f32x4*>(out_ptr + idx) = v;
-            else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_ptr + idx));
-            if constexpr (EPI == kEpiRelu)   // the sign bits of what was just stored: `h > 0` of the ReLU backward
-              nib[c][p] = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
-          }
-        }
-      if constexpr (EPI == kEpiRelu) {
-        if (a.maskbits_out) {   // (wave-uniform)
-          // One byte per lane, written as DWORDS: lane 4k gathers the bytes of lanes 4k .. 4k + 3 (a quad shares its
-          // pixel quad lq, hence its validity) with three quad-permute DPP moves and stores 4 bytes -- 16 dword stores
-          // of one 64-byte run per unit.  (First version: 64 byte stores per unit, +1.0-1.7 us per two-chain layer,
-          // profiles/r04_ab_maskbits.txt: sub-dword writes are what cost, not the 327 KB.)
-#pragma unroll
-          for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int p = 0; p < NPG; ++p) {
-              const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
-              const int y = y0 + prow, xb = x0 + pcol * 16 + lq * 4;
-              const int b = (int)nib[c][p];
-              const unsigned w = (unsigned)b | ((unsigned)__builtin_amdgcn_mov_dpp(b, 0x55, 0xf, 0xf, true) << 8) |
-                                 ((unsigned)__builtin_amdgcn_mov_dpp(b, 0xaa, 0xf, 0xf, true) << 16) |
-                                 ((unsigned)__builtin_amdgcn_mov_dpp(b, 0xff, 0xf, 0xf, true) << 24);
-              if ((lane & 3) == 0 && y < k.H && xb < k.pitch)
-                *reinterpret_cast<unsigned*>(a.maskbits_out + bits_at(c, y, x0 + pcol * 16)) = w;
-            }
-        }
-      }
-    };
-    if constexpr ((LARVA_DIAG & 16) != 0) {
-      store_all(std::true_type{});
-    } else if constexpr (G::COLS == 16) {
-      if (k.plain) store_all(std::true_type{});
-      else store_all(std::false_type{});
-    } else if constexpr (LARVA_WIDE_PLAIN != 0) {
-      store_all(std::true_type{});
-    } else {
-      store_all(std::false_type{});
-    }
-  } else {
-    // Output store policy.  Non-temporal for the 3 x 48 tiles: the 7 MB store burst of the 256
-    // workgroups drains faster (-0.7 us per launch in a chain of whole-batch launches that writes a
-    // tensor per layer: 15.3 vs 16.1 us).  The strip kernel takes the policy per launch
-    // (k.plain): with two half-batch chains sharing the CUs, plain stores are 0.5 us per
-    // layer faster in the FORWARD chain (the next layer reads the tensor at once: 14.2-14.5 ->
-    // 13.75-14.0 us, forward region of the step 604 -> 581 us); in the backward chain they were 0.6 us per layer
-    // slower in round 2 (step 1.696 ms all-plain vs 1.688) and are FASTER with round 4's kernels (1.634-1.641 ms all-plain,
-    // 1.648-1.650 forward only, 1.657-1.660 all-non-temporal: profiles/r04_ab_strip_plain.txt) -- the caller's default
-    // (autograd.DualChain.plain_stores) is now `all`.  The 48-column tiles were re-measured too and stay non-temporal
-    // (LARVA_WIDE_PLAIN, profiles/r04_ab_wide_plain.txt).
-    const size_t plane = (size_t)k.H * k.pitch;
-    auto store_all = [&](auto plain_tag) {
-      constexpr bool kPlain = decltype(plain_tag)::value;
-#pragma unroll
-      for (int c = 0; c < NCT; ++c)
-#pragma unroll
-        for (int p = 0; p < NPG; ++p) {
-          const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
-          const int y = y0 + prow, x = x0 + pcol * 16 + lr;
-          const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * k.pitch + x;
-          const f32x4 v = acc[c][p] + bias[c];
-          if (y < k.H && x < k.pitch) {
-            const bool real = x < k.W;  // columns [W, pitch) are kept at zero for the next layer
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float o = v[r];
@@ -1225,10 +854,10 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
               if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
               if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
               if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
-              o = real ? o : 0.f;
-              if constexpr (kPlain) out_ptr[idx0 + r * plane] = o;
-              else __builtin_nontemporal_store(o, &out_ptr[idx0 + r * plane]);
+              v[r] = (xb + r < k.W) ? o : 0.f;   // columns [W, pitch) are kept at zero for the next layer
             }
+            if constexpr (kPlain) *reinterpret_cast<f32x4*>(out_ptr + idx) = v;
+            else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_ptr + idx));
           }
         }
     };
@@ -1240,6 +869,32 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     } else {
       store_all(std::false_type{});
     }
+  } else {
+    // Register-staged path (any width): channel-major accumulators, four 4-byte stores per (c, p)
+    const size_t plane = (size_t)k.H * k.pitch;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPG; ++p) {
+        const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
+        const int y = y0 + prow, x = x0 + pcol * 16 + lr;
+        const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * k.pitch + x;
+        const f32x4 v = acc[c][p] + bias[c];
+        if (y < k.H && x < k.pitch) {
+          const bool real = x < k.W;  // columns [W, pitch) are kept at zero for the next layer
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float o = v[r];
+            if constexpr (EPI == kEpiRelu) o = fmaxf(o, 0.f);
+            if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
+            if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
+            if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
+            o = real ? o : 0.f;
+            if constexpr ((LARVA_DIAG & 16) != 0) out_ptr[idx0 + r * plane] = o;
+            else __builtin_nontemporal_store(o, &out_ptr[idx0 + r * plane]);
+          }
+        }
+      }
   }
 #if LARVA_DIAG & 32
   stamp(4);
@@ -1256,7 +911,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
 __device__ __forceinline__ void fetch_args(const ConvArgs& a) {
   asm volatile("" ::"s"(a.src[0]), "s"(a.wpk), "s"(a.bias), "s"(a.out), "s"(a.cin_per_src), "s"(a.n_chunks), "s"(a.N),
                "s"(a.H), "s"(a.W), "s"(a.pitch), "s"(a.tiles_x), "s"(a.tiles_y), "s"(a.magic_tx), "s"(a.magic_ty),
-               "s"(a.magic_cps), "s"(a.nwg), "s"(a.tile_tab), "s"(a.maskbits_out), "s"(a.plain_stores), "s"(a.tab_n),
+               "s"(a.magic_cps), "s"(a.nwg), "s"(a.tile_tab), "s"(a.plain_stores), "s"(a.tab_n),
                "s"(a.tab16[0]), "s"(a.tab16[16]));
 }
 
@@ -1278,7 +933,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
   // at priority 0 and take the matrix pipe only when these waves cannot use it.
   __builtin_amdgcn_s_setprio(1);
 
-  if constexpr (VEC && ConvCfg<COUT, G>::LOADER) {
+  if constexpr (VEC) {
     if (wave == 4) {
       if constexpr (!(LARVA_DIAG & 2)) run_loader<COUT, G>(a, smem, tid & 63, n, y0, x0);
       return;
@@ -1308,14 +963,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, float* smem) {
 }
 
 template <int COUT, bool VEC, int EPI>
-__global__ __launch_bounds__(VEC ? ConvCfg<COUT>::THREADS_DMA : 256, VEC ? LARVA_WG_PER_CU : 1) void conv3x3_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(VEC ? ConvCfg<COUT>::THREADS_DMA : 256, VEC ? kWgPerCu : 1) void conv3x3_mfma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   conv_tile<COUT, VEC, EPI>(a, smem);
 }
 
 // the same launch on 4 x 48 tiles (16-byte path, 48 / 32 channels)
 template <int COUT, int EPI>
-__global__ __launch_bounds__((ConvCfg<COUT, GeoWide4>::THREADS_DMA), LARVA_WG_PER_CU) void conv3x3_mfma_rows4_kernel(ConvArgs a) {
+__global__ __launch_bounds__((ConvCfg<COUT, GeoWide4>::THREADS_DMA), kWgPerCu) void conv3x3_mfma_rows4_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   conv_tile<COUT, true, EPI, GeoWide4>(a, smem);
 }
@@ -1381,7 +1036,7 @@ __device__ __forceinline__ void run_loader_persist(const ConvArgs& a, float* sme
 }
 
 template <int COUT, int EPI>
-__global__ __launch_bounds__((ConvCfg<COUT>::THREADS_DMA), LARVA_WG_PER_CU) void conv3x3_mfma_persist_kernel(ConvArgs a) {
+__global__ __launch_bounds__((ConvCfg<COUT>::THREADS_DMA), kWgPerCu) void conv3x3_mfma_persist_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = GeoWide;
   fetch_args(a);
@@ -1393,14 +1048,14 @@ __global__ __launch_bounds__((ConvCfg<COUT>::THREADS_DMA), LARVA_WG_PER_CU) void
     return;
   }
   if constexpr (COUT == 48) {   // 27 units -> 7,7,7,6 (as conv_tile)
-    if (wave < 3) run_role<COUT, G, true, EPI, 1, 0, 7, false, false, true>(a, smem, wave, wave, 0, 0, 0, tid);
-    else run_role<COUT, G, true, EPI, 3, 7, 2, false, false, true>(a, smem, 0, wave, 0, 0, 0, tid);
+    if (wave < 3) run_role<COUT, G, true, EPI, 1, 0, 7, true>(a, smem, wave, wave, 0, 0, 0, tid);
+    else run_role<COUT, G, true, EPI, 3, 7, 2, true>(a, smem, 0, wave, 0, 0, 0, tid);
   } else if constexpr (COUT == 32) {   // 18 -> 5,5,4,4
-    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 5, false, false, true>(a, smem, wave, wave, 0, 0, 0, tid);
-    else run_role<COUT, G, true, EPI, 1, 5, 4, false, false, true>(a, smem, wave - 2, wave, 0, 0, 0, tid);
+    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 5, true>(a, smem, wave, wave, 0, 0, 0, tid);
+    else run_role<COUT, G, true, EPI, 1, 5, 4, true>(a, smem, wave - 2, wave, 0, 0, 0, tid);
   } else {   // 64: 36 -> 9,9,9,9
     static_assert(COUT == 64, "unsupported channel count");
-    run_role<COUT, G, true, EPI, 1, 0, 9, false, false, true>(a, smem, wave, wave, 0, 0, 0, tid);
+    run_role<COUT, G, true, EPI, 1, 0, 9, true>(a, smem, wave, wave, 0, 0, 0, tid);
   }
 }
 
@@ -1412,39 +1067,32 @@ template <int COUT, int EPI, typename G>
 __device__ __forceinline__ void strip_roles(const ConvArgs& a, float* smem, int wave, int n, int y0, int x0, int tid) {
   static_assert(ConvCfg<COUT, G>::LOADER, "the strip kernel is launched with a loader wave");
   static_assert(COUT == 48 || COUT == 32 || COUT == 64, "strip tiles: 32, 48 or 64 output channels");
-  // mask / residual operands come through LDS (AuxTile): needs the two past-the-end turns of the loader, i.e.
-  // n_chunks >= 2, which the host checks
-  constexpr bool AL = LARVA_AUX_LDS && LARVA_PIXEL_MAJOR && LARVA_AUX_EARLY && !(LARVA_DIAG & 6) && COUT != 64 &&
-                      (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2);
   if (wave == 4) {
-    if constexpr (!AL) run_loader<COUT, G>(a, smem, tid & 63, n, y0, x0);
-    else if constexpr (EPI == kEpiMask) run_loader<COUT, G, 1>(a, smem, tid & 63, n, y0, x0, a.mask);
-    else if constexpr (EPI == kEpiRes1) run_loader<COUT, G, 1>(a, smem, tid & 63, n, y0, x0, a.res0);
-    else run_loader<COUT, G, 2>(a, smem, tid & 63, n, y0, x0, a.res0, a.res1);
+    run_loader<COUT, G>(a, smem, tid & 63, n, y0, x0);
     return;
   }
   if constexpr (COUT == 64) {
     // ROWS pixel groups x 4 cout groups = 20 / 16 units: every wave one cout group x all pixel groups (5,5,5,5 / 4,4,4,4)
-    run_role<COUT, G, true, EPI, 1, 0, G::ROWS, false>(a, smem, wave, wave, n, y0, x0, tid);
+    run_role<COUT, G, true, EPI, 1, 0, G::ROWS>(a, smem, wave, wave, n, y0, x0, tid);
   } else if constexpr (COUT == 48) {
     // ROWS pixel groups x 3 cout groups: waves 0..2 own one cout group x the first ROWS-1 pixel groups, wave 3
     // all three cout groups of the last pixel group (15 units -> 4,4,4,3; 12 -> 3,3,3,3)
-    if (wave < 3) run_role<COUT, G, true, EPI, 1, 0, G::ROWS - 1, AL>(a, smem, wave, wave, n, y0, x0, tid);
-    else run_role<COUT, G, true, EPI, 3, G::ROWS - 1, 1, AL>(a, smem, 0, wave, n, y0, x0, tid);
+    if (wave < 3) run_role<COUT, G, true, EPI, 1, 0, G::ROWS - 1>(a, smem, wave, wave, n, y0, x0, tid);
+    else run_role<COUT, G, true, EPI, 3, G::ROWS - 1, 1>(a, smem, 0, wave, n, y0, x0, tid);
   } else if constexpr (G::ROWS == 5) {
     // 32 channels, 5 pixel groups x 2 cout groups = 10 units -> 3,3,2,2
-    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 3, AL>(a, smem, wave, wave, n, y0, x0, tid);
-    else if (wave == 2) run_role<COUT, G, true, EPI, 2, 3, 1, AL>(a, smem, 0, wave, n, y0, x0, tid);
-    else run_role<COUT, G, true, EPI, 2, 4, 1, AL>(a, smem, 0, wave, n, y0, x0, tid);
+    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 3>(a, smem, wave, wave, n, y0, x0, tid);
+    else if (wave == 2) run_role<COUT, G, true, EPI, 2, 3, 1>(a, smem, 0, wave, n, y0, x0, tid);
+    else run_role<COUT, G, true, EPI, 2, 4, 1>(a, smem, 0, wave, n, y0, x0, tid);
   } else {
     // 32 channels, 4 pixel groups x 2 cout groups = 8 units -> 2,2,2,2
-    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 2, AL>(a, smem, wave, wave, n, y0, x0, tid);
-    else run_role<COUT, G, true, EPI, 1, 2, 2, AL>(a, smem, wave - 2, wave, n, y0, x0, tid);
+    if (wave < 2) run_role<COUT, G, true, EPI, 1, 0, 2>(a, smem, wave, wave, n, y0, x0, tid);
+    else run_role<COUT, G, true, EPI, 1, 2, 2>(a, smem, wave - 2, wave, n, y0, x0, tid);
   }
 }
 
 template <int COUT, int EPI>
-__global__ __launch_bounds__(320, LARVA_WG_PER_CU) void conv3x3_mfma_strip_kernel(ConvArgs a) {
+__global__ __launch_bounds__(320, kWgPerCu) void conv3x3_mfma_strip_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   stamp(0);
   fetch_args(a);
@@ -1452,101 +1100,26 @@ __global__ __launch_bounds__(320, LARVA_WG_PER_CU) void conv3x3_mfma_strip_kerne
   const int n = div_by_magic(tile, a.magic_tx);   // tiles_x = tiles per image
   const int slot = tile - n * a.tiles_x;
   unsigned e;
-  if (LARVA_INLINE_TABLE && a.tab_n) {   // (uniform)
+  if (a.tab_n) {   // (uniform)
     // a scalar load at a computed offset of the kernarg segment, whose two table lines fetch_args has just pulled into
     // the scalar cache with the other arguments: a cache hit instead of a vector load's trip to L2
     const unsigned pair = (unsigned)a.tab16[slot >> 1];
     const unsigned h = (slot & 1) ? pair >> 16 : pair & 0xffffu;
     e = (h & 0xffu) | (((h >> 8) & 0x7fu) << 16) | ((h >> 15) << 31);   // -> y0 | x0 << 12 | five << 31
   } else {
-#if LARVA_TABLE_SCALAR
-    e = reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(reinterpret_cast<uintptr_t>(a.tile_tab))[slot];
-#else
     e = a.tile_tab[slot];
-#endif
   }
   const int y0 = (int)(e & 0xfffu), x0 = (int)((e >> 12) & 0xfffu);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  __builtin_amdgcn_s_setprio(LARVA_PRIO_BOOST ? 3 : 1);
+  __builtin_amdgcn_s_setprio(1);
   if (e >> 31) strip_roles<COUT, EPI, GeoS5>(a, smem, wave, n, y0, x0, tid);
   else strip_roles<COUT, EPI, GeoS4>(a, smem, wave, n, y0, x0, tid);
 }
-template <int COUT, typename G, int EPI>
-constexpr size_t kStripLdsOf = ConvCfg<COUT, G>::LDS_BYTES_DMA +
-    ((LARVA_AUX_LDS && COUT != 64 && (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiRes2)) ? AuxTile<COUT, G>::FLOATS * sizeof(float) : 0);
-template <int COUT, int EPI = kEpiRelu>
-constexpr size_t kStripLdsBytes = kStripLdsOf<COUT, GeoS5, EPI> > kStripLdsOf<COUT, GeoS4, EPI> ? kStripLdsOf<COUT, GeoS5, EPI>
-                                                                                                : kStripLdsOf<COUT, GeoS4, EPI>;
-static_assert(LARVA_WG_PER_CU * kStripLdsBytes<48, kEpiRes2> <= 160 * 1024 && 2 * kStripLdsBytes<64, kEpiRes2> <= 160 * 1024,
-              "strip workgroups per CU");
-
-// ---------------------------------------------------------------------------------------------
-// MEASUREMENT KERNEL (round 4, tools/probe_chain_kernel.py; not on the product path): a whole chain of conv3x3 + ReLU
-// layers of one half batch in ONE launch.  What would the layer chains gain if a kernel boundary (last drain -> next
-// entry 2.0-2.2 us, grid-wide drain skew 1.8-2.6 us, kernarg / table fetch in front of every workgroup) were
-// replaced by an in-launch dependency?  Every workgroup keeps its strip tile for all layers; the activations
-// ping-pong between two buffers; a workgroup that has drained its stores of layer L adds 1 to its IMAGE's counter, and
-// the input pieces of layer L + 1 wait (behind that layer's weight pieces) until the counter says all tiles of the image
-// are done with layer L -- which also covers the write-after-read on the ping-pong buffer.  Visibility: all tiles of an
-// image run on ONE XCD (xcd_remap + the round-robin deal of workgroups, which the probe checks through XCC_ID), whose L2
-// serves plain stores to `sc1` loads (L1 bypassed); the counters are agent-scope atomics in that same L2.  Residency:
-// the grid is 256 workgroups at two per CU -- two such launches fill the chip exactly and nothing else may run.
-// Every spin is bounded.
-// ---------------------------------------------------------------------------------------------
-struct ChainProbeArgs {
-  ConvArgs a;            // layer 0 as a strip launch would get it (src[0] = buf[0], out = buf[1])
-  float* buf[2];         // ping-pong activations [N][COUT][H][pitch]
-  unsigned* counters;    // [N], zero at launch
-  unsigned* err;         // [1]
-  int* xcc_out;          // [nwg] or null: the XCD each workgroup ran on
-  int layers;
-  unsigned long long* trace;   // [nwg][layers][4] or null: layer entered / input released / stores issued / barrier passed
-  int naps;                    // 64-clock naps between two looks at an image's counter
-};
-
-template <int COUT, typename G>
-__device__ __forceinline__ void chain_roles(const ChainProbeArgs& p, float* smem, int wave, int n, int y0, int x0, int tid) {
-  static_assert(COUT == 48, "the chain probe is built for 48 channels");
-  for (int L = 0; L < p.layers; ++L) {
-    const ChainIO io{p.buf[L & 1], p.buf[(L + 1) & 1], L ? p.counters + n : nullptr, (unsigned)(L * p.a.tiles_x), p.err,
-                     reinterpret_cast<volatile unsigned*>(smem + kStripLdsBytes<COUT, kEpiRelu> / sizeof(float)), (unsigned)L,
-                     p.trace ? p.trace + ((size_t)blockIdx.x * p.layers + L) * 8 : nullptr, p.naps};
-    if (io.trace && tid == 0) io.trace[0] = __builtin_amdgcn_s_memrealtime();
-    if (wave == 4) {
-      if (io.dep) asm volatile("s_barrier" ::: "memory");   // (the MFMA waves' meeting point behind the counter poll)
-      run_loader<COUT, G, 0, true>(p.a, smem, tid & 63, n, y0, x0, nullptr, nullptr, io.src);
-      if (io.trace && (tid & 63) == 0) io.trace[5] = __builtin_amdgcn_s_memrealtime();
-    } else {
-      if (wave < 3) run_role<COUT, G, true, kEpiRelu, 1, 0, G::ROWS - 1, false, true>(p.a, smem, wave, wave, n, y0, x0, tid, io);
-      else run_role<COUT, G, true, kEpiRelu, 3, G::ROWS - 1, 1, false, true>(p.a, smem, 0, wave, n, y0, x0, tid, io);
-      if (io.trace && tid == 0) io.trace[2] = __builtin_amdgcn_s_memrealtime();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
-      if (io.trace && (tid & 63) == 0 && (wave == 0 || wave == 3)) io.trace[wave == 0 ? 4 : 6] = __builtin_amdgcn_s_memrealtime();
-    }
-    asm volatile("s_barrier" ::: "memory");             // everybody's have, and nobody reads the ring any more
-    if (io.trace && tid == 0) io.trace[3] = __builtin_amdgcn_s_memrealtime();
-    if (tid == 0) __hip_atomic_fetch_add(p.counters + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 template <int COUT>
-__global__ __launch_bounds__(320, LARVA_WG_PER_CU) void conv3x3_strip_chain_kernel(ChainProbeArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tile = xcd_remap(blockIdx.x, p.a.nwg);
-  const int n = div_by_magic(tile, p.a.magic_tx);
-  const int slot = tile - n * p.a.tiles_x;
-  const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)p.a.tile_tab[slot]);   // (uniform: the layer loop sits under it)
-  const int y0 = (int)(e & 0xfffu), x0 = (int)((e >> 12) & 0xfffu);
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (tid == 0) smem[kStripLdsBytes<COUT, kEpiRelu> / sizeof(float)] = 0.f;   // (the layer flag; layer 0 waits for nothing, and
-                                                                               //  every wave meets at a barrier before layer 1)
-  if (p.xcc_out && tid == 0) p.xcc_out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 20) | (n << 8);
-  __builtin_amdgcn_s_setprio(1);
-  if (e >> 31) chain_roles<COUT, GeoS5>(p, smem, wave, n, y0, x0, tid);
-  else chain_roles<COUT, GeoS4>(p, smem, wave, n, y0, x0, tid);
-}
+constexpr size_t kStripLdsBytes = ConvCfg<COUT, GeoS5>::LDS_BYTES_DMA > ConvCfg<COUT, GeoS4>::LDS_BYTES_DMA ? ConvCfg<COUT, GeoS5>::LDS_BYTES_DMA
+                                                                                                            : ConvCfg<COUT, GeoS4>::LDS_BYTES_DMA;
+static_assert(kWgPerCu * kStripLdsBytes<48> <= 160 * 1024 && kWgPerCu * kStripLdsBytes<64> <= 160 * 1024, "strip workgroups per CU");
 
 // Several INDEPENDENT convolutions of one shape and one epilogue in one launch (blockIdx.y = job).
 // A single conv launch at the training shape is one workgroup per CU and spends half of its time
@@ -1559,7 +1132,7 @@ struct ConvBatch {
 };
 
 template <int COUT, int EPI>
-__global__ __launch_bounds__(ConvCfg<COUT>::THREADS_DMA, LARVA_WG_PER_CU) void conv3x3_mfma_batch_kernel(ConvBatch b) {
+__global__ __launch_bounds__(ConvCfg<COUT>::THREADS_DMA, kWgPerCu) void conv3x3_mfma_batch_kernel(ConvBatch b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   conv_tile<COUT, true, EPI>(b.job[blockIdx.y], smem);
 }
@@ -1731,14 +1304,14 @@ static hipError_t launch_rows4_e(const ConvArgs& a, hipStream_t stream, const La
   return hipGetLastError();
 }
 
-// workgroup slots of the device for the 16-byte-path kernels (LARVA_WG_PER_CU per CU)
+// workgroup slots of the device for the 16-byte-path kernels (kWgPerCu per CU)
 static int conv_slots() {
   static int slots = 0;
   if (!slots) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;
-    slots = LARVA_WG_PER_CU * cus;
+    slots = kWgPerCu * cus;
   }
   return slots;
 }
@@ -1765,8 +1338,7 @@ static hipError_t launch_persist_e(const ConvArgs& a, hipStream_t stream, const 
 // persistent tiles exist for the epilogues of an inference forward; anything else: hipErrorNotSupported
 template <int COUT>
 static hipError_t launch_persist(const ConvArgs& a, int epi, hipStream_t stream, const LaunchTiming* tm) {
-  if constexpr (!ConvCfg<COUT>::LOADER || !LARVA_PIXEL_MAJOR) return hipErrorNotSupported;
-  else switch (epi) {
+  switch (epi) {
     case kEpiPlain: return launch_persist_e<COUT, kEpiPlain>(a, stream, tm);
     case kEpiRelu: return launch_persist_e<COUT, kEpiRelu>(a, stream, tm);
     case kEpiRes1: return launch_persist_e<COUT, kEpiRes1>(a, stream, tm);
@@ -1798,9 +1370,6 @@ static hipError_t launch_conv_v(const ConvArgs& a, int epi, hipStream_t stream, 
     case kEpiPlain: return launch_conv_e<COUT, VEC, kEpiPlain>(a, stream, tm);
     case kEpiRelu: return launch_conv_e<COUT, VEC, kEpiRelu>(a, stream, tm);
     case kEpiMask: return launch_conv_e<COUT, VEC, kEpiMask>(a, stream, tm);
-    case kEpiMaskBits:
-      if constexpr (VEC && LARVA_PIXEL_MAJOR) return launch_conv_e<COUT, VEC, kEpiMaskBits>(a, stream, tm);
-      else return hipErrorNotSupported;
     case kEpiRes1: return launch_conv_e<COUT, VEC, kEpiRes1>(a, stream, tm);
     case kEpiRes2: return launch_conv_e<COUT, VEC, kEpiRes2>(a, stream, tm);
     case kEpiShuffle: return launch_conv_e<COUT, VEC, kEpiShuffle>(a, stream, tm);
@@ -1836,9 +1405,6 @@ static hipError_t launch_batch(const ConvBatch& b, int njobs, int epi, hipStream
     case kEpiPlain: return launch_batch_e<COUT, kEpiPlain>(b, njobs, stream);
     case kEpiRelu: return launch_batch_e<COUT, kEpiRelu>(b, njobs, stream);
     case kEpiMask: return launch_batch_e<COUT, kEpiMask>(b, njobs, stream);
-    case kEpiMaskBits:
-      if constexpr (LARVA_PIXEL_MAJOR) return launch_batch_e<COUT, kEpiMaskBits>(b, njobs, stream);
-      else return hipErrorNotSupported;
     case kEpiRes1: return launch_batch_e<COUT, kEpiRes1>(b, njobs, stream);
     case kEpiRes2: return launch_batch_e<COUT, kEpiRes2>(b, njobs, stream);
     case kEpiShuffle: return launch_batch_e<COUT, kEpiShuffle>(b, njobs, stream);
@@ -1853,7 +1419,7 @@ static hipError_t launch_batch(const ConvBatch& b, int njobs, int epi, hipStream
 template <int COUT, int EPI>
 static hipError_t launch_strip_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
   static bool attr_set = false;
-  constexpr size_t lds = kStripLdsBytes<COUT, EPI>;
+  constexpr size_t lds = kStripLdsBytes<COUT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_strip_kernel<COUT, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1874,9 +1440,6 @@ static hipError_t launch_strip(const ConvArgs& a, int epi, hipStream_t stream, c
     case kEpiPlain: return launch_strip_e<COUT, kEpiPlain>(a, stream, tm);
     case kEpiRelu: return launch_strip_e<COUT, kEpiRelu>(a, stream, tm);
     case kEpiMask: return launch_strip_e<COUT, kEpiMask>(a, stream, tm);
-    case kEpiMaskBits:
-      if constexpr (LARVA_PIXEL_MAJOR) return launch_strip_e<COUT, kEpiMaskBits>(a, stream, tm);
-      else return hipErrorNotSupported;
     case kEpiRes1: return launch_strip_e<COUT, kEpiRes1>(a, stream, tm);
     case kEpiRes2: return launch_strip_e<COUT, kEpiRes2>(a, stream, tm);
     case kEpiShuffle: return launch_strip_e<COUT, kEpiShuffle>(a, stream, tm);
@@ -1970,15 +1533,9 @@ int larva_diag_next_slot(void) { return g_diag_next_slot; }
 // (cout, n_src*cin_per_src).  Epilogue, in this order: relu -> mask -> +res0 -> +res1 -> store
 // (mode 0, [N][cout][H][W]) or pixel-shuffle(4) store with optional +base (mode 1,
 // [N][cout/16][4H][4W]).  Stream-ordered, never allocates or synchronises.
-struct MaskBitsArg {
-  const unsigned char* in = nullptr;   // ReLU-backward mask as sign bits (instead of `mask`)
-  unsigned char* out = nullptr;        // conv+ReLU: also write the sign bits of the output
-};
-
 static int conv_build(const float* const* src, int n_src, int cin_per_src, const float* wpk, const float* bias,
                       const float* res0, const float* res1, const float* mask, const float* base, float* out,
-                      int N, int H, int W, int pitch, int relu, int mode, ConvArgs& a, bool& aligned, int& epi,
-                      MaskBitsArg mb = MaskBitsArg{}) {
+                      int N, int H, int W, int pitch, int relu, int mode, ConvArgs& a, bool& aligned, int& epi) {
   if (pitch == 0) pitch = W;
   if (pitch < W) return (int)hipErrorInvalidValue;
   if (n_src < 1 || n_src > kMaxSrc || cin_per_src % kCh || cin_per_src <= 0 || N <= 0 || H <= 0 || W <= 0)
@@ -2004,13 +1561,6 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
                           reinterpret_cast<uintptr_t>(res1) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0);
   a.wpk = wpk; a.bias = bias; a.res0 = res0; a.res1 = res1; a.mask = mask; a.base = base;
   a.out = out;
-  a.maskbits = mb.in; a.maskbits_out = mb.out;
-  if (mb.in || mb.out) {
-    // sign bits exist on the 16-byte path with pixel-major accumulators only; a launch is either the producer
-    // (conv + ReLU, nothing else fused) or the consumer (ReLU-backward mask, nothing else fused)
-    if (!aligned || !LARVA_PIXEL_MAJOR) return (int)hipErrorNotSupported;
-    if (mode != 0 || mask || res0 || res1 || (mb.in && (relu || mb.out)) || (mb.out && !relu)) return (int)hipErrorInvalidValue;
-  }
   a.cin_per_src = cin_per_src;
   a.n_chunks = n_src * cin_per_src / kCh;
   a.N = N; a.H = H; a.W = W; a.pitch = pitch;
@@ -2027,9 +1577,8 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
     epi = base ? kEpiShuffleBase : kEpiShuffle;
   } else {
     if (base) return (int)hipErrorInvalidValue;
-    const int code = (relu ? 1 : 0) | (mask ? 2 : 0) | (res0 ? 4 : 0) | (res1 ? 8 : 0) | (mb.in ? 16 : 0);
+    const int code = (relu ? 1 : 0) | (mask ? 2 : 0) | (res0 ? 4 : 0) | (res1 ? 8 : 0);
     switch (code) {
-      case 16: epi = kEpiMaskBits; break;
       case 0: epi = kEpiPlain; break;
       case 1: epi = kEpiRelu; break;
       case 2: epi = kEpiMask; break;
@@ -2048,7 +1597,7 @@ static int conv_build(const float* const* src, int n_src, int cin_per_src, const
 // 65.1 against 64.0 us -- the "fewer rounds" argument (935 instead of 1243 tiles) does not hold, workgroups are placed
 // as slots free up, not in rounds.  So: 4 rows for 32-channel launches of more than one round's worth of tiles.
 static int conv_tile_rows(int N, int H, int pitch, int cout, int epi, bool aligned, int forced) {
-  const bool can4 = aligned && LARVA_PIXEL_MAJOR && (cout == 48 || cout == 32) &&
+  const bool can4 = aligned && (cout == 48 || cout == 32) &&
                     (epi == kEpiPlain || epi == kEpiRelu || epi == kEpiRes1 || epi == kEpiRes2 || epi == kEpiShuffle || epi == kEpiShuffleBase);
   if (forced == 3 || !can4) return 3;
   if (forced == 4) return 4;
@@ -2059,16 +1608,16 @@ static int conv_tile_rows(int N, int H, int pitch, int cout, int epi, bool align
 static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                          const float* bias, const float* res0, const float* res1, const float* mask,
                          const float* base, float* out, int N, int cout, int H, int W, int pitch, int relu,
-                         int mode, void* stream, const LaunchTiming* tm, MaskBitsArg mb = MaskBitsArg{}, int tile_rows = 0) {
+                         int mode, void* stream, const LaunchTiming* tm, int tile_rows = 0) {
   ConvArgs a;
   bool aligned;
   int epi;
   const int rc = conv_build(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, H, W, pitch, relu,
-                            mode, a, aligned, epi, mb);
+                            mode, a, aligned, epi);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (tile_rows != 0 && tile_rows != 3 && tile_rows != 4) return (int)hipErrorInvalidValue;
-  if (!mb.in && !mb.out && conv_tile_rows(N, H, a.pitch, cout, epi, aligned, tile_rows) == 4) {
+  if (conv_tile_rows(N, H, a.pitch, cout, epi, aligned, tile_rows) == 4) {
     a.tiles_y = (H + 3) / 4;
     a.magic_ty = div_magic(a.tiles_y);
     a.nwg = N * a.tiles_x * a.tiles_y;
@@ -2082,7 +1631,7 @@ static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, co
   // (LARVA_PERSIST=0: one workgroup per tile as before -- read per call, the tests compare the two)
   const char* pe = getenv("LARVA_PERSIST");
   const bool persist_on = !(pe && pe[0] == '0');
-  if (persist_on && aligned && !mb.in && !mb.out && a.nwg > conv_slots() && a.n_chunks >= 1) {
+  if (persist_on && aligned && a.nwg > conv_slots()) {
     hipError_t e = hipErrorNotSupported;
     switch (cout) {
 #if !LARVA_DIAG_ONLY48
@@ -2124,24 +1673,16 @@ int larva_conv3x3_fwd_pitched(const float* const* src, int n_src, int cin_per_sr
                        relu, mode, stream, nullptr);
 }
 
-// ReLU sign bits.  larva_maskbits_bytes: size of the sign-bit tensor of an [N][cout][H][pitch] activation
-// ([N][cout / 16][H][ceil(pitch / 16)][64] bytes, see ConvArgs::maskbits).  The *_mb entry points are their namesakes
-// with two more operands: maskbits_out (conv + ReLU launches: also write the output's sign bits) and maskbits (the
-// ReLU-backward mask `h > 0` of models/LarvaNet.py:211's autograd given as those bits instead of the fp32 tensor h:
-// relu = 0, mask = res0 = res1 = NULL).  16-byte staging path only: hipErrorNotSupported otherwise (the caller
-// then passes the fp32 mask).  Results are bit-identical to the fp32-mask launch.
-long long larva_maskbits_bytes(int N, int cout, int H, int pitch) {
-  if (N <= 0 || cout <= 0 || cout % 16 || H <= 0 || pitch <= 0) return -1;
-  return (long long)N * (long long)maskbits_image_bytes(cout, H, pitch);
-}
-
-int larva_conv3x3_fwd_pitched_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                                 const float* bias, const float* res0, const float* res1, const float* mask,
-                                 const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                                 int relu, int mode, const unsigned char* maskbits, unsigned char* maskbits_out,
-                                 int tile_rows, void* stream) {
+// ... and with the tile height of a whole-tensor launch chosen by the caller: tile_rows 0 = the library's choice (3 x 48
+// tiles; 4 x 48 for 32-channel launches of more tiles than workgroup slots), 3 / 4 = that height (tests, A/B timing;
+// 4 rows exist on the 16-byte path at 48 / 32 channels for the epilogues of an inference forward: hipErrorNotSupported
+// otherwise).  Results do not depend on the tiling.
+int larva_conv3x3_fwd_tiled(const float* const* src, int n_src, int cin_per_src, const float* wpk,
+                            const float* bias, const float* res0, const float* res1, const float* mask,
+                            const float* base, float* out, int N, int cout, int H, int W, int pitch,
+                            int relu, int mode, int tile_rows, void* stream) {
   return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch,
-                       relu, mode, stream, nullptr, MaskBitsArg{maskbits, maskbits_out}, tile_rows);
+                       relu, mode, stream, nullptr, tile_rows);
 }
 
 // njobs (2..4) INDEPENDENT convolutions of one shape and one fusion in ONE launch (their workgroups
@@ -2149,11 +1690,11 @@ int larva_conv3x3_fwd_pitched_mb(const float* const* src, int n_src, int cin_per
 // of njobs pointers, or NULL when no job uses it (a fusion is either used by all jobs or by none).
 // Only the 16-byte staging path (pitch % 4 == 0, 16-byte aligned tensors): otherwise
 // hipErrorNotSupported, and the caller issues the jobs one by one.
-static int conv_batch_dispatch(int njobs, const float* const* src, int n_src, int cin_per_src,
+int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int cin_per_src,
                             const float* const* wpk, const float* const* bias, const float* const* res0,
                             const float* const* res1, const float* const* mask, const float* const* base,
                             float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
-                            const unsigned char* const* maskbits, unsigned char* const* maskbits_out, void* stream) {
+                            void* stream) {
   if (njobs < 2 || njobs > kMaxConvJobs || !src || !wpk || !out) return (int)hipErrorInvalidValue;
   ConvBatch b{};
   int epi0 = -1;
@@ -2162,12 +1703,10 @@ static int conv_batch_dispatch(int njobs, const float* const* src, int n_src, in
     int epi;
     const int rc = conv_build(src + (size_t)j * n_src, n_src, cin_per_src, wpk[j], bias ? bias[j] : nullptr,
                               res0 ? res0[j] : nullptr, res1 ? res1[j] : nullptr, mask ? mask[j] : nullptr,
-                              base ? base[j] : nullptr, out[j], N, H, W, pitch, relu, mode, b.job[j], aligned, epi,
-                              MaskBitsArg{maskbits ? maskbits[j] : nullptr, maskbits_out ? maskbits_out[j] : nullptr});
+                              base ? base[j] : nullptr, out[j], N, H, W, pitch, relu, mode, b.job[j], aligned, epi);
     if (rc) return rc;
     if (!aligned) return (int)hipErrorNotSupported;
     if (j > 0 && epi != epi0) return (int)hipErrorInvalidValue;
-    if ((maskbits && !maskbits[j]) || (maskbits_out && !maskbits_out[j])) return (int)hipErrorInvalidValue;   // all jobs or none
     epi0 = epi;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -2179,24 +1718,6 @@ static int conv_batch_dispatch(int njobs, const float* const* src, int n_src, in
     case 48: return (int)launch_batch<48>(b, njobs, epi0, s);
     default: return (int)hipErrorInvalidValue;
   }
-}
-
-int larva_conv3x3_fwd_batch(int njobs, const float* const* src, int n_src, int cin_per_src,
-                            const float* const* wpk, const float* const* bias, const float* const* res0,
-                            const float* const* res1, const float* const* mask, const float* const* base,
-                            float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
-                            void* stream) {
-  return conv_batch_dispatch(njobs, src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch,
-                             relu, mode, nullptr, nullptr, stream);
-}
-
-int larva_conv3x3_fwd_batch_mb(int njobs, const float* const* src, int n_src, int cin_per_src,
-                               const float* const* wpk, const float* const* bias, const float* const* res0,
-                               const float* const* res1, const float* const* mask, const float* const* base,
-                               float* const* out, int N, int cout, int H, int W, int pitch, int relu, int mode,
-                               const unsigned char* const* maskbits, unsigned char* const* maskbits_out, void* stream) {
-  return conv_batch_dispatch(njobs, src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch,
-                             relu, mode, maskbits, maskbits_out, stream);
 }
 
 // njobs (2..4) EXITS of the training step in one launch (models/LarvaNet.py:104-109 for several i):
@@ -2288,32 +1809,28 @@ int larva_strip_tile_table(int H, int W, int phase, unsigned* tab, int cap) {
 }
 
 // larva_conv3x3_fwd_pitched on strip tiles: `tile_tab` = DEVICE copy of larva_strip_tile_table(H,
-// pitch) with `tiles_per_image` entries.  plain_stores: mode-0 output written with plain instead of
-// non-temporal stores (faster when the next launch reads it at once, see the kernel's epilogue).
-// cout = 32, 48 or 64 and the 16-byte staging path only (pitch % 4 == 0, 16-byte aligned tensors), otherwise
-// hipErrorNotSupported.  Results are bit-identical to
-// larva_conv3x3_fwd_pitched: every output's K loop runs in the same order, only the assignment of
-// pixels to workgroups differs.
+// pitch) with `tiles_per_image` entries, `tile_tab_host` = the HOST array larva_strip_tile_table filled (the same
+// entries) or NULL: given, and small enough (<= 64 tiles, H <= 256, pitch <= 2048), the table travels inside the kernel
+// arguments and a workgroup finds its tile without a dependent memory round trip (ConvArgs::tab16).  plain_stores:
+// mode-0 output written with plain instead of non-temporal stores (faster when the next launch reads it at once, see
+// the kernel's epilogue).  cout = 32, 48 or 64 and the 16-byte staging path only (pitch % 4 == 0, 16-byte aligned
+// tensors), otherwise hipErrorNotSupported.  Results are bit-identical to larva_conv3x3_fwd_pitched: every output's K
+// loop runs in the same order, only the assignment of pixels to workgroups differs.
 static int strips_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                            const float* bias, const float* res0, const float* res1, const float* mask,
                            const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                           int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
-                           void* stream, const LaunchTiming* tm, MaskBitsArg mb = MaskBitsArg{},
-                           const unsigned* tile_tab_host = nullptr) {
+                           int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
+                           int tiles_per_image, int plain_stores, void* stream, const LaunchTiming* tm) {
   if (cout != 48 && cout != 32 && cout != 64) return (int)hipErrorNotSupported;
   if (!tile_tab || tiles_per_image < 1) return (int)hipErrorInvalidValue;
   ConvArgs a;
   bool aligned;
   int epi;
   const int rc = conv_build(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, H, W, pitch, relu,
-                            mode, a, aligned, epi, mb);
+                            mode, a, aligned, epi);
   if (rc) return rc;
   if (!aligned) return (int)hipErrorNotSupported;
   if ((long long)N * tiles_per_image >= (1ll << 20)) return (int)hipErrorInvalidValue;  // div_by_magic range
-  if (LARVA_AUX_LDS && (epi == kEpiMask || epi == kEpiRes1 || epi == kEpiRes2)) {
-    // the loader wave streams the epilogue's operands during its two past-the-end turns (32-bit lane offsets)
-    if (a.n_chunks < 2 || (long long)cout * H * pitch >= (1ll << 29)) return (int)hipErrorNotSupported;
-  }
   a.tile_tab = tile_tab;
   if (tile_tab_host && tiles_per_image <= 64 && H <= 256 && pitch <= 2048) {
     // the same table inline in the kernel arguments, 16 bits per tile (ConvArgs::tab16)
@@ -2342,74 +1859,10 @@ static int strips_dispatch(const float* const* src, int n_src, int cin_per_src, 
 int larva_conv3x3_fwd_strips(const float* const* src, int n_src, int cin_per_src, const float* wpk,
                              const float* bias, const float* res0, const float* res1, const float* mask,
                              const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                             int relu, int mode, const unsigned* tile_tab, int tiles_per_image, int plain_stores,
-                             void* stream) {
+                             int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
+                             int tiles_per_image, int plain_stores, void* stream) {
   return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu, mode,
-                         tile_tab, tiles_per_image, plain_stores, stream, nullptr);
-}
-
-// ... and `tile_tab_host`: the HOST array larva_strip_tile_table filled (the same entries as the device copy), or NULL.
-// Given, and small enough (<= 64 tiles, H <= 256, pitch <= 2048), the table travels inside the kernel arguments and a
-// workgroup finds its tile without a dependent memory round trip (ConvArgs::tab16).
-int larva_conv3x3_fwd_strips_mb(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                                const float* bias, const float* res0, const float* res1, const float* mask,
-                                const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                                int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
-                                int tiles_per_image, int plain_stores,
-                                const unsigned char* maskbits, unsigned char* maskbits_out, void* stream) {
-  return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu, mode,
-                         tile_tab, tiles_per_image, plain_stores, stream, nullptr, MaskBitsArg{maskbits, maskbits_out},
-                         tile_tab_host);
-}
-
-// Measurement only (tools/probe_chain_kernel.py): `layers` conv3x3 + ReLU layers (48 -> 48 channels, the same packed
-// weights and bias in every layer) over the N images of buf0 [N][48][H][pitch] in ONE launch of N * tiles_per_image
-// workgroups (conv3x3_strip_chain_kernel): layer L reads buf[L % 2] and writes buf[(L + 1) % 2].  state: N + 1 words
-// (per-image counters, then a give-up flag), zeroed here in stream order; xcc_out: N * tiles_per_image ints or null;
-// trace: N * tiles_per_image * layers * 8 stamps (100 MHz: layer entered, input released, wave 0's stores issued, barrier
-// passed, wave 0 drained, loader wave done, wave 3 drained, unused) or null.
-// The grid must be co-resident (<= 256 workgroups per launch, at most two such launches at a time, nothing else running).
-int larva_conv3x3_chain_probe(float* buf0, float* buf1, const float* wpk, const float* bias, int N, int H, int W, int pitch,
-                              const unsigned* tile_tab, int tiles_per_image, unsigned* state, int* xcc_out,
-                              unsigned long long* trace, int layers, int naps, int plain_stores, void* stream) {
-  if (!buf0 || !buf1 || !state || !tile_tab || tiles_per_image < 1 || layers < 1 || N < 1 || N * tiles_per_image > 256)
-    return (int)hipErrorInvalidValue;
-  ChainProbeArgs p{};
-  bool aligned;
-  int epi;
-  const float* src[1] = {buf0};
-  const int rc = conv_build(src, 1, 48, wpk, bias, nullptr, nullptr, nullptr, nullptr, buf1, N, H, W, pitch, 1, 0, p.a, aligned,
-                            epi, MaskBitsArg{});
-  if (rc) return rc;
-  if (!aligned || epi != kEpiRelu || p.a.n_chunks != 6) return (int)hipErrorNotSupported;
-  p.a.tile_tab = tile_tab;
-  p.a.tab_n = 0;
-  p.a.plain_stores = plain_stores ? 1 : 0;   // (0: non-temporal stores)
-  p.a.tiles_x = tiles_per_image;
-  p.a.tiles_y = 1;
-  p.a.magic_tx = div_magic(tiles_per_image);
-  p.a.magic_ty = div_magic(1);
-  p.a.nwg = N * tiles_per_image;
-  p.buf[0] = buf0;
-  p.buf[1] = buf1;
-  p.counters = state;
-  p.err = state + N;
-  p.xcc_out = xcc_out;
-  p.trace = trace;
-  p.naps = naps < 1 ? 1 : naps;
-  p.layers = layers;
-  constexpr size_t lds = kStripLdsBytes<48, kEpiRelu> + 16;   // + the layer flag
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_strip_chain_kernel<48>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipError_t e = hipMemsetAsync(state, 0, sizeof(unsigned) * (size_t)(N + 1), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((conv3x3_strip_chain_kernel<48>), dim3(p.a.nwg), dim3(320), lds, (hipStream_t)stream, p);
-  return (int)hipGetLastError();
+                         tile_tab, tile_tab_host, tiles_per_image, plain_stores, stream, nullptr);
 }
 
 #if LARVA_DIAG & 32
@@ -2421,6 +1874,12 @@ int larva_diag_set_stamps(unsigned long long* buf) {
 }
 #endif
 
+}  // extern "C"
+
+#ifdef LARVA_DIAG_API
+// Measurement entry points that are NOT part of liblarva_hip.so / include/larva_hip.h (tools/build_diag.sh builds
+// tools/_diag/<name>.so = the product's sources + these; declared in tools/larva_diag.h)
+extern "C" {
 // Measurement only (synchronises; not capturable): runs the same launch `iters` times with
 // kernel-attached events and returns the mean and minimum kernel duration in milliseconds.
 extern "C++" {
@@ -2473,13 +1932,10 @@ int larva_conv3x3_fwd_strips_timed(const float* const* src, int n_src, int cin_p
                                    float* min_ms) {
   return timed_launches(iters, mean_ms, min_ms, [&](const LaunchTiming* tm) {
     return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu,
-                           mode, tile_tab, tiles_per_image, plain_stores, stream, tm, MaskBitsArg{}, tile_tab_host);
+                           mode, tile_tab, tile_tab_host, tiles_per_image, plain_stores, stream, tm);
   });
 }
 
 }  // extern "C"
-
-#ifdef LARVA_DIAG_API
-// measurement kernels that are NOT part of liblarva_hip.so (tools/build_variant.sh diag -DLARVA_DIAG_API=1)
 #include "conv3x3_pair_chain.inc"
 #endif

@@ -814,6 +814,7 @@ int larva_l1_bwd_unshuffle4(const float* a, const float* b, const float* gout, f
   return (int)hipGetLastError();
 }
 
+#ifdef LARVA_DIAG_API   // (tools/build_diag.sh; declared in tools/larva_diag.h, not in include/larva_hip.h)
 // Measurement only: one lane stores the 100 MHz wall clock (s_memrealtime) into *dst, in stream order -- a capturable
 // marker between the launches of a hipGraph whose kernels must stay exactly the product's (tools/step_marks.py:
 // when does each chain of the captured step start and end?).  Costs one launch slot (~2 us) on its stream.
@@ -841,6 +842,7 @@ int larva_delay_ticks(int ticks, void* stream) {
   hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
   return (int)hipGetLastError();
 }
+#endif
 
 // out[0] = (sum of n <= 8 device scalars, added in index order) / divisor.
 int larva_sum_scalars(const float* const* terms, int n, float divisor, float* out, void* stream) {
@@ -936,6 +938,6 @@ int larva_sqerr_u8(const float* out, const unsigned char* truth, int C, int H, i
 
 const char* larva_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
-int larva_abi_version(void) { return 4; }   // 4: ReLU sign-bit operands (*_mb entry points).  3: unpadded, swizzled packed weight rows at 32 / 64 channels; AdamW hyper-parameters as doubles
+int larva_abi_version(void) { return 5; }   // 5: product entry points only (measurement entry points live in the -DLARVA_DIAG_API build, tools/larva_diag.h); larva_conv3x3_fwd_tiled; larva_conv3x3_fwd_strips takes the host table; the *_mb sign-bit entry points are gone.  4: ReLU sign-bit operands.  3: unpadded, swizzled packed weight rows at 32 / 64 channels; AdamW hyper-parameters as doubles
 
 }  // extern "C"

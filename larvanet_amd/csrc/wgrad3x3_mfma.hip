@@ -37,17 +37,11 @@
 #ifndef WG_DIAG
 #define WG_DIAG 0
 #endif
-#ifndef WG_ASM_MFMA
-#define WG_ASM_MFMA 1   // 1: the pipelined kernel's MFMAs are inline asm with the accumulator tied in an AGPR
-#endif
-// Operand RUNS in the pipelined kernel (round 4; WgPipe::RUNS): 0 off, 1 for the shapes whose lightest wave has fewer
-// than 17 MFMAs per k-step ((32,32), (64,32), (48,32)), 2 for (48,48) too.
-#ifndef WG_RUNS
-#define WG_RUNS 1
-#endif
-#ifndef WG_MIN_GAPS
-#define WG_MIN_GAPS 6   // MFMAs per k-step of its lightest wave below which a shape stays off the pipelined kernel ((48,16): 6)
-#endif
+// (Settled by earlier rounds' A/Bs and no longer switchable: the pipelined kernel's MFMAs are inline asm with the
+// accumulator tied in an AGPR quad (r1: -7 %); operand RUNS for the shapes whose lightest wave has fewer than 17 MFMAs per
+// k-step -- (32,32), (64,32), (48,32), the heads -- and not for (48,48) (r4: its spelled-out layout is 0.7 % faster); the
+// load -> LDS-write distance of 6 k-steps (r4: 10 / 14 no better).)
+constexpr int kWgMinGaps = 6;   // MFMAs per k-step of its lightest wave below which a shape stays off the pipelined kernel ((48,16): 6)
 
 
 namespace larva {
@@ -111,10 +105,8 @@ __device__ __forceinline__ void wstamp(unsigned long long* area, int k) {
 // of one CU.  Round 4: the tail runs the PIPELINED role at 16 input channels (6-9 MFMAs per k-step, operand runs):
 // 0.47 of a (48, 48) tile launched on its own (tools/bench_wgrad_head.py, 0.55 register-staged on the same box);
 // priced at 0.6.
-#ifndef LARVA_HEAD_COST10
-#define LARVA_HEAD_COST10 6
-#endif
-__host__ __device__ constexpr int flat_head_units(int tiles) { return (tiles * LARVA_HEAD_COST10 + 9) / 10; }
+constexpr int kHeadCost10 = 6;
+__host__ __device__ constexpr int flat_head_units(int tiles) { return (tiles * kHeadCost10 + 9) / 10; }
 
 template <int COUT, int CIN>
 struct WgCfg {
@@ -361,13 +353,9 @@ template <int COUT, int CIN>
 struct WgPipe {
   using C = WgCfg<COUT, CIN>;
   static constexpr int NSLOT = C::DY_ITERS + C::X_ITERS;
-#ifdef WG_LAG
-  static constexpr int LAG = WG_LAG;   // experiment: load -> LDS-write distance in k-steps
-#else
   // k-steps between a slot's global load and its LDS write (~0.35 us each).  Longer only costs
   // registers: at 15 the allocator starts shuttling values through AGPRs (v_accvgpr_* in the loop).
   static constexpr int LAG = 6;
-#endif
   static constexpr int MIN_GAPS = C::CT * (C::NB / 4);          // MFMAs per k-step of the lightest wave
   // The k-step's fillers -- CT + NBW operand reads, two address steps, the global load, the LDS write -- are laid
   // out one per MFMA gap where the lightest wave has >= 17 MFMAs per k-step ((48,48): 21); with fewer (round 3:
@@ -385,7 +373,7 @@ struct WgPipe {
   // element indices: 1.5-2 reads per k-step instead of 7-10.  Same products, another summation order.
   // 16-byte aligned channel strides (4 x odd: the 16 lanes of a quarter hit 16 x 4 distinct banks) where two tile
   // buffers still fit; else the old strides with 8-byte aligned 16-byte reads (ds_read2_b64).
-  static constexpr bool RUNS = WG_ASM_MFMA && !WG_DIAG && (WG_RUNS == 2 || (WG_RUNS == 1 && !SPREAD));
+  static constexpr bool RUNS = !WG_DIAG && !SPREAD;
   static constexpr bool ALIGNED = RUNS && 2 * (size_t)(COUT * 148 + CIN * 284 + 8) * sizeof(float) <= 160 * 1024;
   static constexpr int PSD = ALIGNED ? 148 : C::PSD;
   static constexpr int PSX = ALIGNED ? 284 : C::PSX;
@@ -393,7 +381,7 @@ struct WgPipe {
   static constexpr int X_FLOATS = CIN * PSX + 8;
   static constexpr int BUF_FLOATS = DY_FLOATS + X_FLOATS;
   static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_FLOATS * sizeof(float);
-  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NSLOT + LAG <= 36 && MIN_GAPS >= WG_MIN_GAPS;
+  static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && NSLOT + LAG <= 36 && MIN_GAPS >= kWgMinGaps;
 };
 
 // Per-thread, tile-invariant description of staging slot I: element offset of its 16 bytes
@@ -796,7 +784,7 @@ __device__ __forceinline__ void pipe_gaps_asm(PipeCtx<COUT, CIN, NBW, RunGroups<
 
 template <int COUT, int CIN, int B0, int NBW, bool BIAS, int WV, int KS>
 __device__ __forceinline__ void pipe_kstep(PipeCtx<COUT, CIN, NBW, RunGroups<B0, NBW>::NG>& x) {
-  if constexpr (WG_ASM_MFMA && !WG_DIAG) {
+  if constexpr (!WG_DIAG) {
     int gy = 0, gx = 0;
     uint64_t addr = 0;
     __builtin_amdgcn_sched_barrier(0);
@@ -920,7 +908,7 @@ __device__ __forceinline__ void wg_role_pipe(const WgradBatch& b, const PipeSeg&
   }
 
   // (the compiler does not see the asm MFMAs: cover their write-back before the accumulators are read)
-  if constexpr (WG_ASM_MFMA && !WG_DIAG) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  if constexpr (!WG_DIAG) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
   for (int c = 0; c < C::CT; ++c)
 #pragma unroll

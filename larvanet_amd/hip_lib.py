@@ -35,22 +35,15 @@ SIGNATURES = {
     "larva_conv3x3_fwd_batch": (ctypes.c_int, [ctypes.c_int, _c_pp, ctypes.c_int, ctypes.c_int, _c_pp, _c_pp, _c_pp, _c_pp,
                                                _c_pp, _c_pp, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    "larva_maskbits_bytes": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
-    "larva_conv3x3_fwd_pitched_mb": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
-                                                    _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
-                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
-    "larva_conv3x3_fwd_batch_mb": (ctypes.c_int, [ctypes.c_int, _c_pp, ctypes.c_int, ctypes.c_int, _c_pp, _c_pp, _c_pp, _c_pp,
-                                                  _c_pp, _c_pp, _c_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_pp, _c_pp,
-                                                  ctypes.c_void_p]),
-    "larva_conv3x3_fwd_strips_mb": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
-                                                   _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
-                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                   ctypes.POINTER(ctypes.c_uint), ctypes.c_int, ctypes.c_int,
-                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "larva_conv3x3_fwd_tiled": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
+                                               _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "larva_conv3x3_fwd_strips": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
+                                                _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.POINTER(ctypes.c_uint), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_head_conv3_direct": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_exit_l1_partials": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -59,23 +52,6 @@ SIGNATURES = {
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_strip_tile_table": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint),
                                               ctypes.c_int]),
-    "larva_conv3x3_fwd_strips": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
-                                                _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
-                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    "larva_conv3x3_fwd_strips_timed": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
-                                                      _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
-                                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                      ctypes.POINTER(ctypes.c_uint), ctypes.c_int, ctypes.c_int,
-                                                      ctypes.c_void_p, ctypes.c_int,
-                                                      ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
-    "larva_conv3x3_fwd_timed": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_int, _c_float_p, _c_float_p,
-                                               _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
-                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
-                                               ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "larva_wgrad_partial_floats": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "larva_conv3x3_wgrad": (ctypes.c_int, [_c_pp, _c_pp, _c_pp, _c_pp, _c_pp, _c_int_p, _c_int_p, _c_int_p,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -127,10 +103,6 @@ SIGNATURES = {
     "larva_host_cell_free": (ctypes.c_int, [_c_float_p]),
     "larva_loss_from_partials": (ctypes.c_int, [_c_pp, _c_int_p, _c_float_p, ctypes.c_int, ctypes.c_float,
                                                 _c_float_p, ctypes.c_void_p]),
-    "larva_stamp_clock": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
-    "larva_delay_ticks": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
-    "larva_conv3x3_chain_probe": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int,
-                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "larva_sum_scalars": (ctypes.c_int, [_c_pp, ctypes.c_int, ctypes.c_float, _c_float_p, ctypes.c_void_p]),
     "larva_pixel_unshuffle4": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

@@ -89,7 +89,6 @@ def pack_weights_batch(jobs):
 
 
 _STRIP_TABLES = {}
-INLINE_TILE_TABLE = os.environ.get("LARVA_INLINE_TABLE", "1") != "0"   # A/B: 0 = always the device table
 
 
 def strip_tile_table(H, P, device, phase=0):
@@ -111,7 +110,7 @@ def strip_tile_table(H, P, device, phase=0):
                                    "(run the step once outside the capture first)" % (H, P))
             import numpy as np
             # (entries use bit 31: the raw 32-bit patterns travel as int32); the host array is kept: the launch passes
-            # it along, and small tables then travel inside the kernel arguments (larva_conv3x3_fwd_strips_mb)
+            # it along, and small tables then travel inside the kernel arguments (larva_conv3x3_fwd_strips)
             hit = (torch.from_numpy(np.frombuffer(buf, dtype=np.int32, count=n).copy()).to(device), n, buf)
         _STRIP_TABLES[key] = hit
     return hit or None
@@ -143,39 +142,9 @@ def step_prologue(jobs, x, x16, base):
     hip_lib.check(code, "larva_step_prologue")
 
 
-def maskbits_bytes(N, cout, H, P):
-    """Bytes of the ReLU sign-bit tensor of an [N][cout][H][P] activation (include/larva_hip.h: larva_maskbits_bytes)."""
-    n = int(hip_lib.load().larva_maskbits_bytes(int(N), int(cout), int(H), int(P)))
-    if n < 0:
-        raise RuntimeError("larvanet_amd: no sign-bit layout for %s" % ((N, cout, H, P),))
-    return n
-
-
-def maskbits_ok(*tensors):
-    """Can launches over these [N][c][H][P] operands take the conv kernel's 16-byte staging path -- the only one that
-    writes / reads ReLU sign bits?  (Row pitch a multiple of 4 floats, every tensor 16-byte aligned.)"""
-    return all(t is not None and t.is_cuda and int(t.shape[-1]) % 4 == 0 and t.data_ptr() % 16 == 0 for t in tensors)
-
-
-def new_maskbits(like, cout=None):
-    """Uninitialised sign-bit tensor for an activation shaped like `like` ([N][c][H][P])."""
-    N, c, H, P = (int(v) for v in like.shape)
-    return torch.empty(maskbits_bytes(N, c if cout is None else cout, H, P), device=like.device, dtype=torch.uint8)
-
-
-def _chk_bits(t, name, N, cout, H, P):
-    if t is None:
-        return None
-    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous():
-        raise RuntimeError("larvanet_amd: %s must be a contiguous uint8 tensor on the HIP device" % name)
-    if t.numel() != maskbits_bytes(N, cout, H, P):
-        raise RuntimeError("larvanet_amd: %s has %d bytes, expected %d" % (name, t.numel(), maskbits_bytes(N, cout, H, P)))
-    return t.data_ptr()
-
-
 def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=None,
             shuffle=False, base=None, out=None, logical_w=None, images=None, strips=False, plain_stores=False,
-            maskbits=None, maskbits_out=None, tile_rows=0):
+            tile_rows=0):
     """Fused 3x3 conv over the channel concatenation of `srcs` (list of [N][c][H][P]).
 
     shuffle=False: returns [N][cout][H][P]; shuffle=True: returns PixelShuffle(4) layout
@@ -187,11 +156,9 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     starts with the other tile height): 5 x 16 / 4 x 16 tiles instead of 3 x 48 (same results bit for
     bit; see larva_conv3x3_fwd_strips) where the shape allows, else the regular tiles; plain_stores:
     the strip launch writes its output with plain instead of non-temporal stores.
-    maskbits_out (with relu=True): the launch also writes the sign bits of its output (new_maskbits());
-    maskbits: the ReLU-backward mask given as those bits instead of `mask` (same result bit for bit).  Both need
-    maskbits_ok() operands (the 16-byte staging path) and raise otherwise.
-    tile_rows: 0 = the library picks 3 x 48 or 4 x 48 tiles for a whole-tensor launch (fewer rounds of resident
-    workgroups on large images), 3 / 4 = that height (tests, A/B timing)."""
+    tile_rows: 0 = the library picks the tiling of a whole-tensor launch (3 x 48 tiles; 4 x 48 for large 32-channel
+    launches; persistent workgroups where there are more tiles than workgroup slots), 3 / 4 = that tile height (tests,
+    A/B timing; larva_conv3x3_fwd_tiled)."""
     lib = hip_lib.load()
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
@@ -220,13 +187,6 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     def at(ptr, per_image_floats):   # the same operand, starting at image `lo`
         return None if ptr is None else ptr + 4 * lo * per_image_floats
 
-    bits_in = _chk_bits(maskbits, "maskbits", N, cout, H, P)
-    bits_out = _chk_bits(maskbits_out, "maskbits_out", N, cout, H, P)
-    use_bits = bits_in is not None or bits_out is not None
-    if use_bits:
-        per = maskbits_bytes(1, cout, H, P)
-        bits_in = None if bits_in is None else bits_in + lo * per
-        bits_out = None if bits_out is None else bits_out + lo * per
     lr_img, hr_img = H * P, 16 * H * W
     args = (hip_lib.ptr_array([at(p, cps * lr_img) for p in ptrs]), len(srcs), cps, wpk.data_ptr(),
             _opt(bias, "bias", (cout,)), at(_opt(res0, "res0", full), cout * lr_img),
@@ -237,13 +197,12 @@ def conv3x3(srcs, wpk, cout, bias=None, relu=False, mask=None, res0=None, res1=N
     if strips and cout in (48, 32, 64):
         tab = strip_tile_table(H, P, out.device, phase=1 if strips == 2 else 0)
         if tab is not None:
-            code = lib.larva_conv3x3_fwd_strips_mb(*args, tab[0].data_ptr(), tab[2] if INLINE_TILE_TABLE else None, tab[1],
-                                                   1 if plain_stores else 0, bits_in, bits_out, _stream())
+            code = lib.larva_conv3x3_fwd_strips(*args, tab[0].data_ptr(), tab[2], tab[1], 1 if plain_stores else 0, _stream())
             if code != 801:   # hipErrorNotSupported: unaligned operands -> the regular tiles below
                 hip_lib.check(code, "larva_conv3x3_fwd_strips")
                 return out
-    if use_bits or tile_rows:   # (unaligned operands: hipErrorNotSupported is raised -- callers ask maskbits_ok() first)
-        code = lib.larva_conv3x3_fwd_pitched_mb(*args, bits_in, bits_out, int(tile_rows), _stream())
+    if tile_rows:
+        code = lib.larva_conv3x3_fwd_tiled(*args, int(tile_rows), _stream())
     else:
         code = lib.larva_conv3x3_fwd_pitched(*args, _stream())
     hip_lib.check(code, "larva_conv3x3_fwd")
@@ -269,7 +228,7 @@ def conv3x3_batch(jobs, cout, relu=False, shuffle=False, logical_w=None):
         raise RuntimeError("larvanet_amd: unsupported batched conv shape")
     cin = cps * n_src
     full, hr = (N, cout, H, P), (N, cout // 16, 4 * H, 4 * W)
-    names = ("bias", "res0", "res1", "mask", "base", "maskbits", "maskbits_out")
+    names = ("bias", "res0", "res1", "mask", "base")
     used = {k: norm[0].get(k) is not None for k in names}
     src_ptrs, cols, outs = [], {k: [] for k in names}, []
     for j in norm:
@@ -280,9 +239,6 @@ def conv3x3_batch(jobs, cout, relu=False, shuffle=False, logical_w=None):
         for k, shape in (("bias", (cout,)), ("res0", full), ("res1", full), ("mask", full), ("base", hr)):
             if used[k]:
                 cols[k].append(_chk(j[k], k, shape))
-        for k in ("maskbits", "maskbits_out"):
-            if used[k]:
-                cols[k].append(_chk_bits(j[k], k, N, cout, H, P))
         outs.append(torch.empty(hr if shuffle else full, device=j["srcs"][0].device, dtype=torch.float32))
 
     def arr(k):
@@ -291,14 +247,11 @@ def conv3x3_batch(jobs, cout, relu=False, shuffle=False, logical_w=None):
     common = (len(norm), hip_lib.ptr_array(src_ptrs), n_src, cps, hip_lib.ptr_array([j["wpk"].data_ptr() for j in norm]),
               arr("bias"), arr("res0"), arr("res1"), arr("mask"), arr("base"),
               hip_lib.ptr_array([o.data_ptr() for o in outs]), N, cout, H, W, P, 1 if relu else 0, 1 if shuffle else 0)
-    if used["maskbits"] or used["maskbits_out"]:
-        code = lib.larva_conv3x3_fwd_batch_mb(*common, arr("maskbits"), arr("maskbits_out"), _stream())
-    else:
-        code = lib.larva_conv3x3_fwd_batch(*common, _stream())
+    code = lib.larva_conv3x3_fwd_batch(*common, _stream())
     if code == 801:  # hipErrorNotSupported: unaligned shape, one launch per job
         return [conv3x3(j["srcs"], j["wpk"], cout, bias=j.get("bias"), relu=relu, mask=j.get("mask"),
                         res0=j.get("res0"), res1=j.get("res1"), shuffle=shuffle, base=j.get("base"), out=o,
-                        logical_w=logical_w, maskbits=j.get("maskbits"), maskbits_out=j.get("maskbits_out"))
+                        logical_w=logical_w)
                 for j, o in zip(norm, outs)]
     hip_lib.check(code, "larva_conv3x3_fwd_batch")
     return outs
@@ -360,59 +313,6 @@ def conv3x3_exit_l1_batch(jobs, cout, truth, gvalue, gscale, want_image):
         return None
     hip_lib.check(code, "larva_conv3x3_exit_l1_batch")
     return outs, parts, grads
-
-
-def conv3x3_relu_timed(x, wpk, cout, bias, out, iters):
-    """Measurement only: (mean_ms, min_ms) of the fused conv+ReLU launch, from kernel-attached
-    events (the kernel's own begin/end timestamps)."""
-    import ctypes
-    lib = hip_lib.load()
-    N, cin, H, W = (int(v) for v in x.shape)
-    _chk(x, "x")
-    _chk(wpk, "wpk", (packed_weight_floats(cout, cin),))
-    _chk(out, "out", (N, cout, H, W))
-    mean, best = ctypes.c_float(0), ctypes.c_float(0)
-    code = lib.larva_conv3x3_fwd_timed(hip_lib.ptr_array([x.data_ptr()]), 1, cin, wpk.data_ptr(),
-                                       _opt(bias, "bias", (cout,)), None, None, None, None, out.data_ptr(),
-                                       N, cout, H, W, 1, 0, _stream(), iters, ctypes.byref(mean), ctypes.byref(best))
-    hip_lib.check(code, "larva_conv3x3_fwd_timed")
-    return float(mean.value), float(best.value)
-
-
-def conv3x3_strips_timed(x, wpk, cout, bias, out, iters, images=None, phase=0, relu=False, mask=None, res0=None, res1=None,
-                         plain_stores=False):
-    """Measurement only: (mean_ms, min_ms) of ONE strip-tile launch over images [lo, hi) running alone, with the
-    epilogue the operands select, from kernel-attached events -- the figure a profiler reports per dispatch of
-    conv3x3_mfma_strip_kernel<cout, EPI>."""
-    import ctypes
-    lib = hip_lib.load()
-    N, cin, H, W = (int(v) for v in x.shape)
-    _chk(x, "x")
-    _chk(wpk, "wpk", (packed_weight_floats(cout, cin),))
-    full = (N, cout, H, W)
-    _chk(out, "out", full)
-    lo, hi = (0, N) if images is None else images
-    tab = strip_tile_table(H, W, out.device, phase=phase)
-    if tab is None:
-        raise RuntimeError("larvanet_amd: no strip tiling for %d x %d" % (H, W))
-
-    def at(t, name):
-        return None if t is None else _chk(t, name, full) + 4 * lo * cout * H * W
-
-    mean, best = ctypes.c_float(0), ctypes.c_float(0)
-    code = lib.larva_conv3x3_fwd_strips_timed(
-        hip_lib.ptr_array([x.data_ptr() + 4 * lo * cin * H * W]), 1, cin, wpk.data_ptr(), _opt(bias, "bias", (cout,)),
-        at(res0, "res0"), at(res1, "res1"), at(mask, "mask"), None, out.data_ptr() + 4 * lo * cout * H * W, hi - lo, cout, H, W, W,
-        1 if relu else 0, 0, tab[0].data_ptr(), tab[2] if INLINE_TILE_TABLE else None, tab[1], 1 if plain_stores else 0,
-        _stream(), iters, ctypes.byref(mean),
-        ctypes.byref(best))
-    hip_lib.check(code, "larva_conv3x3_fwd_strips_timed")
-    return float(mean.value), float(best.value)
-
-
-def conv3x3_relu_strips_timed(x, wpk, cout, bias, out, iters, images=None, phase=0):
-    """conv3x3_strips_timed for the fused conv + bias + ReLU launch."""
-    return conv3x3_strips_timed(x, wpk, cout, bias, out, iters, images=images, phase=phase, relu=True)
 
 
 def wgrad_partial_floats(cout, cin, splits):

@@ -31,7 +31,11 @@ def test_library_exports_every_declared_symbol():
     assert sorted(hip_lib.SIGNATURES) == declared  # binding table and header agree
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.larva_abi_version() == 4
+    assert lib.larva_abi_version() == 5
+    # product entry points only: the measurement entry points (tools/larva_diag.h) exist in tools/_diag/*.so builds alone
+    for name in ("larva_stamp_clock", "larva_delay_ticks", "larva_conv3x3_fwd_timed", "larva_conv3x3_fwd_strips_timed",
+                 "larva_conv3x3_pair_chain_probe", "larva_conv3x3_chain_probe", "larva_maskbits_bytes"):
+        assert name not in declared and not hasattr(lib, name), name
     # pure host-side size helpers need no device
     def stride(c):   # cout_stride() of csrc/larva_common.h: c itself where c % 32 is 16 (or 0: swizzled rows), else c + 16
         return c if c % 32 in (0, 16) else c + 16

@@ -935,9 +935,18 @@ def test_adamw_host_scalars_match_torch_and_unaligned_views(hip_device):
 
 
 def test_timed_launches_compute_what_the_plain_launches_compute(hip_device):
-    """larva_conv3x3_fwd_timed / larva_conv3x3_fwd_strips_timed (bench.py's kernel-attached event timings): the
-    same output as the untimed launch, and durations that are positive and ordered (min <= mean)."""
+    """larva_conv3x3_fwd_timed / larva_conv3x3_fwd_strips_timed (kernel-attached event timings: bench.py's
+    `launch_alone_ms`): entry points of the MEASUREMENT library (tools/build_diag.sh, tools/larva_diag.h), not of the
+    product ABI.  Same output as the product's untimed launch, durations positive and ordered (min <= mean)."""
+    import importlib.util
+    import os
     from larvanet_amd import kernels as K
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("diag_lib", os.path.join(root, "tools", "diag_lib.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    if not D.available():
+        pytest.skip("tools/_diag/diag.so has not been built (tools/build_diag.sh diag)")
     gen = torch.Generator().manual_seed(8)
     x = (torch.randn(4, 48, 48, 48, generator=gen) * 20).to(hip_device)
     w = (torch.randn(48, 48, 3, 3, generator=gen) * 0.05).to(hip_device)
@@ -945,10 +954,10 @@ def test_timed_launches_compute_what_the_plain_launches_compute(hip_device):
     fwd, _ = K.pack_weights(w)
     ref = K.conv3x3(x, fwd, 48, bias=b, relu=True)
     out = torch.full_like(ref, float("nan"))
-    mean, best = K.conv3x3_relu_timed(x, fwd, 48, b, out, 3)
+    mean, best = D.conv3x3_relu_timed(x, fwd, 48, b, out, 3)
     assert torch.equal(out, ref) and 0 < best <= mean < 1.0
     out = torch.full_like(ref, float("nan"))
-    mean, best = K.conv3x3_relu_strips_timed(x, fwd, 48, b, out, 3, images=(1, 3))
+    mean, best = D.conv3x3_strips_timed(x, fwd, 48, b, out, 3, images=(1, 3), relu=True)
     torch.cuda.synchronize()
     assert torch.equal(out[1:3], ref[1:3]) and bool(torch.isnan(out[0]).all()) and bool(torch.isnan(out[3]).all())
     assert 0 < best <= mean < 1.0
@@ -1096,98 +1105,6 @@ def test_canonical_batch_at_32_and_64_channels(hip_device, canonical_wide_case, 
         close(dw, c["dw"], 3e-5, "wgrad splits=%d" % splits)
         close(db, c["db"], 3e-5, "bias grad splits=%d" % splits)
     assert scale > 10   # (the activations really are at the 0-255 scale's order of magnitude)
-
-
-def _decode_maskbits(bits, N, C, H, P):
-    """Independent reading of include/larva_hip.h's layout: bytes [N][C/16][H][ceil(P/16)][64], byte index inside a
-    unit = ((x % 16) / 4) * 16 + c % 16, bit r = pixel x - x % 4 + r  ->  bool [N][C][H][P] (columns >= P dropped)."""
-    nxg = (P + 15) // 16
-    b = bits.reshape(N, C // 16, H, nxg, 4, 16)           # [.., pixel quad, channel in group]
-    r = (b[..., None] >> np.arange(4, dtype=np.uint8)) & 1    # [n, cg, y, xg, q, ch, r]
-    r = r.transpose(0, 1, 5, 2, 3, 4, 6).reshape(N, C, H, nxg * 16)
-    return r[..., :P].astype(bool)
-
-
-@pytest.mark.parametrize("N,C,H,W,mode", [(2, 48, 9, 48, "wide"), (1, 48, 7, 52, "wide"), (1, 48, 5, 20, "wide"),
-                                          (2, 32, 6, 48, "wide"), (1, 64, 6, 52, "wide"),
-                                          (4, 48, 48, 48, "strips"), (2, 32, 13, 36, "strips"), (2, 64, 9, 48, "strips"),
-                                          (2, 48, 9, 48, "batch")])
-def test_relu_sign_bits_replace_the_fp32_mask_bit_for_bit(hip_device, N, C, H, W, mode):
-    """Round 4: the conv + ReLU launch also writes the sign bits of its output (1 byte per lane and 16 x 16 unit) and the
-    ReLU-backward launch reads them instead of the fp32 activation (models/LarvaNet.py:211's `h > 0`).  (1) the bits,
-    decoded here from the documented layout, equal oracle-relu(conv) > 0 wherever the pre-activation is not within
-    rounding of 0, and equal the kernel's OWN h > 0 everywhere; (2) the masked dgrad from the bits is bit-identical to
-    the one from the fp32 mask and matches the C oracle; wide tiles, strip tiles (both table phases, image sub-ranges)
-    and the batched launch; widths that are not a multiple of 16 (partial units)."""
-    from larvanet_amd import kernels as K
-    from oracle import larva_ref as R
-    rng = np.random.default_rng(N * 7 + C * 3 + H * 5 + W + len(mode))
-    x = _rand(rng, (N, C, H, W), 20.0)
-    w = _rand(rng, (C, C, 3, 3), 0.05)
-    b = _rand(rng, (C,), 1.0)
-    dy = _rand(rng, (N, C, H, W), 1e-3)
-    w2 = _rand(rng, (C, C, 3, 3), 0.05)
-    xd, dyd = _dev(x, hip_device), _dev(dy, hip_device)
-    fwd, _ = K.pack_weights(_dev(w, hip_device))
-    _, bwd2 = K.pack_weights(_dev(w2, hip_device))
-    bd = _dev(b, hip_device)
-    assert K.maskbits_ok(xd, dyd)
-    bits = torch.zeros(K.maskbits_bytes(N, C, H, W), dtype=torch.uint8, device=hip_device)
-    assert bits.numel() == N * (C // 16) * H * ((W + 15) // 16) * 64
-
-    def fwd_bwd(use_bits):
-        kw_f = {"maskbits_out": bits} if use_bits else {}
-        if mode == "wide":
-            h = K.conv3x3(xd, fwd, C, bias=bd, relu=True, **kw_f)
-            dh = K.conv3x3(dyd, bwd2, C, **({"maskbits": bits} if use_bits else {"mask": h}))
-        elif mode == "strips":
-            h = torch.empty_like(xd)
-            dh = torch.empty_like(xd)
-            half = N // 2
-            for k, rng_ in enumerate(((0, half), (half, N))):
-                K.conv3x3(xd, fwd, C, bias=bd, relu=True, out=h, images=rng_, strips=2 if k else True, **kw_f)
-            for k, rng_ in enumerate(((0, half), (half, N))):
-                # (the other table phase than the producer's: the layout does not depend on the tiling)
-                K.conv3x3(dyd, bwd2, C, out=dh, images=rng_, strips=True if k else 2,
-                          **({"maskbits": bits} if use_bits else {"mask": h}))
-        else:
-            bits2 = torch.zeros_like(bits)
-            hs = K.conv3x3_batch([dict({"srcs": xd, "wpk": fwd, "bias": bd}, **({"maskbits_out": bb} if use_bits else {}))
-                                  for bb in (bits, bits2)], C, relu=True)
-            assert torch.equal(hs[0], hs[1]) and (not use_bits or torch.equal(bits, bits2))
-            h = hs[0]
-            dhs = K.conv3x3_batch([dict({"srcs": dyd, "wpk": bwd2}, **({"maskbits": bb} if use_bits else {"mask": h}))
-                                   for bb in (bits, bits2)], C)
-            assert torch.equal(dhs[0], dhs[1])
-            dh = dhs[0]
-        torch.cuda.synchronize()
-        return h.cpu().numpy(), dh.cpu().numpy()
-
-    h_ref, dh_ref = fwd_bwd(False)
-    h_bits, dh_bits = fwd_bwd(True)
-    assert np.array_equal(h_ref, h_bits)
-    got = _decode_maskbits(bits.cpu().numpy(), N, C, H, W)
-    assert np.array_equal(got, h_bits > 0)                  # the kernel's own predicate, every element
-    pre = R.conv3x3(x, w, b)
-    sure = np.abs(pre) > 1e-3                               # (away from fp32-vs-double rounding of the pre-activation)
-    assert np.array_equal(got[sure], (pre > 0)[sure])
-    assert np.array_equal(dh_ref, dh_bits)                  # bit for bit
-    ref = np.where(pre > 0, R.conv3x3_dgrad(dy, w2), 0).astype(np.float32)
-    ok = sure | (ref == 0)
-    _report("dgrad masked by sign bits", np.where(ok, dh_bits, 0), np.where(ok, ref, 0), 2e-5)
-
-
-def test_sign_bits_are_refused_off_the_16_byte_path(hip_device):
-    from larvanet_amd import kernels as K
-    x = torch.zeros(1, 48, 5, 13, device=hip_device)        # pitch 13: register-staged path
-    assert not K.maskbits_ok(x)
-    fwd, _ = K.pack_weights(torch.zeros(48, 48, 3, 3, device=hip_device))
-    bits = torch.zeros(K.maskbits_bytes(1, 48, 5, 13), dtype=torch.uint8, device=hip_device)
-    with pytest.raises(RuntimeError, match="hip error 801"):
-        K.conv3x3(x, fwd, 48, relu=True, maskbits_out=bits)
-    with pytest.raises(RuntimeError):                       # a consumer with another fusion is an invalid request
-        K.conv3x3(torch.zeros(1, 48, 8, 16, device=hip_device), fwd, 48, relu=True,
-                  maskbits=torch.zeros(K.maskbits_bytes(1, 48, 8, 16), dtype=torch.uint8, device=hip_device))
 
 
 @pytest.mark.parametrize("N,C,H,W", [(1, 48, 23, 100), (2, 48, 9, 48), (1, 32, 14, 52), (1, 48, 5, 20)])

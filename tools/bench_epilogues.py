@@ -3,13 +3,15 @@
   alone     one half-batch launch running alone, kernel-attached events (what rocprofv3 reports per dispatch)
   chains    two half-batch chains of 40 links that ALL have that epilogue, a tensor and a weight image per layer
             as in a training step, captured graph, per full-batch layer
-Run with LARVA_HIP_LIB=<variant .so> for a same-box A/B (tools/ab_aux_lds.sh)."""
+Run with LARVA_HIP_LIB=<variant .so> (and LARVA_DIAG_LIB for the `alone` column) for a same-box A/B (tools/ab_lib.sh)."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from larvanet_amd import kernels as K
+import diag_lib   # (tools/diag_lib.py)
 
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(0)
@@ -26,18 +28,11 @@ streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 HALVES = [(0, 8), (8, 16)]
 
 
-BITS = [K.new_maskbits(acts[0]) for _ in range(LAYERS)]
-
-
 def operands(kind, i):
     if kind == "relu":
         return {"relu": True}
     if kind == "plain":         # no epilogue operand, non-temporal stores: the floor of the mask / residual links
         return {}
-    if kind == "relu+bits":     # the producer of round 4's sign bits
-        return {"relu": True, "maskbits_out": BITS[i]}
-    if kind == "maskbits":      # the ReLU-backward mask as sign bits
-        return {"maskbits": BITS[(i + 3) % LAYERS]}
     if kind == "mask":
         return {"mask": acts[(i + 3) % LAYERS]}
     if kind == "res0":
@@ -84,13 +79,13 @@ def timed(fn, reps=20):
 
 
 print("lib: %s   channels: %d" % (os.environ.get("LARVA_HIP_LIB", "default"), C))
-for kind in ("relu", "relu+bits", "plain", "mask", "maskbits", "res0", "res2"):
+for kind in ("relu", "plain", "mask", "res0", "res2"):
     kw = operands(kind, 0)
-    if "bits" in kind:          # (no kernel-attached timing entry for the *_mb launches: rocprofv3 --kernel-trace has it)
-        mean = best = float("nan")
+    if diag_lib.available():    # kernel-attached timing lives in the measurement library (tools/build_diag.sh)
+        diag_lib.conv3x3_strips_timed(acts[0], wpks[0], C, b, acts[1], 5, images=(0, 8), **kw)
+        mean, best = diag_lib.conv3x3_strips_timed(acts[0], wpks[0], C, b, acts[1], 100, images=(0, 8), **kw)
     else:
-        K.conv3x3_strips_timed(acts[0], wpks[0], C, b, acts[1], 5, images=(0, 8), **kw)
-        mean, best = K.conv3x3_strips_timed(acts[0], wpks[0], C, b, acts[1], 100, images=(0, 8), **kw)
+        mean = best = float("nan")
     for a in acts[1:]:
         a.copy_(acts[0])
     chain = timed(graphed(lambda: epilogue_chain(kind)))

@@ -7,6 +7,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from larvanet_amd import kernels as K
 
@@ -21,7 +22,8 @@ def conv_us(C, iters=40):
     fwd, _ = K.pack_weights(w)
     out = torch.empty_like(x)
     K.conv3x3(x, fwd, C, bias=b, relu=True, out=out)
-    mean, _ = K.conv3x3_relu_timed(x, fwd, C, b, out, iters)
+    import diag_lib   # (tools/diag_lib.py: kernel-attached timing lives in the measurement library)
+    mean, _ = diag_lib.conv3x3_relu_timed(x, fwd, C, b, out, iters)
     return mean * 1e3
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build liblarva_hip.so with extra -D options into tools/_diag/<name>.so for same-box A/B timing:
-#   tools/build_variant.sh aux_late -DLARVA_AUX_EARLY=0
-#   LARVA_HIP_LIB=tools/_diag/aux_late.so python bench.py ...
+#   tools/build_variant.sh nodiag -DLARVA_DIAG=16
+#   LARVA_HIP_LIB=tools/_diag/nodiag.so python bench.py ...
 set -euo pipefail
 cd "$(dirname "$0")/.."
 name=$1; shift

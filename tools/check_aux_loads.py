@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The conv kernel's loader-wave path issues its epilogue operands (mask / residuals / base / truth / sign bits) as the
 YOUNGEST vector loads of an MFMA wave's prologue and every counted wait of the LDS-DMA ring leaves `kAuxLoads` of them
-in flight (run_role, LARVA_AUX_LATE).  That count is a compile-time product; the loads are the compiler's.  If it
+in flight (run_role, kAuxLate).  That count is a compile-time product; the loads are the compiler's.  If it
 emitted FEWER vector loads than counted, `s_waitcnt vmcnt(NPW + kAuxLoads)` could pass with a piece of chunk 0 still
 in flight.  This script reads the device assembly (hipcc -S) and, for every ring wait of every kernel, counts the
 global loads between the last LDS-DMA piece in front of it and the wait:
@@ -11,6 +11,8 @@ global loads between the last LDS-DMA piece in front of it and the wait:
 
   hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -o /tmp/conv.s larvanet_amd/csrc/conv3x3_mfma.hip
   python tools/check_aux_loads.py /tmp/conv.s
+larvanet_amd/build.py runs it on the device assembly of every build of conv3x3_mfma.hip (-save-temps) and fails the
+build on a mismatch (exit status 1).
 """
 import re
 import sys
@@ -41,7 +43,8 @@ while i < len(lines):
             state["loads_since_dma"] += 1
         elif ln.startswith("s_waitcnt vmcnt(") and i + 1 < len(lines) and lines[i + 1].strip() == "s_barrier":
             n = int(re.search(r"vmcnt\((\d+)\)", ln).group(1))
-            rows[kernel].append((n, state["loads_since_dma"], state["dma_run"]))
+            if n > 0:   # (vmcnt(0) waits for everything: always safe -- the persistent loader's last hand-overs)
+                rows[kernel].append((n, state["loads_since_dma"], state["dma_run"]))
             state["dma_run"] = 0
         elif ln.startswith(".Lfunc_end"):
             kernel, state = None, None

@@ -37,7 +37,7 @@ def build():
     for v in only:
         so = os.path.join(OUT, "libconv_diag%d%s.so" % (v, TAG))
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLARVA_DIAG=%d" % v,
-               "-DLARVA_DIAG_ONLY48=1"] + EXTRA + [SRC, "-o", so]
+               "-DLARVA_DIAG_ONLY48=1", "-DLARVA_DIAG_API=1"] + EXTRA + [SRC, "-o", so]
         procs.append(subprocess.Popen(cmd))
     for p in procs:
         assert p.wait() == 0
@@ -59,7 +59,9 @@ def main():
     out = torch.empty_like(x)
     out_hr = torch.empty_like(base)
     import ctypes as ct
-    sig = hip_lib.SIGNATURES["larva_conv3x3_fwd_timed"]
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import diag_lib
+    sig = diag_lib.SIGNATURES["larva_conv3x3_fwd_timed"]
     stream = torch.cuda.current_stream().cuda_stream
     epis = {"relu": dict(relu=1), "res1": dict(res0=r0), "res2": dict(res0=r0, res1=r1), "mask": dict(mask=r0),
             "shuffle+base": dict(mode=1, base=base)}

@@ -93,14 +93,14 @@ def main():
     wslot = [0]
 
     def d_conv(srcs, wpk, cout, **kw):
-        epi = "+".join(k for k in ("relu", "mask", "maskbits", "res0", "res1", "shuffle", "base") if kw.get(k) is not None and kw.get(k) is not False) or "plain"
+        epi = "+".join(k for k in ("relu", "mask", "res0", "res1", "shuffle", "base") if kw.get(k) is not None and kw.get(k) is not False) or "plain"
         first = srcs if isinstance(srcs, torch.Tensor) else srcs[0]
         nsrc = 1 if isinstance(srcs, torch.Tensor) else len(srcs)
         return "%s%s images=%s %s" % ("strips " if kw.get("strips") else "wide ", epi, kw.get("images"), "K=%d" % (nsrc * int(first.shape[1])))
 
     saved = [("conv3x3", wrap("conv3x3", d_conv)),
              ("conv3x3_batch", wrap("conv3x3_batch", lambda jobs, cout, **kw: "batch x%d %s" % (len(jobs), "+".join(
-                 k for k in ("relu", "shuffle") if kw.get(k)) + ("+mask" if jobs[0].get("mask") is not None or jobs[0].get("maskbits") is not None else "")))),
+                 k for k in ("relu", "shuffle") if kw.get(k)) + ("+mask" if jobs[0].get("mask") is not None else "")))),
              ("conv3x3_exit_l1_batch", wrap("conv3x3_exit_l1_batch", lambda jobs, *a, **kw: "exits x%d shuffle+base+L1" % len(jobs))),
              ("conv3x3_wgrad_partial_flat", wrap("conv3x3_wgrad_partial_flat",
                                                  lambda jobs, cout, cin, nwg, head=None: "flat wgrad %d layers%s on %d workgroups" % (len(jobs), " + head" if head is not None else "", nwg), wgrad=True))]

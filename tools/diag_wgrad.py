@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "_diag")
 SRC = os.path.join(ROOT, "larvanet_amd", "csrc", "wgrad3x3_mfma.hip")
-LAGS = {1000: ("full, LAG 10", 0, 10), 1001: ("full, LAG 3", 0, 3), 1002: ("full, LAG 15", 0, 15)}
+LAGS = {}   # (the load -> LDS-write distance was a build switch until round 5: 3 / 10 / 15 k-steps measured no better than 6)
 VARIANTS = {0: "full kernel", 1: "no MFMA", 2: "no staging", 4: "no operand reads", 8: "no bias sums",
             16: "no LDS writes", 32: "no address math", 64: "no global loads", 96: "no addr, no loads",
             144: "loads waited, no write", 3: "noMFMA no staging", 5: "noMFMA no reads", 17: "noMFMA no LDS writes",

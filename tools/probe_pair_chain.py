@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Round 5: both half-batch conv3x3 + ReLU chains in ONE launch, the two strip tiles of a CU owned by
 ONE 640-thread workgroup (conv3x3_pair_chain_kernel, csrc/conv3x3_pair_chain.inc; a measurement kernel that exists only
-in the -DLARVA_DIAG_API build: tools/build_variant.sh diag -DLARVA_DIAG_API=1).
+in the measurement library: tools/build_diag.sh diag; tools/larva_diag.h).
 
 Checked bit for bit against the same chains as 2 x `layers` strip launches, then timed like bench.py's `roofline` block
 (captured graph, replay / layers) beside bench.py's own two-chain figure in the same process.  Gate (VERDICT): <= 12.0 us per
 full-batch layer on the 40-link chain.
-usage: LARVA_HIP_LIB=tools/_diag/diag.so probe_pair_chain.py [layers=40]
+usage: probe_pair_chain.py [layers=40]
 env:   PAIR_LOCK="0,2,3,4" (phase locks to try, in chunks), PAIR_PRIO="1:1,..." (compute-wave priorities A:B), PAIR_NAPS"""
 import ctypes
 import os
@@ -18,15 +18,13 @@ import numpy as np
 import torch
 import bench
 from larvanet_amd import hip_lib, kernels as K
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import diag_lib
 
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda", 0)
 C, B, P = bench.CH, bench.BATCH, bench.PATCH
-lib = hip_lib.load()
-fn = lib.larva_conv3x3_pair_chain_probe   # AttributeError: not a -DLARVA_DIAG_API build
-fn.restype = ctypes.c_int
-fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p,
-                                                                                    ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+fn = diag_lib.load().larva_conv3x3_pair_chain_probe
 x0, wpk, b, bufs, rms = bench.chain_operands(dev, C, layers, False)
 half = B // 2
 parts = ((0, half), (half, B))

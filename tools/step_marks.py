@@ -24,7 +24,9 @@ def measure(every=False, link_marks=(0, 8, 16, 24)):
     import numpy as np
     import torch
     from larvanet_amd import autograd as A, hip_lib, kernels as K
-    lib = hip_lib.load()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import diag_lib   # (larva_stamp_clock is a measurement entry point: tools/build_diag.sh, tools/larva_diag.h)
+    lib = diag_lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator().manual_seed(1)
     x = (torch.rand(16, 3, 48, 48, generator=g) * 255).to(dev)
