@@ -709,7 +709,62 @@ def full_image_block(dev):
         out[key] = {"ms_per_image": ms, "value": out["hr_pixels"] / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s", "flop": flop,
                     "frac_of_peak": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         del m
+    out["roofline"] = full_image_layer_block(dev)
     return out
+
+
+def full_image_layer_block(dev, c=CH):
+    """The dominant kernel of the full-image forward the way `roofline` names the training step's: one 48 -> 48 conv3x3 of the
+    339 x 510 image (pitch 512) -- what validate.py's forward issues 34 times per image -- as a captured graph of 20
+    dependent launches, per epilogue, on the persistent tiles the library picks for it and (LARVA_PERSIST=0) as one
+    workgroup per tile.  Algorithmic work 2 * 9 * c * c FLOP per LR pixel."""
+    import torch
+    from larvanet_amd import kernels as K
+    H, W = FULL_IMAGE[1], FULL_IMAGE[2]
+    P = (W + 3) // 4 * 4
+    g = torch.Generator().manual_seed(0)
+    x = torch.zeros(1, c, H, P, device=dev)
+    x[..., :W] = (torch.randn(1, c, H, W, generator=g) * 20).to(dev)
+    r0, r1 = x.flip(1).contiguous(), x.flip(2).contiguous()
+    w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.zeros(c, device=dev)
+    fwd, _ = K.pack_weights(w)
+    bufs = [torch.empty_like(x) for _ in range(2)]
+    flop = 2 * 9 * c * c * H * W
+    kinds = {"relu": dict(relu=True), "res1": dict(res0=r0), "res2": dict(res0=r0, res1=r1)}
+    res = {}
+    keep = os.environ.get("LARVA_PERSIST")
+    try:
+        for mode, tag in (("1", "persistent"), ("0", "one_workgroup_per_tile")):
+            os.environ["LARVA_PERSIST"] = mode
+            res[tag] = {}
+            for name, kw in kinds.items():
+                def chain():
+                    src = x
+                    for i in range(20):
+                        K.conv3x3(src, fwd, c, bias=b, out=bufs[i & 1], logical_w=W, tile_rows=3, **kw)
+                        src = bufs[i & 1]
+                chain()
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    chain()
+                us = replay_ms(graph, 10) * 1e3 / 20
+                res[tag][name] = {"us_per_layer": us, "frac": flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    finally:
+        if keep is None:
+            os.environ.pop("LARVA_PERSIST", None)
+        else:
+            os.environ["LARVA_PERSIST"] = keep
+    tiles = ((H + 2) // 3) * ((P + 47) // 48)
+    best = res["persistent"]["relu"]
+    return {"bound": "mfma", "achieved": best["frac"] * FP32_MFMA_PEAK_TFLOPS, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": best["frac"], "traffic": None,
+            "kernel": "conv3x3_mfma_persist_kernel<%d, 1> (fused conv3x3+bias+ReLU on a 1 x %d x %d x %d image: %d tiles of 3 x 48 "
+                      "pixels walked by 512 persistent workgroups)" % (c, c, H, W, tiles),
+            "flop_per_launch": flop, "avg_us": best["us_per_layer"], "by_epilogue": res,
+            "timing": "HIP event pairs around 10 replays of a captured graph of 20 dependent launches (median of 3)",
+            "profile": "profiles/r05_infer_LarvaNet_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/infer_full_image.py)"}
 
 
 class GpuFault(Exception):
