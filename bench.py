@@ -65,8 +65,8 @@ FULL_IMAGE = (3, 339, 510)                               # DIV2K-val-like LR ima
 # itself); they are READ from the CSVs under profiles/ at run time -- a tile change that is not followed by new PMC
 # passes shows as a stale file name here, not as a silently wrong constant.  FETCH_SIZE is doubled per the guide's
 # gfx950 correction for 16-byte-per-lane streams; both counters are in KB.
-PMC_CONV_CSV = "profiles/r04_pmc_conv.csv"      # tools/profile_r04.sh: passes over `bench.py --roofline-only`
-PMC_WGRAD_CSV = "profiles/r04_pmc_wgrad.csv"    # passes over `bench.py --wgrad-only` (flat grid over 40 layers + reduction)
+PMC_CONV_CSV = "profiles/r05_pmc_conv.csv"      # tools/profile_r04.sh: passes over `bench.py --roofline-only`
+PMC_WGRAD_CSV = "profiles/r05_pmc_wgrad.csv"    # passes over `bench.py --wgrad-only` (flat grid over 40 layers + reduction)
 PMC_WGRAD_LAYERS = 40
 
 

@@ -605,30 +605,53 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiShuffleBase)
                            ? 1 : ((EPI == kEpiRes2 || EPI == kEpiShuffleL1) ? 2 : 0);
   f32x4 aux[NAUX > 0 ? NAUX : 1][NAUX > 0 ? NCT : 1][NAUX > 0 ? NPG : 1];
-  // part >= 0: only the units u = c * NPG + p with u % 4 == part (PERSIST: a tile's operands are requested a quarter at a
-  // time in front of its first four K chunks -- as one burst at the tile's start, on every CU at once, they stood in the
-  // memory pipeline in front of the loader wave's next chunks: +14 us per layer with two residual operands; the last
-  // quarter still has the rest of the K loop to arrive)
+  // PERSIST: a tile's operands are requested a quarter at a time in front of its first four K chunks (part = 0..3: the
+  // (operand, unit) pairs q = op * NU + u with q % 4 == part) -- as one burst at the tile's start, on every CU at once,
+  // they stood in the memory pipeline in front of the loader wave's next chunks: +14 us per layer with two residual
+  // operands; the last quarter still has the rest of the K loop to arrive.  And only the first kEarlyPairs pairs (28
+  // registers) are requested under the K loop at all; the rest (part = kLatePart) at the head of the epilogue, into the
+  // registers the MFMA operands have just left.  Round 5: a 5-wave workgroup puts waves 0 and 4 on the same SIMD, two
+  // workgroups per CU are FOUR waves on that SIMD = at most 128 VGPRs, and the two-residual kernel held 147 (64
+  // channels: 141 with one residual, 190 with two): the second workgroup of every CU entered only when the first had
+  // left (in-kernel stamps, profiles/r05_infer_wide_layer_stamps.txt: 256 of 512 workgroups enter 28-46 us late).  Capped
+  // by the compiler instead (launch bounds) it spills 32 registers and the layer takes 78 against 70 us.
+  constexpr int NU = NCT * NPG;
+  // (48 channels only: at 32 every variant is below 128 anyway, at 64 one workgroup per CU already keeps the matrix pipe
+  // as busy as two -- residual layers 110-113 us against 107 for conv + ReLU -- and late operands would stand exposed)
+  constexpr int kEarlyPairs = PERSIST && COUT == 48 ? (NAUX * NU < 7 ? NAUX * NU : 7) : NAUX * NU;
+  constexpr int kLatePart = 4;
   auto load_aux = [&](int part = -1) {
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
       for (int p = 0; p < NPG; ++p) {
-        if (part >= 0 && (c * NPG + p) % 4 != part) continue;   // (wave-uniform)
         const int pg = PG0 + p, prow = pg / G::PC, pcol = pg % G::PC;
         const int y = min(y0 + prow, a.H - 1), x = min(x0 + pcol * 16 + lr, a.W - 1);
+        // does this call request operand `op` of unit (c, p)?   (wave-uniform, constant after unrolling)
+        auto want = [&](int op) {
+          const int q = op * NU + c * NPG + p;
+          return part < 0 ? true : part == kLatePart ? q >= kEarlyPairs : (q < kEarlyPairs && q % 4 == part);
+        };
         if constexpr (kShuffleEpi) {
           const int HH = 4 * a.H, WW = 4 * a.W;
           const size_t idx = (((size_t)n * C::CT + (ct0 + c)) * HH + (4 * y + lq)) * WW + 4 * x;
-          aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.base + idx);
-          if constexpr (EPI == kEpiShuffleL1) aux[1][c][p] = *reinterpret_cast<const f32x4*>(a.truth + idx);
+          if (want(0)) aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.base + idx);
+          if constexpr (EPI == kEpiShuffleL1) {
+            if (want(1)) aux[1][c][p] = *reinterpret_cast<const f32x4*>(a.truth + idx);
+          }
         } else if constexpr (kPixMajor) {
           const size_t plane = (size_t)a.H * a.pitch;
           const int xb = min(x0 + pcol * 16 + lq * 4, a.pitch - 4);   // (pitch % 4 == 0 on this path)
           const size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * a.pitch + xb;
-          if constexpr (EPI == kEpiMask) aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.mask + idx);
-          if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.res0 + idx);
-          if constexpr (EPI == kEpiRes2) aux[1][c][p] = *reinterpret_cast<const f32x4*>(a.res1 + idx);
+          if constexpr (EPI == kEpiMask) {
+            if (want(0)) aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.mask + idx);
+          }
+          if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) {
+            if (want(0)) aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.res0 + idx);
+          }
+          if constexpr (EPI == kEpiRes2) {
+            if (want(1)) aux[1][c][p] = *reinterpret_cast<const f32x4*>(a.res1 + idx);
+          }
         } else {
           const size_t plane = (size_t)a.H * a.pitch;
           const size_t idx0 = ((size_t)n * COUT + (ct0 + c) * 16 + lq * 4) * plane + (size_t)y * a.pitch + x;
@@ -695,6 +718,10 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kEarlyPairs < NAUX * NU) {
+      load_aux(kLatePart);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   } else if constexpr (VEC) {
     // ---- LDS-DMA ring: chunk c lives in stage c % 3; chunks c+1 and c+2 are in flight --------
     // Prologue: the weight pieces of chunk 0 go out first (their offsets need no arithmetic), then bias (and the
@@ -1039,6 +1066,7 @@ template <int COUT, int EPI>
 __global__ __launch_bounds__((ConvCfg<COUT>::THREADS_DMA), kWgPerCu) void conv3x3_mfma_persist_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using G = GeoWide;
+  stamp(0);
   fetch_args(a);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

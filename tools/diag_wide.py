@@ -42,6 +42,27 @@ def launch():
     hip_lib.check(code, "larva_conv3x3_fwd_pitched")
 
 
+os.environ["LARVA_PERSIST"] = "1"
+for _ in range(3):
+    launch()
+torch.cuda.synchronize()
+assert lib.larva_diag_set_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
+for _ in range(3):
+    launch()
+torch.cuda.synchronize()
+t = stamps.cpu().numpy().reshape(tiles, 16).astype(np.float64) / 100.0
+t = t[t[:, 0] > 0]
+t0 = t[:, 0].min()
+end = t[:, 5] - t0
+print("persistent tiles (the product's launch for this shape), conv3x3 48 -> 48 + %s on 1 x 48 x %d x %d: %d workgroups walk %d tiles; span %.1f us = "
+      "%.3f of the fp32 matrix peak; workgroups enter within %.2f us; their last store drains at p10 %.1f / median %.1f / p90 %.1f / max %.1f us"
+      % (kind, H, W, len(t), tiles, end.max(), 2 * 9 * 48 * 48 * H * W / (end.max() * 1e-6) / 157.3e12, (t[:, 0] - t0).max(),
+         np.percentile(end, 10), np.median(end), np.percentile(end, 90), end.max()))
+late = np.sort(t[:, 0] - t0)
+print("   entries: %d within 1 us, %d later (at %s us)" % (np.sum(late < 1.0), np.sum(late >= 1.0), " ".join("%.0f" % v for v in late[late >= 1.0][::16])))
+stamps.zero_()
+torch.cuda.synchronize()
+os.environ["LARVA_PERSIST"] = "0"   # below: one workgroup per tile (the launch of rounds 1-4), every tile's own timeline
 for _ in range(3):
     launch()
 torch.cuda.synchronize()
@@ -54,7 +75,7 @@ t0 = t[:, 0].min()
 ent, issued, landed, kdone, stored, drained = (t[:, i] - t0 for i in (0, 1, 2, 3, 4, 5))
 span = drained.max()
 flop = 2 * 9 * 48 * 48 * H * W
-print("conv3x3 48 -> 48 + %s on 1 x 48 x %d x %d (pitch %d): %d workgroups of 3 x 48 pixels, launch span %.1f us = %.3f of the fp32 matrix peak"
+print("one workgroup per tile (LARVA_PERSIST=0): conv3x3 48 -> 48 + %s on 1 x 48 x %d x %d (pitch %d): %d workgroups of 3 x 48 pixels, launch span %.1f us = %.3f of the fp32 matrix peak"
       % (kind, H, W, P, tiles, span, flop / (span * 1e-6) / 157.3e12))
 life = drained - ent
 print("workgroup life (entry -> stores drained): p10 %.1f / median %.1f / p90 %.1f us; entry -> first chunk landed %.2f | K loop %.2f | stores issued %.2f | "

@@ -2,7 +2,7 @@
 # Matrix-pipe occupancy and clock of the (32, 32) flat weight-gradient launch: one rocprofv3 counter pass.
 set -euo pipefail
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r04_pmc_c32
 mkdir -p $O
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -- python3 $R/tools/bench_wgrad_widths.py 32 64 > $O/mfma.log 2>&1

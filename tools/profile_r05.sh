@@ -50,3 +50,10 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
 done
 cd $R
 python tools/pmc_summary.py gpurun_out/r05_prof/pmc_infer.csv fetch=$O/infer_pmc1 write=$O/infer_pmc2 mfma=$O/infer_pmc3
+rm -rf $O/infer_LarvaNet $O/infer_LarvaNetV2 $O/infer_pmc1 $O/infer_pmc2 $O/infer_pmc3
+# one stamped full-image layer per epilogue (tools/_diag/libconv_diag32.so = -DLARVA_DIAG=32, built in the build container)
+if [ -f tools/_diag/libconv_diag32.so ]; then
+  for e in relu res1 res2; do python tools/diag_wide.py $e >> $O/infer_wide_layer_stamps.txt 2>&1 || echo "diag_wide $e failed"; done
+fi
+python tools/bench_wide_layer.py > $O/ab_persist.txt 2>&1 || echo "bench_wide_layer failed"
+ls -la $O
