@@ -65,8 +65,9 @@ FULL_IMAGE = (3, 339, 510)                               # DIV2K-val-like LR ima
 # itself); they are READ from the CSVs under profiles/ at run time -- a tile change that is not followed by new PMC
 # passes shows as a stale file name here, not as a silently wrong constant.  FETCH_SIZE is doubled per the guide's
 # gfx950 correction for 16-byte-per-lane streams; both counters are in KB.
-PMC_CONV_CSV = "profiles/r05_pmc_conv.csv"      # tools/profile_r04.sh: passes over `bench.py --roofline-only`
+PMC_CONV_CSV = "profiles/r05_pmc_conv.csv"      # tools/profile_r05.sh: passes over `bench.py --roofline-only`
 PMC_WGRAD_CSV = "profiles/r05_pmc_wgrad.csv"    # passes over `bench.py --wgrad-only` (flat grid over 40 layers + reduction)
+PMC_INFER_CSV = "profiles/r05_pmc_infer.csv"    # passes over tools/infer_full_image.py (the persistent full-image launches)
 PMC_WGRAD_LAYERS = 40
 
 
@@ -759,7 +760,10 @@ def full_image_layer_block(dev, c=CH):
     tiles = ((H + 2) // 3) * ((P + 47) // 48)
     best = res["persistent"]["relu"]
     return {"bound": "mfma", "achieved": best["frac"] * FP32_MFMA_PEAK_TFLOPS, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": best["frac"], "traffic": None,
+            "frac": best["frac"],
+            "traffic": hbm_traffic_bytes(PMC_INFER_CSV, "conv3x3_mfma_persist_kernel<48, 1>") if c == 48 else None,
+            "traffic_source": TRAFFIC_NOTE % PMC_INFER_CSV,
+            "algorithmic_bytes": 2 * 4 * c * H * W,
             "kernel": "conv3x3_mfma_persist_kernel<%d, 1> (fused conv3x3+bias+ReLU on a 1 x %d x %d x %d image: %d tiles of 3 x 48 "
                       "pixels walked by 512 persistent workgroups)" % (c, c, H, W, tiles),
             "flop_per_launch": flop, "avg_us": best["us_per_layer"], "by_epilogue": res,
