@@ -55,6 +55,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // padding costs no address select and no zero page.  Nothing here is per-lane arithmetic: the wave
 // issues 3 scalar moves and the load.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kDmaZero = 0x80000000u;
 
 __device__ __forceinline__ i32x4 dma_rsrc(const void* base) {

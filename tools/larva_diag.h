@@ -37,6 +37,48 @@ int larva_conv3x3_pair_chain_probe(float* buf0, float* buf1, const float* wpk, c
                                    int tiles_per_image, unsigned* state, int* xcc_out, unsigned long long* trace, int layers,
                                    int lock, int naps, int prio_a, int prio_b, void* stream);
 
+/* ---- layer pipeline (round 5 experiment; csrc/conv3x3_pipe.inc) -------------------------------
+ * A CHAIN of 48 -> 48 convolutions over one [N][48][H][pitch] tensor shape in ONE launch: the body of a full-image
+ * forward, LarvaNetModule.forward's `for i in range(self.len): fea = body_i(fea)` + the first conv of the last leg
+ * (models/LarvaNet.py:205-220,236-248,256-257,283-293) as validate.py:94-102 / runtime.py call it.  Persistent workgroups walk
+ * the (layer, tile) positions in order; a tile of layer i waits until the three tile rows around it of layer dep are
+ * stored and visible (per-row counters, agent scope), so the layers overlap where the per-layer launches each paid a
+ * launch boundary, a cold start and a tail.  Results are bit-identical to
+ * larva_conv3x3_fwd_pitched layer by layer.
+ *
+ * Every layer writes a tensor of its OWN (nothing the launch still reads is overwritten).  dep: the layer whose output
+ * this layer's src is, -1 when src was written before the launch; every other operand written inside the launch
+ * (res0, res1, further src tensors) must be the output of dep or of a layer dep depends on.  relu / res0 / res1 as
+ * larva_conv3x3_fwd (relu with residuals: unsupported).  16-byte path only (pitch % 4 == 0, aligned tensors):
+ * hipErrorNotSupported otherwise.
+ *
+ * larva_conv3x3_pipeline_plan validates, writes the device-side layer table into `workspace`
+ * (larva_conv3x3_pipeline_workspace_bytes(), 256-byte aligned; a SYNCHRONOUS copy: call it outside captured regions)
+ * and fills `plan` (host memory, larva_conv3x3_pipeline_plan_bytes()).  larva_conv3x3_pipeline_run issues one memset
+ * node (the counters) and the launch: stream-ordered, allocation-free, capturable.  error_word: one device-accessible
+ * word (pinned host memory works), zeroed by the caller; every wait inside the kernel is bounded (spin_limit polls,
+ * 0 = about two seconds) and a wait that expires sets the word to 1 and lets the launch drain -- its outputs are then
+ * garbage and the caller must refuse them.
+ * MEASURED AND NOT ADOPTED (profiles/r05_layer_pipeline.txt): bit-identical on every case of
+ * tests/test_hip_kernels.py, but 72.7 us per layer against 62.8 for one persistent launch per layer; with every wait,
+ * signal and coherent access switched off it is 63.2 -- the per-layer launches already run at the K loop's ceiling at the
+ * clock the chip sustains (2.2-2.25 GHz), there is no launch-boundary time left to win. */
+typedef struct larva_pipe_layer {
+  const float* src[8];
+  int n_src, cin_per_src;
+  const float* wpk;
+  const float* bias;
+  const float* res0;
+  const float* res1;
+  float* out;
+  int relu, dep;
+} larva_pipe_layer;
+long long larva_conv3x3_pipeline_workspace_bytes(int n_layers, int N, int H);
+long long larva_conv3x3_pipeline_plan_bytes(void);
+int larva_conv3x3_pipeline_plan(const void* layers /* larva_pipe_layer[n_layers] */, int n_layers, int N, int cout, int H,
+                                int W, int pitch, void* workspace, unsigned* error_word, void* plan);
+int larva_conv3x3_pipeline_run(const void* plan, int spin_limit, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
