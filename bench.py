@@ -1118,6 +1118,31 @@ def main():
                     "what": "SURVEY 8(d): forward 40 C->C convs + head, backward dgrad + wgrad per C->C conv + the head's wgrad "
                             "(elementwise work excluded) over the timed ms_per_step of one rank"}
 
+    # The clock the chip sustains under this load (the guide's 157.3 TFLOP/s is 2.4 GHz): one napping wave on a side stream
+    # counts shader cycles against the 100 MHz wall clock while 40 more steps run (measurement library; untimed).
+    if world == 1 and not a.no_extras:
+        D = diag_lib()
+        if D is not None:
+            try:
+                side = torch.cuda.Stream()
+                cells = torch.zeros(2, dtype=torch.int64, device=dev)
+                for _ in range(5):
+                    model.train_step_larva(args, val, x, truth)
+                with torch.cuda.stream(side):
+                    hip_check = D.load().larva_clock_probe(3000000, cells.data_ptr(), side.cuda_stream)   # 30 ms
+                for _ in range(40):
+                    model.train_step_larva(args, val, x, truth)
+                torch.cuda.synchronize()
+                ticks, cycles = (int(v) for v in cells.tolist())
+                if hip_check == 0 and ticks > 0:
+                    ghz = cycles / ticks * 0.1
+                    line["step"]["sustained_clock_ghz"] = ghz
+                    line["step"]["frac_of_peak_at_sustained_clock"] = line["step"]["frac_of_peak"] * 2.4 / ghz
+                    line["step"]["sustained_clock_is"] = ("s_memtime cycles / s_memrealtime ticks of one napping wave beside 30 ms of the "
+                                                          "timed loop (larva_clock_probe, measurement library); the guide's peak is quoted at 2.4 GHz")
+            except Exception as e:   # an extra: never costs the line
+                line["step"]["sustained_clock_error"] = "%s: %s" % (type(e).__name__, e)
+
     # the REQUIRED blocks first (inference forward, `roofline`, the isolated weight-gradient pair): a fault inside a later
     # extra then cannot cost the line its roofline
     with torch.no_grad():

@@ -842,6 +842,31 @@ int larva_delay_ticks(int ticks, void* stream) {
   hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
   return (int)hipGetLastError();
 }
+
+// Measurement only: the shader clock WHILE something else runs.  One wave naps until the 100 MHz wall clock has advanced
+// by `ticks` (bounded: at most 1 << 20 naps) and stores {wall ticks, shader cycles (s_memtime)} it saw go by: launched on
+// a side stream beside the replays of the captured step, cycles / ticks * 100 MHz is the clock the chip sustains under
+// that load (bench.py `step.sustained_clock_ghz`; the guide's peaks are quoted at 2.4 GHz).
+__global__ void clock_probe_kernel(int ticks, unsigned long long* out) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  for (int i = 0; i < (1 << 20); ++i) {
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if ((long long)(r1 - r0) >= (long long)ticks) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    out[0] = r1 - r0;
+    out[1] = c1 - c0;
+  }
+}
+
+int larva_clock_probe(int ticks, unsigned long long* out, void* stream) {
+  if (!out || ticks <= 0 || ticks > 10000000) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks, out);
+  return (int)hipGetLastError();
+}
 #endif
 
 // out[0] = (sum of n <= 8 device scalars, added in index order) / divisor.

@@ -18,6 +18,7 @@ SIGNATURES = {
     "larva_conv3x3_fwd_strips_timed": (_i, [_pp, _i, _i] + [_p] * 7 + [_i] * 7 + [_p, ctypes.POINTER(ctypes.c_uint), _i, _i, _p, _i, _f, _f]),
     "larva_stamp_clock": (_i, [_p, _p]),
     "larva_delay_ticks": (_i, [_i, _p]),
+    "larva_clock_probe": (_i, [_i, _p, _p]),
     "larva_conv3x3_pair_chain_probe": (_i, [_p] * 4 + [_i] * 4 + [_p] * 4 + [_i, _p, _p, _p] + [_i] * 5 + [_p]),
     "larva_conv3x3_pipeline_workspace_bytes": (ctypes.c_longlong, [_i, _i, _i]),
     "larva_conv3x3_pipeline_plan_bytes": (ctypes.c_longlong, []),

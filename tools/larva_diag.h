@@ -29,6 +29,11 @@ int larva_stamp_clock(unsigned long long* dst, void* stream);
 /* A one-wave launch that sleeps until the 100 MHz wall clock has advanced by `ticks` (<= 100000; bounded), in stream
  * order: a tunable delay in front of one chain of a captured two-chain graph (tools/ab_stagger.sh). */
 int larva_delay_ticks(int ticks, void* stream);
+
+/* One wave that naps for `ticks` of the 100 MHz wall clock and stores out[0] = wall ticks, out[1] = shader cycles
+ * (s_memtime) that went by: beside another stream's work, out[1] / out[0] * 0.1 = the clock in GHz the chip sustains
+ * under that load (bench.py `step.sustained_clock_ghz`). */
+int larva_clock_probe(int ticks, unsigned long long* out, void* stream);
 /* Round 5: both half-batch conv3x3 + ReLU chains of `layers` layers in ONE launch, the two strip tiles of a CU owned by
  * one 704-thread workgroup (csrc/conv3x3_pair_chain.inc has the protocol; tools/probe_pair_chain.py drives it;
  * profiles/r05_probe_pair_chain.txt has the result: 13.1-13.4 us per layer against 14.2-14.35 as launches, gate 12.0). */
