@@ -1297,3 +1297,22 @@ def test_layer_pipeline_refuses_what_it_cannot_order(hip_device):
                 [dict(srcs=[x], wpk=fwd, out=a, dep=0)]):                              # dep is not an earlier layer
         with pytest.raises(RuntimeError, match="hip error 1"):
             D.ConvPipeline(bad)
+
+
+def test_pair_chain_probe_equals_the_strip_launches_bit_for_bit(hip_device):
+    """The round-5 one-launch chain (both half-batch chains in one launch, LDS flags inside a workgroup, per-tile inboxes
+    between workgroups: csrc/conv3x3_pair_chain.inc, measurement library only) run through its own tool on a short chain:
+    identical to the 2 x layers strip launches bit for bit, no bounded wait expired, with and without the phase lock."""
+    import os
+    import subprocess
+    import sys
+    _diag_lib_or_skip()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PAIR_LOCK="0,3")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "probe_pair_chain.py"), "6"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("one launch vs")]
+    assert len(lines) == 2, res.stdout[-2000:]
+    for l in lines:
+        assert "bit-identical True" in l and "gave up waiting: 0" in l, l
