@@ -69,7 +69,8 @@ __device__ __forceinline__ i32x4 dma_rsrc(const void* base) {
 }
 
 // SC1: the load bypasses this CU's vector L1 (served by the XCD's L2) -- for bytes another workgroup of the SAME launch
-// has just written (tools/probe_chain_kernel.py); every other caller reads what an earlier launch wrote.
+// has just written (the pair-chain and layer-pipeline measurement kernels; across XCDs: conv3x3_pipe.inc); every other caller
+// reads what an earlier launch wrote.
 template <bool SC1 = false>
 __device__ __forceinline__ void lds_dma16_buf(i32x4 rsrc, unsigned voff, int soff_uniform, unsigned lds_addr_uniform) {
   unsigned keep;

@@ -828,7 +828,7 @@ int larva_stamp_clock(unsigned long long* dst, void* stream) {
 
 // Measurement only: one wave that sleeps until the 100 MHz wall clock has advanced by `ticks` (bounded: at most 4096
 // naps of 64 clocks), in stream order -- a capturable, tunable delay in front of one chain of a two-chain graph
-// (tools/ab_stagger.sh: how does the step depend on the phase the two chains start in?).
+// (profiles/r04_ab_stagger.txt: how does the step depend on the phase the two chains start in?).
 __global__ void delay_kernel(int ticks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < 4096; ++i) {

@@ -27,7 +27,7 @@ int larva_conv3x3_fwd_strips_timed(const float* const* src, int n_src, int cin_p
  * launches of a graph (tools/step_marks.py). */
 int larva_stamp_clock(unsigned long long* dst, void* stream);
 /* A one-wave launch that sleeps until the 100 MHz wall clock has advanced by `ticks` (<= 100000; bounded), in stream
- * order: a tunable delay in front of one chain of a captured two-chain graph (tools/ab_stagger.sh). */
+ * order: a tunable delay in front of one chain of a captured two-chain graph (profiles/r04_ab_stagger.txt; the script is in git history). */
 int larva_delay_ticks(int ticks, void* stream);
 
 /* One wave that naps for `ticks` of the 100 MHz wall clock and stores out[0] = wall ticks, out[1] = shader cycles
