@@ -704,12 +704,13 @@ class HeadFn(torch.autograd.Function):
     DIRECT_ABOVE_PIXELS = 100000
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pc, x16=None):
+    def forward(ctx, x, weight, bias, pc, x16=None, training=True):
+        """training: a backward may follow (the caller's view: inside forward() the grad mode is always off and
+        needs_input_grad reports the parameters' requires_grad even under no_grad)."""
         N, C, H, W = x.shape
         P = PaddedWidth.pitch_of(W) if _lw() is not None else W
         cout = int(weight.shape[0])
-        # a weight gradient will be asked for (needs_input_grad reports the parameters' requires_grad even under no_grad)
-        training = torch.is_grad_enabled() and bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        training = bool(training) and bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         want = HeadFn.direct if HeadFn.direct != "auto" else (not training and N * H * P > HeadFn.DIRECT_ABOVE_PIXELS)
         use_direct = want and C == 3 and cout % 16 == 0
         if x16 is not None:      # prepared by the step's prologue launch (step_prologue)
@@ -739,8 +740,8 @@ class HeadFn(torch.autograd.Function):
             DualChain.join()   # dy comes off the two dgrad chains and is read right here
         (dw, db), = _wgrad([(dy, x16, ctx.wshape, 0, cin, tw, tb)], cout, 16, inplace=tw is not None)
         if tw is not None:
-            return None, None, None, None, None
-        return None, dw, db, None, None
+            return None, None, None, None, None, None
+        return None, dw, db, None, None, None
 
 
 class BodyFn(torch.autograd.Function):

@@ -107,7 +107,7 @@ class LarvaHead(nn.Module):
         _require_hip(x)
         c = self.feature_extraction
         self._pc.refresh()
-        return HeadFn.apply(x.contiguous(), c.weight, c.bias, self._pc, x16)
+        return HeadFn.apply(x.contiguous(), c.weight, c.bias, self._pc, x16, torch.is_grad_enabled())
 
 
 class LarvaLeg(nn.Module):

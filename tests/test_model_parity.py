@@ -396,6 +396,37 @@ def test_forward_and_train_step_shape_fuzz_against_the_cpu_restatement(hip_devic
             assert np.abs(ga - gb).max() <= 2e-4 * max(np.abs(gb).max(), 1e-30), (case, name, blocks, k)
 
 
+def test_train_step_on_a_patch_larger_than_the_direct_head_threshold(hip_device):
+    """LarvaHead picks its direct K = 27 kernel for INFERENCE on more than 100 k LR pixels; a training step on that many
+    pixels (2 x 3 x 232 x 232) must keep the padded-MFMA launch and the padded input its weight gradient reads (inside an
+    autograd.Function the grad mode is always off: the flag comes from the module).  Loss and every gradient against
+    oracle/larva_torch.py; the same image through upscale() afterwards takes the direct kernel and matches too."""
+    from oracle import larva_torch as T
+    from larvanet_amd.autograd import HeadFn
+    blocks = [1]
+    m = _model("LarvaNet", ["--num_modules=1", "--num_blocks=1"], training=True, seed=7)
+    sd = {k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()}
+    rng = np.random.RandomState(77)
+    n, p = 2, 232
+    assert n * p * p > HeadFn.DIRECT_ABOVE_PIXELS
+    x = torch.from_numpy(rng.randint(0, 256, size=(n, 3, p, p)).astype(np.float32))
+    t = torch.from_numpy(rng.randint(0, 256, size=(n, 3, 4 * p, 4 * p)).astype(np.float32))
+    m.use_hip_graph = False
+    loss, _ = m._forward_backward(x.to(hip_device), t.to(hip_device))
+    torch.cuda.synchronize()
+    sd_req = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_loss = T.multi_exit_loss(sd_req, x, t, blocks)
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-5 * abs(float(ref_loss.detach()))
+    for k, prm in m.model.named_parameters():
+        ga, gb = prm.grad.cpu().numpy(), sd_req[k].grad.numpy()
+        assert np.abs(ga - gb).max() <= 2e-4 * max(np.abs(gb).max(), 1e-30), k
+    got = m.upscale([x[0].numpy(), x[1].numpy()], 4)
+    with torch.no_grad():
+        ref = T.forward(sd, x, blocks).numpy()
+    assert np.abs(got - ref).max() <= 2e-3
+
+
 @pytest.mark.parametrize("name,flags", [("LarvaNet", ["--num_modules=3", "--num_blocks=2,1,2"]),
                                         ("LarvaNetV2", ["--num_modules=2", "--num_blocks=1,2"])])
 def test_early_loss_capture_trains_exactly_like_the_single_graph(hip_device, name, flags):
