@@ -29,6 +29,8 @@ def model(name, argv, seed):
 rng = np.random.RandomState(99)
 cases = [(2, 52, 52), (4, 52, 52), (16, 24, 24), (3, 100, 100), (1, 200, 200), (2, 150, 150), (5, 64, 64), (8, 96, 96), (2, 48, 130), (3, 61, 47),
          (7, 33, 58), (16, 48, 48)]
+if os.environ.get("FUZZ_CASES"):   # "n,h,w;n,h,w;..."
+    cases = [tuple(int(v) for v in c.split(",")) for c in os.environ["FUZZ_CASES"].split(";")]
 bad = 0
 for ci, (n, h, w) in enumerate(cases):
     for v2 in (False, True):
