@@ -825,6 +825,8 @@ class LarvaNet(BaseModel):
         return StepScope(defer_wgrad=False, joint_input_grads=False, dual_chain=self.dual_chain,
                          lazy_chain_joins=(True, False))
 
+    INFER_GRAPH_BELOW_PIXELS = 100000   # LR pixels per batch above which the inference forward is not captured (see _infer)
+
     def _infer(self, x):
         """self.model(x) without gradients.  A batch shape seen for the second time is captured into a
         hipGraph (launched one by one from Python the ~36 kernels of a 16 x 3 x 48 x 48 forward are
@@ -833,6 +835,11 @@ class LarvaNet(BaseModel):
         graph's output buffer: callers that keep it across calls copy it (upscale() moves it to the
         host anyway)."""
         if not (self.use_hip_graph and x.is_cuda) or torch.is_grad_enabled():
+            return self.model(x)
+        # A whole validation image is 36 launches of 60 us each: the host is ~2 ms ahead of the GPU after the first few,
+        # and eager launches have no replay boundary and no copy into a static input: 2.162 against 2.178 ms per
+        # 339 x 510 image (tools/infer_modes.py, round 5).  The capture pays where the launches are short.
+        if int(x.shape[0]) * int(x.shape[2]) * int(x.shape[3]) > self.INFER_GRAPH_BELOW_PIXELS:
             return self.model(x)
         cache = self.__dict__.setdefault("_infer_graphs", {})
         seen = self.__dict__.setdefault("_infer_seen", {})
