@@ -620,6 +620,8 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   // as busy as two -- residual layers 110-113 us against 107 for conv + ReLU -- and late operands would stand exposed)
   constexpr int kEarlyPairs = PERSIST && COUT == 48 ? (NAUX * NU < 7 ? NAUX * NU : 7) : NAUX * NU;
   constexpr int kLatePart = 4;
+  // (tried: `part` as a compile-time tag behind a switch, so that the units of the unrolled nest lose their scalar
+  // branches -- the four copies of the loads cost registers instead: 71 / 80 us per residual layer against 63 / 66)
   auto load_aux = [&](int part = -1) {
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
@@ -638,6 +640,32 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
           if (want(0)) aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.base + idx);
           if constexpr (EPI == kEpiShuffleL1) {
             if (want(1)) aux[1][c][p] = *reinterpret_cast<const f32x4*>(a.truth + idx);
+          }
+        } else if constexpr (kPixMajor && PERSIST) {
+          // Buffer loads: the lane's own offset is ONE VGPR for the whole launch, the unit's offset inside image n a
+          // wave-uniform scalar operand -- no vector address arithmetic in front of the K chunks: 63.3 -> 62.8 / 66.2 -> 65.4 us
+          // per residual layer of a full image, 10 / 3 VGPRs fewer.  (Such a layer takes ~2.5 us longer than conv + ReLU
+          // even with its operand HOT in L2, tools/probe_res_operand.py: issue slots of the MFMA waves, not memory.)  What a lane of an edge tile requests past the image
+          // comes back as zeros (the descriptor covers exactly the image's COUT planes) and is never used.
+          const unsigned plane = (unsigned)a.H * (unsigned)a.pitch;
+          const unsigned lane_off = 4u * ((unsigned)lr * plane + (unsigned)lq * 4u);
+          const int soff = __builtin_amdgcn_readfirstlane(
+              (int)(4u * ((unsigned)((ct0 + c) * 16) * plane + (unsigned)(y0 + prow) * (unsigned)a.pitch + (unsigned)(x0 + pcol * 16))));
+          auto image = [&](const float* t) {
+            const unsigned long long b = reinterpret_cast<unsigned long long>(t + (size_t)n * COUT * plane);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+            return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                     (int)(COUT * plane * 4u), 0x00020000);
+          };
+          if constexpr (EPI == kEpiMask) {
+            if (want(0)) aux[0][c][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(image(a.mask), lane_off, soff, 0));
+          }
+          if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) {
+            if (want(0)) aux[0][c][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(image(a.res0), lane_off, soff, 0));
+          }
+          if constexpr (EPI == kEpiRes2) {
+            if (want(1)) aux[1][c][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(image(a.res1), lane_off, soff, 0));
           }
         } else if constexpr (kPixMajor) {
           const size_t plane = (size_t)a.H * a.pitch;
