@@ -605,12 +605,9 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   constexpr int NAUX = (EPI == kEpiMask || EPI == kEpiRes1 || EPI == kEpiShuffleBase)
                            ? 1 : ((EPI == kEpiRes2 || EPI == kEpiShuffleL1) ? 2 : 0);
   f32x4 aux[NAUX > 0 ? NAUX : 1][NAUX > 0 ? NCT : 1][NAUX > 0 ? NPG : 1];
-  // PERSIST: a tile's operands are requested a quarter at a time in front of its first four K chunks (part = 0..3: the
-  // (operand, unit) pairs q = op * NU + u with q % 4 == part) -- as one burst at the tile's start, on every CU at once,
-  // they stood in the memory pipeline in front of the loader wave's next chunks: +14 us per layer with two residual
-  // operands; the last quarter still has the rest of the K loop to arrive.  And only the first kEarlyPairs pairs (28
-  // registers) are requested under the K loop at all; the rest (part = kLatePart) at the head of the epilogue, into the
-  // registers the MFMA operands have just left.  Round 5: a 5-wave workgroup puts waves 0 and 4 on the same SIMD, two
+  // PERSIST: a tile's operands are requested under its K loop, wave w's in front of chunk w (part = kEarlyAll; see the
+  // loop) -- but only the first kEarlyPairs (operand, unit) pairs q = op * NU + u (28 registers); the rest (part =
+  // kLatePart) at the head of the epilogue, into the registers the MFMA operands have just left.  Round 5: a 5-wave workgroup puts waves 0 and 4 on the same SIMD, two
   // workgroups per CU are FOUR waves on that SIMD = at most 128 VGPRs, and the two-residual kernel held 147 (64
   // channels: 141 with one residual, 190 with two): the second workgroup of every CU entered only when the first had
   // left (in-kernel stamps, profiles/r05_infer_wide_layer_stamps.txt: 256 of 512 workgroups enter 28-46 us late).  Capped
@@ -619,7 +616,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
   // (48 channels only: at 32 every variant is below 128 anyway, at 64 one workgroup per CU already keeps the matrix pipe
   // as busy as two -- residual layers 110-113 us against 107 for conv + ReLU -- and late operands would stand exposed)
   constexpr int kEarlyPairs = PERSIST && COUT == 48 ? (NAUX * NU < 7 ? NAUX * NU : 7) : NAUX * NU;
-  constexpr int kLatePart = 4;
+  constexpr int kLatePart = 4, kEarlyAll = 5;
   // (tried: `part` as a compile-time tag behind a switch, so that the units of the unrolled nest lose their scalar
   // branches -- the four copies of the loads cost registers instead: 71 / 80 us per residual layer against 63 / 66)
   auto load_aux = [&](int part = -1) {
@@ -632,7 +629,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
         // does this call request operand `op` of unit (c, p)?   (wave-uniform, constant after unrolling)
         auto want = [&](int op) {
           const int q = op * NU + c * NPG + p;
-          return part < 0 ? true : part == kLatePart ? q >= kEarlyPairs : (q < kEarlyPairs && q % 4 == part);
+          return part < 0 ? true : part == kLatePart ? q >= kEarlyPairs : q < kEarlyPairs;
         };
         if constexpr (kShuffleEpi) {
           const int HH = 4 * a.H, WW = 4 * a.W;
@@ -730,19 +727,22 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     // bias and the epilogue's operands of THIS tile have the K loop to arrive (the vmcnt(0) behind it also covers the
     // previous tile's stores, long drained)
     load_bias();
+    const int my_chunk = a.n_chunks >= 4 ? (wave & 3) : 0;
     __builtin_amdgcn_sched_barrier(0);
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
       asm volatile("s_barrier" ::: "memory");   // the loader has seen the chunk land; everybody is done with the stage before it
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (NAUX > 0) {
-        if (chunk < 4) load_aux(chunk);
+        // wave w requests its early operands in front of chunk w: the workgroup's operand traffic is spread over the first
+        // four chunks (as one burst at the tile's start, on every CU at once, it stood in the memory pipeline in front of
+        // the loader wave's next chunks: +14 us per layer with two residual operands), and a wave pays one uniform branch
+        // per chunk.  (Until late in round 5: a quarter of EVERY wave's units per chunk -- a scalar branch per unit in
+        // front of four chunks' first MFMAs: 62.8 against 61.2 us for a one-residual layer, same box.)
+        if (chunk == my_chunk) load_aux(kEarlyAll);
         __builtin_amdgcn_sched_barrier(0);
       }
       mfma_chunk<COUT, G, NCT, PG0, NPG, kPixMajor>(smem + pstage * C::STAGE_FLOATS, ct0, lane, acc);
       pstage = pstage == C::NST - 1 ? 0 : pstage + 1;
-    }
-    if constexpr (NAUX > 0) {
-      for (int part = a.n_chunks; part < 4; ++part) load_aux(part);   // (fewer than four chunks: the rest now)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
