@@ -638,8 +638,9 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
           if constexpr (EPI == kEpiShuffleL1) {
             if (want(1)) aux[1][c][p] = *reinterpret_cast<const f32x4*>(a.truth + idx);
           }
-        } else if constexpr (kPixMajor) {
-          // Buffer loads: the lane's own offset is ONE VGPR for the whole launch, the unit's offset inside image n a
+        } else if constexpr (kPixMajor && (PERSIST || G::COLS == 16)) {
+          // Buffer loads (persistent tiles and strip tiles; the 3 x 48 / 4 x 48 one-workgroup-per-tile launches keep their
+          // global loads below: with these a full-image residual layer took 75.9 instead of 66.4 us): the lane's own offset is ONE VGPR for the whole launch, the unit's offset inside image n a
           // wave-uniform scalar operand -- no vector address arithmetic per unit.  Persistent tiles: 63.3 -> 62.8 / 66.2 ->
           // 65.4 us per residual layer of a full image, 10 / 3 VGPRs fewer (such a layer takes longer than conv + ReLU even
           // with its operand HOT in L2, tools/probe_res_operand.py: issue slots of the MFMA waves, not memory); the
@@ -665,6 +666,19 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
           }
           if constexpr (EPI == kEpiRes2) {
             if (want(1)) aux[1][c][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(image(a.res1), lane_off, soff, 0));
+          }
+        } else if constexpr (kPixMajor) {
+          const size_t plane = (size_t)a.H * a.pitch;
+          const int xb = min(x0 + pcol * 16 + lq * 4, a.pitch - 4);   // (pitch % 4 == 0 on this path)
+          const size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * a.pitch + xb;
+          if constexpr (EPI == kEpiMask) {
+            if (want(0)) aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.mask + idx);
+          }
+          if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) {
+            if (want(0)) aux[0][c][p] = *reinterpret_cast<const f32x4*>(a.res0 + idx);
+          }
+          if constexpr (EPI == kEpiRes2) {
+            if (want(1)) aux[1][c][p] = *reinterpret_cast<const f32x4*>(a.res1 + idx);
           }
         } else {
           const size_t plane = (size_t)a.H * a.pitch;
