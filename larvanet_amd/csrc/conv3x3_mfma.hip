@@ -894,8 +894,12 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
     // with two half-batch chains sharing the CUs plain stores are faster in both chains (step 1.634-1.641 ms all-plain,
     // 1.648-1.650 forward only, 1.657-1.660 all-non-temporal: profiles/r04_ab_strip_plain.txt).
     const size_t plane = (size_t)k.H * k.pitch;
-    auto store_all = [&](auto plain_tag) {
+    // INTERIOR (a tile wholly inside the image -- every tile of a 48 x 48 training patch, all but the last column of tiles
+    // of a 339 x 510 image): no per-lane bounds, no per-element zero fill.  The epilogue's vector instructions compete
+    // with the co-resident workgroup's MFMAs for the SIMD's issue port, so what is not issued here is its K loop's gain.
+    auto store_all = [&](auto plain_tag, auto interior_tag) {
       constexpr bool kPlain = decltype(plain_tag)::value;
+      constexpr bool kInterior = decltype(interior_tag)::value;
 #pragma unroll
       for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -904,7 +908,7 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
           const int y = y0 + prow, xb = x0 + pcol * 16 + lq * 4;
           const size_t idx = ((size_t)n * COUT + (ct0 + c) * 16 + lr) * plane + (size_t)y * k.pitch + xb;
           f32x4 v = acc[c][p] + bias[c];
-          if (y < k.H && xb < k.pitch) {
+          if (kInterior || (y < k.H && xb < k.pitch)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float o = v[r];
@@ -912,20 +916,33 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
               if constexpr (EPI == kEpiMask) o = (aux[0][c][p][r] > 0.f) ? o : 0.f;
               if constexpr (EPI == kEpiRes1 || EPI == kEpiRes2) o += aux[0][c][p][r];
               if constexpr (EPI == kEpiRes2) o += aux[1][c][p][r];
-              v[r] = (xb + r < k.W) ? o : 0.f;   // columns [W, pitch) are kept at zero for the next layer
+              v[r] = (kInterior || xb + r < k.W) ? o : 0.f;   // columns [W, pitch) are kept at zero for the next layer
             }
             if constexpr (kPlain) *reinterpret_cast<f32x4*>(out_ptr + idx) = v;
             else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_ptr + idx));
           }
         }
     };
+    // (not for the two-residual and mask epilogues: the second copy of the epilogue costs the two-residual persistent
+    // kernel its 128 registers -- 71.0 instead of 65.6 us per layer -- and the training step gains nothing either way)
+    constexpr bool kFastPath = EPI == kEpiPlain || EPI == kEpiRelu || EPI == kEpiRes1;
+    const bool interior = kFastPath && y0 + G::ROWS <= k.H && x0 + G::COLS <= k.W;   // (wave-uniform)
+    auto store_policy = [&](auto plain_tag) {
+      if constexpr (kFastPath) {
+        if (interior) {
+          store_all(plain_tag, std::true_type{});
+          return;
+        }
+      }
+      store_all(plain_tag, std::false_type{});
+    };
     if constexpr ((LARVA_DIAG & 16) != 0) {
-      store_all(std::true_type{});
+      store_policy(std::true_type{});
     } else if constexpr (G::COLS == 16) {
-      if (k.plain) store_all(std::true_type{});
-      else store_all(std::false_type{});
+      if (k.plain) store_policy(std::true_type{});
+      else store_policy(std::false_type{});
     } else {
-      store_all(std::false_type{});
+      store_policy(std::false_type{});
     }
   } else {
     // Register-staged path (any width): channel-major accumulators, four 4-byte stores per (c, p)
