@@ -1414,6 +1414,8 @@ static hipError_t launch_persist_e(const ConvArgs& a, hipStream_t stream, const 
 // persistent tiles exist for the epilogues of an inference forward; anything else: hipErrorNotSupported
 template <int COUT>
 static hipError_t launch_persist(const ConvArgs& a, int epi, hipStream_t stream, const LaunchTiming* tm) {
+  // (the residual / mask operands of these kernels come by buffer loads with 32-bit byte offsets inside one image)
+  if ((long long)COUT * a.H * a.pitch * 4 >= (1ll << 31)) return hipErrorNotSupported;
   switch (epi) {
     case kEpiPlain: return launch_persist_e<COUT, kEpiPlain>(a, stream, tm);
     case kEpiRelu: return launch_persist_e<COUT, kEpiRelu>(a, stream, tm);
@@ -1907,6 +1909,8 @@ static int strips_dispatch(const float* const* src, int n_src, int cin_per_src, 
   if (rc) return rc;
   if (!aligned) return (int)hipErrorNotSupported;
   if ((long long)N * tiles_per_image >= (1ll << 20)) return (int)hipErrorInvalidValue;  // div_by_magic range
+  // (the strip kernel's residual / mask operands come by buffer loads with 32-bit byte offsets inside one image)
+  if ((long long)cout * H * a.pitch * 4 >= (1ll << 31)) return (int)hipErrorNotSupported;
   a.tile_tab = tile_tab;
   if (tile_tab_host && tiles_per_image <= 64 && H <= 256 && pitch <= 2048) {
     // the same table inline in the kernel arguments, 16 bits per tile (ConvArgs::tab16)
@@ -2059,6 +2063,7 @@ int larva_conv3x3_pipeline_plan(const void* layers_v, int n_layers, int N, int c
   if (!layers || !workspace || !error_word || !plan_v || n_layers <= 0 || n_layers > kPipeMaxLayers || cout != 48)
     return (int)hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return (int)hipErrorInvalidValue;
+  if ((long long)48 * H * (pitch ? pitch : W) * 4 >= (1ll << 31)) return (int)hipErrorNotSupported;   // 32-bit byte offsets inside one image
   PipePlan* plan = static_cast<PipePlan*>(plan_v);
   PipeLayer table[kPipeMaxLayers];
   ConvArgs shape{};
