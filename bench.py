@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: HR Mpixels/s of the LarvaNet x4 multi-exit TRAINING step on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--extras]
 
 N > 1 works both ways: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py
 --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or as a plain
@@ -19,25 +19,28 @@ ms_per_step are the MEDIAN round, min / max are reported beside it.  The loop ha
 semantics: every step is handed fresh device tensors (train_larva.py:123-128) and returns loss.item()
 (models/LarvaNet.py:139).
 
-The JSON line also carries
-  roofline            fp32-MFMA roofline of the dominant kernel (fused conv3x3+ReLU, 48->48,
-                      16x48x48) the way the step runs it: two concurrent half-batch strip-tile
-                      launches per layer, timed live with events around a captured graph
-  roofline_single_chain   the same layer as one whole-batch launch (round 1's dominant kernel)
-  roofline_c32/_c64   the same kernel at 32 and 64 channels (BASELINE configs 2 and 5)
-  roofline_wgrad      all weight gradients of the step (one flat grid over the 40 layers + the head, one
-                      reduction) priced on what the step pays (captured forward+backward with and without
-                      them); `isolated_loop`: the launch pair alone, back to back
-  cpu_baseline        the same training step in the torch CPU restatement (oracle/, kind "port") on
-                      the host cores of this box, bounded sample
-  infer               inference-forward throughput (LarvaNetModule.forward) on the batch
-  infer_full_image    V1 and V2 on one 3 x 339 x 510 image (BASELINE config 5 at N = 1)
+OUTPUT.  stdout carries exactly ONE line: a COMPACT JSON object (<= 4 KB, no prose fields; `compact_line`
+below names every key it keeps).  The FULL record -- every block with its method notes -- goes to
+`bench_full.json` (in $LARVA_BENCH_FULL, else gpurun_out/ when it exists, else beside this file) and, as one
+line prefixed `bench_full: `, to stderr.
+
+Blocks of the default run (all in the compact line):
+  roofline            fp32-MFMA roofline of the dominant kernel (fused conv3x3+ReLU, 48->48, 16x48x48) the way
+                      the step runs it: two concurrent half-batch strip-tile launches per layer; avg_ms = replay
+                      of a captured 40-link graph / 40 (the step's own chain length), settled like the headline,
+                      median of 7 sets with frac_min / frac_max; beside it the steady-state slope, the rocprofv3
+                      lone-launch average and the PMC MFMA-busy fraction read from the committed profiles/
+  roofline_wgrad      all weight gradients of the step, priced on what the step pays (captured forward+backward
+                      with and without them)
   step                the whole step's 183.7 GFLOP over ms_per_step against the fp32 matrix peak
-  value_async_resident   the loop without the reference's per-step loss.item() and with the batch already in
-                      the captured step's input buffers (round 2's headline; --async-loss makes it `value`)
-  roofline_wgrad_c32/_c64   the weight-gradient launch + reduction at 32 / 64 channels
-  rccl_ranks, allreduce_exposed_us   N > 1: ranks in the RCCL communicator and the event-timed gap
-                      per step between the last weight-gradient kernel and the optimizer
+  infer               inference forward (LarvaNetModule.forward) on the batch
+  infer_full_image    V1 on one 3 x 339 x 510 image (BASELINE config 5 at N = 1) + its dominant layer
+  cpu_baseline        the same training step in the torch CPU restatement (oracle/, kind "port") on the host
+                      cores of this box, bounded sample; configs[0] (EDSR-baseline CPU step) beside it
+  rccl_ranks, allreduce_exposed_us, dp_schedule, ms_per_step_per_rank     N > 1 only
+--extras adds (full record only): the whole-batch single chain, 32 / 64 channels, V2 full-image inference, the
+data-parallel schedules on one GPU with and without a one-rank RCCL communicator, the async / resident loop, the
+chains' in-step marker timing, the sustained clock.
 """
 import argparse
 import json
@@ -61,27 +64,34 @@ FLAGS = ["--num_modules=4", "--num_blocks=4,4,4,4"]
 HR_PIX_PER_BATCH = BATCH * (PATCH * SCALE) ** 2          # 589 824
 FP32_MFMA_PEAK_TFLOPS = 157.3                            # MI355X_MICROARCH.md: Peak FP32 (matrix)
 FULL_IMAGE = (3, 339, 510)                               # DIV2K-val-like LR image
-# HBM-side bytes per launch come from the committed rocprofv3 --pmc passes (counters cannot be collected by this run
-# itself); they are READ from the CSVs under profiles/ at run time -- a tile change that is not followed by new PMC
-# passes shows as a stale file name here, not as a silently wrong constant.  FETCH_SIZE is doubled per the guide's
-# gfx950 correction for 16-byte-per-lane streams; both counters are in KB.
-PMC_CONV_CSV = "profiles/r05_pmc_conv.csv"      # tools/profile_r05.sh: passes over `bench.py --roofline-only`
-PMC_WGRAD_CSV = "profiles/r05_pmc_wgrad.csv"    # passes over `bench.py --wgrad-only` (flat grid over 40 layers + reduction)
-PMC_INFER_CSV = "profiles/r05_pmc_infer.csv"    # passes over tools/infer_full_image.py (the persistent full-image launches)
+# HBM-side bytes per launch, the MFMA-busy fraction and the lone-launch duration come from the committed rocprofv3 passes
+# (counters cannot be collected by this run itself); they are READ from the CSVs under profiles/ at run time -- newest
+# round first -- and the file used is named in the record: a kernel change that is not followed by new passes shows as a
+# stale file name, not as a silently wrong constant.  FETCH_SIZE is doubled per the guide's gfx950 correction for
+# 16-byte-per-lane streams; both counters are in KB.
+PROFILE_ROUNDS = ("r06", "r05")
 PMC_WGRAD_LAYERS = 40
+SIMDS = 256 * 4                                          # MFMA-busy cycles are summed over the chip's SIMDs
+
+
+def profile_csv(stem):
+    """profiles/<round>_<stem>.csv of the newest round that has one (tools/profile_r06.sh writes them)."""
+    for r in PROFILE_ROUNDS:
+        rel = "profiles/%s_%s.csv" % (r, stem)
+        if os.path.exists(os.path.join(ROOT, rel)):
+            return rel
+    raise SystemExit("bench.py: no profiles/{%s}_%s.csv -- roofline.traffic is taken from the committed PMC passes"
+                     % (",".join(PROFILE_ROUNDS), stem))
 
 
 def pmc_mean(path, kernel_substr, counter):
     """mean_per_launch of `counter` for the first kernel whose name contains `kernel_substr` in a committed PMC
     summary (columns: pass,kernel,counter,launches,mean_per_launch,mean_duration_us)."""
     import csv
-    full = os.path.join(ROOT, path)
-    if not os.path.exists(full):
-        raise SystemExit("bench.py: %s is missing -- roofline.traffic is taken from the committed PMC passes" % path)
-    with open(full, newline="") as f:
+    with open(os.path.join(ROOT, path), newline="") as f:
         for row in csv.DictReader(f):
             if kernel_substr in row["kernel"] and row["counter"] == counter:
-                return float(row.get("mean_per_launch") or row["mean_per_launch_KB"])
+                return float(row["mean_per_launch"])
     raise SystemExit("bench.py: no %s row for a kernel matching %r in %s" % (counter, kernel_substr, path))
 
 
@@ -89,21 +99,36 @@ def hbm_traffic_bytes(path, kernel_substr):
     return (2.0 * pmc_mean(path, kernel_substr, "FETCH_SIZE") + pmc_mean(path, kernel_substr, "WRITE_SIZE")) * 1024.0
 
 
+def mfma_busy_cycles_per_simd(path, kernel_substr):
+    """SQ_VALU_MFMA_BUSY_CYCLES per launch / the chip's 1024 SIMDs: the cycles one SIMD's matrix pipe is busy in a launch
+    (= MFMAs per SIMD x 32 for v_mfma_f32_16x16x4_f32: the PMC check that the kernel issues the algorithmic minimum)."""
+    return pmc_mean(path, kernel_substr, "SQ_VALU_MFMA_BUSY_CYCLES") / SIMDS
+
+
+def rocprof_avg_us(stem, kernel_substr):
+    """(AverageNs / 1e3, calls, file) of a kernel in a committed `rocprofv3 --kernel-trace --stats` summary."""
+    import csv
+    path = profile_csv(stem)
+    with open(os.path.join(ROOT, path), newline="") as f:
+        for row in csv.DictReader(f):
+            if kernel_substr in row["Name"]:
+                return float(row["AverageNs"]) / 1e3, int(row["Calls"]), path
+    return None, 0, path
+
+
 def conv_traffic(dual):
     """(bytes per LAYER, source) of the fused conv+ReLU layer: two half-batch strip launches, or one whole-batch launch."""
+    p = profile_csv("pmc_conv")
     if dual:
-        return 2 * hbm_traffic_bytes(PMC_CONV_CSV, "conv3x3_mfma_strip_kernel<48, 1>"), PMC_CONV_CSV
-    return hbm_traffic_bytes(PMC_CONV_CSV, "conv3x3_mfma_kernel<48, true, 1>"), PMC_CONV_CSV
+        return 2 * hbm_traffic_bytes(p, "conv3x3_mfma_strip_kernel<48, 1>"), p
+    return hbm_traffic_bytes(p, "conv3x3_mfma_kernel<48, true, 1>"), p
 
 
 def wgrad_traffic_per_layer():
     """Weight-gradient kernel (the flat grid over 40 layers) + its reduction, per layer."""
-    return (hbm_traffic_bytes(PMC_WGRAD_CSV, "wgrad3x3_pipe_flat_kernel<48, 48>") +
-            hbm_traffic_bytes(PMC_WGRAD_CSV, "wgrad_reduce_kernel")) / float(PMC_WGRAD_LAYERS)
-
-
-TRAFFIC_NOTE = ("read at run time from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
-                "correction); not measured by this run")
+    p = profile_csv("pmc_wgrad")
+    return (hbm_traffic_bytes(p, "wgrad3x3_pipe_flat_kernel<48, 48>") +
+            hbm_traffic_bytes(p, "wgrad_reduce_kernel")) / float(PMC_WGRAD_LAYERS), p
 
 
 def conv_flop(c):
@@ -229,69 +254,69 @@ def chain_operands(dev, c, chain=40, decaying=False):
     return x0, fwd, b, bufs, run(fwd)
 
 
-def replay_ms(graph, reps=10):
-    """Median of 3 event-timed runs of `reps` back-to-back replays -> ms per replay."""
+def replay_stats(graph, reps=10, sets=7, settle=True):
+    """Event-timed sets of `reps` back-to-back replays -> {"median", "min", "max", "sets": [ms per replay ...],
+    "settle_blocks"}.  settle: the rule of the headline loop in front of the timed sets -- untimed blocks of `reps`
+    replays until two consecutive blocks agree within 0.5 % (at most 20): a chain replayed behind idle time runs its first
+    few hundred microseconds on a ramping clock, which is what spread round 5's `roofline.frac` over 0.640-0.683 while
+    the step time held +-0.4 %."""
     import torch
-    for _ in range(3):
-        graph.replay()
-    torch.cuda.synchronize()
-    best = []
-    for _ in range(3):
+
+    def one():
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(reps):
             graph.replay()
         e.record()
         torch.cuda.synchronize()
-        best.append(s.elapsed_time(e) / reps)
-    return sorted(best)[1]
+        return s.elapsed_time(e) / reps
+
+    blocks, prev = 0, None
+    for _ in range(20 if settle else 1):
+        cur = one()
+        blocks += 1
+        if prev is not None and abs(cur - prev) <= 0.005 * prev:
+            break
+        prev = cur
+    vals = [one() for _ in range(sets)]
+    srt = sorted(vals)
+    return {"median": srt[len(srt) // 2], "min": srt[0], "max": srt[-1], "sets": vals, "settle_blocks": blocks}
+
+
+def replay_ms(graph, reps=10):
+    """Median ms per replay of 3 event-timed sets (no settle phase): the extras' short form."""
+    return replay_stats(graph, reps, sets=3, settle=False)["median"]
 
 
 # Layers per captured chain.  The roofline fraction is priced on the SHORT chain (replay / 40: the chain length of the
 # training step, fixed cost of a replay included -- graph launch, the chains ramping up, the last drain: ~55 us per
 # replay in profiles/r03_dual_chain_overlap.txt).  The slope between the long and the short chain, (t(160) - t(40)) / 120
-# = what one more layer costs in the steady state, is reported beside it as `*_steady_state` (round 3 made it the
-# headline, which was a change of definition, not of kernel: VERDICT r3 / ADVICE r3).
+# = what one more layer costs in the steady state, is reported beside it as `*_steady_state`, never as the headline.
 CHAIN_SHORT, CHAIN_LONG = 40, 160
 
 
-def chain_time_ms(dev, c, chain=CHAIN_SHORT, reps=10, decaying=False):
-    """The fused conv3x3+ReLU kernel the way it runs inside the training step: captured chains of dependent launches
-    (each reads the previous one's output), replayed back to back, timed by a HIP event pair on the launch stream.
-    Returns (slope between the 160- and the 40-launch chain in ms per launch, RMS of the last output, replay / 40)."""
+def chain_graphs(dev, c, dual, chain=CHAIN_SHORT, decaying=False, lengths=(CHAIN_SHORT, CHAIN_LONG)):
+    """Captured graphs of the fused conv3x3+ReLU layer chained `n` times (each launch reads the previous one's output),
+    n in `lengths`.  dual=False: whole-batch launches (3 x 48 tiles, conv3x3_mfma_kernel) on one stream.  dual=True: the
+    way the training step runs its layer chain (autograd.DualChain): two half-batch chains of strip-tile launches
+    (5 x 16 / 4 x 16 pixel tiles, 256 workgroups per launch, plain stores) on two streams inside one graph.
+    -> ({n: graph}, rms of the calibrated chain's last output), or None when the strip tiling does not apply."""
     import torch
     from larvanet_amd import kernels as K
-    x0, wpk, b, bufs, rms = chain_operands(dev, c, chain, decaying)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        K.conv3x3(x0, wpk, c, bias=b, relu=True, out=bufs[0])
-    torch.cuda.current_stream().wait_stream(side)
-    times = {}
-    for n in (CHAIN_SHORT, CHAIN_LONG):
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            for i in range(n):
-                # (the calibrated chain is `chain` layers long: every `chain` layers it starts again from x0)
-                K.conv3x3(x0 if i % chain == 0 else bufs[(i - 1) & 1], wpk, c, bias=b, relu=True, out=bufs[i & 1])
-        times[n] = replay_ms(graph, reps)
-    return (times[CHAIN_LONG] - times[CHAIN_SHORT]) / (CHAIN_LONG - CHAIN_SHORT), rms, times[CHAIN_SHORT] / CHAIN_SHORT
-
-
-def dual_chain_time_ms(dev, c=CH, chain=40, reps=10, decaying=False):
-    """The same layers the way the training step runs its layer chain (autograd.DualChain): two
-    half-batch chains of strip-tile launches (5 x 16 / 4 x 16 pixel tiles, 256 workgroups per launch)
-    on two streams inside one captured graph; per FULL-BATCH layer = replay time / chain."""
-    import torch
-    from larvanet_amd import kernels as K
-    for phase in (0, 1):
-        if K.strip_tile_table(PATCH, PATCH, dev, phase) is None:
-            return None
+    if dual:
+        for phase in (0, 1):
+            if K.strip_tile_table(PATCH, PATCH, dev, phase) is None:
+                return None
     x0, wpk, b, bufs, rms = chain_operands(dev, c, chain, decaying)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     parts = ((0, BATCH // 2), (BATCH // 2, BATCH))
 
     def body(n):
+        if not dual:
+            for i in range(n):
+                # (the calibrated chain is `chain` layers long: every `chain` layers it starts again from x0)
+                K.conv3x3(x0 if i % chain == 0 else bufs[(i - 1) & 1], wpk, c, bias=b, relu=True, out=bufs[i & 1])
+            return
         cur = torch.cuda.current_stream()
         for st in streams:
             st.wait_stream(cur)
@@ -300,7 +325,7 @@ def dual_chain_time_ms(dev, c=CH, chain=40, reps=10, decaying=False):
             for k, st in enumerate(streams):
                 with torch.cuda.stream(st):
                     K.conv3x3(src, wpk, c, bias=b, relu=True, out=bufs[i & 1], images=parts[k],
-                              strips=2 if k else True, plain_stores=True)   # (plain stores: what the step's forward chain uses)
+                              strips=2 if k else True, plain_stores=True)
         for st in streams:
             cur.wait_stream(st)
 
@@ -310,13 +335,12 @@ def dual_chain_time_ms(dev, c=CH, chain=40, reps=10, decaying=False):
         body(2)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    times = {}
-    for n in (CHAIN_SHORT, CHAIN_LONG):
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+    graphs = {}
+    for n in lengths:
+        graphs[n] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graphs[n], capture_error_mode="thread_local"):
             body(n)
-        times[n] = replay_ms(graph, reps)
-    return (times[CHAIN_LONG] - times[CHAIN_SHORT]) / (CHAIN_LONG - CHAIN_SHORT), rms, times[CHAIN_SHORT] / CHAIN_SHORT
+    return graphs, rms
 
 
 def diag_lib():
@@ -329,47 +353,20 @@ def diag_lib():
     return mod if mod.available() else None
 
 
-def time_dominant_kernel(dev, iters=50):
-    """Isolated launches of the same kernel, two ways: kernel-attached HIP events
-    (hipExtLaunchKernelGGL start/stop = the kernel's own begin/end; measurement library only) and a plain event pair
-    around each launch (includes the launch gap).  Extra information beside the in-graph chain."""
-    import numpy as np
+def strip_launch_alone_ms(dev, c, iters=50):
+    """(mean, min) ms of one half-batch strip-tile conv+ReLU launch running alone (kernel-attached events: the
+    measurement library only; None without it)."""
     import torch
     from larvanet_amd import kernels as K
     D = diag_lib()
-    g = torch.Generator().manual_seed(5)
-    x = (torch.randn(BATCH, CH, PATCH, PATCH, generator=g) * 20).to(dev)
-    w = (torch.randn(CH, CH, 3, 3, generator=g) * 0.05).to(dev)
-    b = torch.zeros(CH, device=dev)
-    fwd, _ = K.pack_weights(w)
-    out = torch.empty_like(x)
-    for _ in range(5):
-        K.conv3x3(x, fwd, CH, bias=b, relu=True, out=out)
-    torch.cuda.synchronize()
-    k_mean, k_min = D.conv3x3_relu_timed(x, fwd, CH, b, out, iters) if D is not None else (None, None)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for s, e in evs:
-        s.record()
-        K.conv3x3(x, fwd, CH, bias=b, relu=True, out=out)
-        e.record()
-    torch.cuda.synchronize()
-    pair = sorted(s.elapsed_time(e) for s, e in evs)
-    return k_mean, k_min, float(np.mean(pair))
-
-
-def strip_launch_alone_ms(dev, c, iters=50):
-    """(mean, min) ms of one half-batch strip-tile conv+ReLU launch running alone (kernel-attached events)."""
-    import torch
-    from larvanet_amd import kernels as K
+    if D is None:
+        return None
     g = torch.Generator().manual_seed(5)
     x = (torch.randn(BATCH, c, PATCH, PATCH, generator=g) * 20).to(dev)
     w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(dev)
     b = torch.zeros(c, device=dev)
     fwd, _ = K.pack_weights(w)
     out = torch.empty_like(x)
-    D = diag_lib()
-    if D is None:
-        return None
     try:
         D.conv3x3_strips_timed(x, fwd, c, b, out, 5, images=(0, BATCH // 2), relu=True)
         return D.conv3x3_strips_timed(x, fwd, c, b, out, iters, images=(0, BATCH // 2), relu=True)
@@ -377,74 +374,65 @@ def strip_launch_alone_ms(dev, c, iters=50):
         return None
 
 
-def roofline_block(dev, c=CH, full=True, dual=False, quick=False):
-    """fp32-MFMA roofline of the fused conv3x3+ReLU layer at 16 x c x 48 x 48.  dual=False: one
-    chain of whole-batch launches (3 x 48 tiles, conv3x3_mfma_kernel).  dual=True: the layer as the
-    training step runs it since round 2 -- two concurrent half-batch launches of
-    conv3x3_mfma_strip_kernel; `avg_ms` is then the time per FULL-BATCH layer (= per pair of
-    launches), `flop_per_launch` one launch's half."""
-    reps = 2 if quick else 10   # quick: a short run for rocprofv3 --pmc passes (every dispatch is serialised there)
-    res = dual_chain_time_ms(dev, c, reps=reps) if dual else chain_time_ms(dev, c, reps=reps)
+def roofline_block(dev, c=CH, dual=True, quick=False, extras=False, sets=7):
+    """fp32-MFMA roofline of the fused conv3x3+ReLU layer at 16 x c x 48 x 48.  dual=True: the layer as the training
+    step runs it -- two concurrent half-batch launches of conv3x3_mfma_strip_kernel; dual=False: one chain of
+    whole-batch launches of conv3x3_mfma_kernel.  `avg_ms` is the time per FULL-BATCH layer either way.
+
+    achieved = algorithmic FLOP per layer (2 * 9 * c * c per LR pixel x 36 864 pixels) / avg_ms, with
+    avg_ms = MEDIAN over `sets` event-timed sets of 10 back-to-back replays of a captured 40-link graph / 40, taken
+    after the settle rule of replay_stats; frac_min / frac_max are the slowest / fastest set.  `frac_steady_state`:
+    the slope (t160 - t40) / 120.  quick: a short run for rocprofv3 --pmc passes (every dispatch is serialised there)."""
+    res = chain_graphs(dev, c, dual)
     if res is None:
         return None
-    slope_ms, rms, ms40 = res
-    # `frac` / `achieved` / `avg_ms` are priced on a captured chain as long as the step's own (40 links, replay / 40:
-    # graph launch, the chains' ramp and the last drain included) -- rounds 1-2's definition, comparable across rounds
-    # and what the step pays per layer.  The slope between a 160- and a 40-link chain (what one MORE layer costs once
-    # the chains are in their steady state) is reported beside it as *_steady_state and is never the headline.
+    graphs, rms = res
+    reps = 2 if quick else 10
+    short = replay_stats(graphs[CHAIN_SHORT], reps, sets=1 if quick else sets, settle=not quick)
+    long_ = replay_stats(graphs[CHAIN_LONG], reps, sets=1 if quick else 3, settle=False)
+    ms40 = short["median"] / CHAIN_SHORT
+    slope = (long_["median"] - short["median"]) / (CHAIN_LONG - CHAIN_SHORT)
     flop = conv_flop(c)
-    achieved = flop / (ms40 * 1e-3) / 1e12
-    steady = flop / (slope_ms * 1e-3) / 1e12
-    alg_bytes = 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c)
-    blk = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_ms": ms40, "avg_ms_chain40": ms40,
-           "avg_ms_is": "replay of a captured %d-link chain / %d (the chain length the training step runs)" % (CHAIN_SHORT, CHAIN_SHORT),
-           "avg_ms_steady_state": slope_ms, "achieved_steady_state": steady,
-           "frac_steady_state": steady / FP32_MFMA_PEAK_TFLOPS,
-           "steady_state_is": "(t%d - t%d) / %d: the replay's fixed cost (graph launch, ramp, last drain) removed; "
-                              "NOT the headline fraction" % (CHAIN_LONG, CHAIN_SHORT, CHAIN_LONG - CHAIN_SHORT),
-           "inputs": "layer 0 reads N(0,1)*20 activations; weights rescaled so the RMS stays there down the 40-layer chain "
-                     "(last layer's output RMS %.1f)" % rms}
+    tf = lambda ms: flop / (ms * 1e-3) / 1e12
+    kname = ("conv3x3_mfma_strip_kernel<%d, 1>" if dual else "conv3x3_mfma_kernel<%d, true, 1>") % c
+    blk = {"bound": "mfma", "achieved": tf(ms40), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": tf(ms40) / FP32_MFMA_PEAK_TFLOPS,
+           "frac_min": tf(short["max"] / CHAIN_SHORT) / FP32_MFMA_PEAK_TFLOPS,
+           "frac_max": tf(short["min"] / CHAIN_SHORT) / FP32_MFMA_PEAK_TFLOPS,
+           "traffic": None, "avg_ms": ms40, "sets": len(short["sets"]), "settle_blocks": short["settle_blocks"],
+           "avg_ms_sets": [v / CHAIN_SHORT for v in short["sets"]],
+           "avg_ms_steady_state": slope, "frac_steady_state": tf(slope) / FP32_MFMA_PEAK_TFLOPS,
+           "kernel": kname + (" x2 concurrent half-batch strip launches = one 16x%dx48x48 conv3x3+bias+ReLU layer" % c if dual
+                              else " one whole-batch launch, 16x%dx48x48 conv3x3+bias+ReLU" % c),
+           "launches_per_layer": 2 if dual else 1, "flop_per_launch": flop // 2 if dual else flop, "flop_per_layer": flop,
+           "algorithmic_bytes_per_layer": 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c),
+           "chain_links": CHAIN_SHORT, "last_output_rms": rms,
+           "timing": "HIP event pairs around 10 back-to-back replays of a captured %d-link chain, / %d; settle blocks until two "
+                     "agree within 0.5 %%, then median of %d sets (min / max -> frac_max / frac_min); steady state = "
+                     "(t%d - t%d) / %d" % (CHAIN_SHORT, CHAIN_SHORT, sets, CHAIN_LONG, CHAIN_SHORT, CHAIN_LONG - CHAIN_SHORT)}
     if c == CH:
         blk["traffic"], src = conv_traffic(dual)
-        blk["traffic_source"] = TRAFFIC_NOTE % src
-        if (full or dual) and not quick:
-            old_ms = (dual_chain_time_ms(dev, c, decaying=True) if dual else chain_time_ms(dev, c, decaying=True))[2]
-            blk["avg_ms_decaying_inputs"] = old_ms
-            blk["avg_ms_decaying_inputs_is"] = ("the same replay / 40 with round 2's microbenchmark operands (ones in, weights x 0.05: the "
-                                                "activations shrink ~30x per layer, most layers multiply zeros / denormals), for "
-                                                "comparison: the chip clocks higher on them")
-    if dual:
-        alone = None if quick else strip_launch_alone_ms(dev, c)
-        if alone is not None:
-            blk["launch_alone_ms"] = alone[0]
-            blk["launch_alone_is"] = ("mean duration of ONE half-batch strip launch running alone, kernel-attached HIP events over "
-                                      "50 launches (min %.5f): the figure rocprofv3 --stats reports per dispatch of this kernel "
-                                      "(profiles/r03_bench_kernel_stats.csv), NOT half of avg_ms -- two such launches "
-                                      "overlap in the step" % alone[1])
-        blk.update({
-            "kernel": "conv3x3_mfma_strip_kernel<%d, 1> (fused conv3x3+bias+ReLU, 5x16 / 4x16 pixel tiles), two concurrent " % c +
-                      "half-batch launches (8x%dx48x48 each) = one 16x%dx48x48 fp32 layer" % (c, c),
-            "launches_per_layer": 2, "flop_per_launch": flop // 2, "flop_per_layer": flop,
-            "traffic_is": "HBM-side bytes per LAYER (two launches)",
-            "algorithmic_bytes_per_layer": alg_bytes,
-            "timing": "HIP event pairs around 10 replays of captured graphs of two half-batch chains on two streams, 40 and "
-                      "160 layers long (median of 3 each); avg_ms = t40 / 40 per full-batch layer (rounds 1-2's definition, includes "
-                      "the replay's fixed cost); avg_ms_steady_state = (t160 - t40) / 120.  The un-profiled in-kernel stamp "
-                      "profile profiles/r04_dual_chain_overlap.txt records both figures for the same 40-link graph; under "
-                      "rocprofv3 the two chains do not overlap (the profiler makes the multi-stream graph launch "
-                      "host-bound): its per-launch durations are those of a launch running alone"})
-    else:
-        blk.update({
-            "kernel": "conv3x3_mfma_kernel<%d, true, 1> (fused conv3x3+bias+ReLU), 16x%dx48x48 fp32" % (c, c),
-            "flop_per_launch": flop,
-            "timing": "HIP event pairs around 10 replays of captured chains of 40 and 160 dependent launches (median of 3 "
-                      "each); avg_ms = t40 / 40, avg_ms_steady_state = (t160 - t40) / 120",
-            "algorithmic_bytes_per_launch": alg_bytes})
-    if full and not quick:
-        k_mean_ms, k_min_ms, pair_ms = time_dominant_kernel(dev)
-        blk.update({"isolated_kernel_attached_ms": k_mean_ms, "isolated_min_ms": k_min_ms,
-                    "event_pair_ms_incl_launch_gap": pair_ms})
+        blk["traffic_source"] = src
+        blk["traffic_is"] = ("HBM-side bytes per LAYER from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled per "
+                             "the gfx950 correction), read at run time from the committed summary; not measured by this run")
+        us, calls, stats = rocprof_avg_us("bench_kernel_stats", kname)
+        if us is not None:
+            # rocprofv3 serialises the two chains: its per-dispatch average is ONE launch running alone (half a layer when
+            # dual).  mfma_busy_frac = the PMC pass's matrix-pipe cycles per SIMD over that duration at the 2.4 GHz the peak
+            # is quoted at: equal to frac_lone_launch exactly when the kernel issues the algorithmic minimum of MFMAs
+            lone_flop = flop // 2 if dual else flop
+            cyc = mfma_busy_cycles_per_simd(src, kname)
+            blk["rocprof"] = {"kernel_stats": stats, "pmc": src, "lone_launch_us": us, "calls": calls,
+                              "frac_lone_launch": lone_flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                              "mfma_busy_cycles_per_simd": cyc, "mfma_busy_frac": cyc / 2.4e3 / us}
+    if extras and not quick:
+        if dual:
+            alone = strip_launch_alone_ms(dev, c)
+            if alone is not None:
+                blk["launch_alone_ms"], blk["launch_alone_min_ms"] = alone
+        if c == CH:
+            g2, _ = chain_graphs(dev, c, dual, decaying=True, lengths=(CHAIN_SHORT,))
+            blk["avg_ms_decaying_inputs"] = replay_ms(g2[CHAIN_SHORT]) / CHAIN_SHORT   # round 2's operands, for comparison
     return blk
 
 
@@ -477,19 +465,7 @@ def wgrad_block(dev, c=CH, jobs=40, iters=10):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         pair()
-    for _ in range(3):  # the chip needs a few hundred microseconds of load to settle its clock
-        graph.replay()
-    torch.cuda.synchronize()
-    runs = []
-    for _ in range(3):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(iters):
-            graph.replay()
-        e.record()
-        torch.cuda.synchronize()
-        runs.append(s.elapsed_time(e) / iters)
-    ms = sorted(runs)[1]
+    ms = replay_stats(graph, iters, sets=3, settle=iters >= 10)["median"]
     achieved = conv_flop(c) * nlayers / (ms * 1e-3) / 1e12
     kernel = (("wgrad3x3_pipe_flat_kernel<64, 32>, two passes over 32 input channels each per workgroup and layer" if c == 64 else
                "wgrad3x3_pipe_flat_kernel<%d, %d>" % (c, c)) + " (one grid of 256 workgroups over %d layers) + wgrad_reduce_kernel" % nlayers
@@ -500,14 +476,12 @@ def wgrad_block(dev, c=CH, jobs=40, iters=10):
            "algorithmic_bytes_per_layer": 2 * BATCH * c * PATCH * PATCH * 4 + 4 * (9 * c * c + c),
            "timing": "HIP event pair around %d replays of a captured graph of the launch pair, back to back (median of 3)" % iters}
     if c == CH:
-        blk["traffic"] = wgrad_traffic_per_layer() * nlayers
-        blk["traffic_source"] = TRAFFIC_NOTE % PMC_WGRAD_CSV
-        blk["traffic_is"] = ("HBM-side bytes of the launch pair = per-layer figure x layers (dy + x read once, partial images "
-                             "written and read once)")
+        per_layer, blk["traffic_source"] = wgrad_traffic_per_layer()
+        blk["traffic"] = per_layer * nlayers   # HBM-side bytes of the launch pair (dy + x read once, partial images written and read once)
     return blk
 
 
-def wgrad_in_step(model, x, truth, reps=30):
+def wgrad_in_step(model, x, truth, reps=10):
     """What the weight gradients cost INSIDE the training step: the captured forward+backward replayed
     with and without its deferred weight-gradient launches (32 + 8 layers, the 3 -> 48 head, one
     reduction); the difference is their time at the clocks and cache state the step gives them (an
@@ -535,19 +509,7 @@ def wgrad_in_step(model, x, truth, reps=30):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             body(with_wgrad)
-        for _ in range(5):
-            graph.replay()
-        torch.cuda.synchronize()
-        runs = []
-        for _ in range(3):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(reps):
-                graph.replay()
-            e.record()
-            torch.cuda.synchronize()
-            runs.append(s.elapsed_time(e) / reps)
-        times[with_wgrad] = sorted(runs)[1]
+        times[with_wgrad] = replay_stats(graph, reps, sets=5, settle=True)["median"]
     layers = sum(BLOCKS) * 2 + 2 * len(BLOCKS)                      # 40 C->C layers
     flop = layers * conv_flop(CH) + 2 * 9 * 3 * CH * BATCH * PATCH * PATCH   # + the 3 -> 48 head
     ms = times[True] - times[False]
@@ -555,7 +517,7 @@ def wgrad_in_step(model, x, truth, reps=30):
     return {"ms_all_weight_gradients": ms, "fwd_bwd_ms": times[True], "fwd_bwd_without_wgrad_ms": times[False],
             "layers": layers, "flop": flop, "achieved": achieved, "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
             "what": "captured forward+backward replayed with and without its deferred weight-gradient launches "
-                    "(HIP events, median of 3 x %d replays)" % reps}
+                    "(HIP events, settled, median of 5 x %d replays)" % reps}
 
 
 def chains_in_step():
@@ -612,7 +574,7 @@ def host_cores():
     return min(cores, int(os.environ.get("LARVA_CPU_BASELINE_THREADS", "32")))
 
 
-def cpu_baseline(budget_s=15.0):
+def cpu_baseline(budget_s=10.0):
     """The reference CPU path (torch CPU operators, all host cores) on the same workload."""
     import numpy as np
     import torch
@@ -669,26 +631,25 @@ def cpu_baseline(budget_s=15.0):
         etimes.append(time.perf_counter() - t0)
     emed = float(np.median(etimes))
     edsr = {"value": 4 * (PATCH * SCALE) ** 2 / emed / 1e6, "unit": "HR Mpixels/s", "ms_per_step": emed * 1e3,
-            "sample": "%d EDSR.train_step steps after 3 warm-ups (64 features, 16 residual blocks, batch 4 x 3x48x48 -> "
-                      "3x192x192, Adam), BASELINE configs[0]; CPU only: EDSR is not on the hot path and has no HIP kernels"
-                      % len(etimes)}
+            "sample": "%d EDSR-baseline x4 train steps (64f/16RB, batch 4 of 3x48x48), BASELINE configs[0], CPU only" % len(etimes)}
     return {"value": HR_PIX_PER_BATCH / med / 1e6, "unit": "HR Mpixels/s", "cores": cores, "kind": "port",
-            "edsr_train_step": edsr,
-            "sample": "%d train steps after 3 warm-ups (median %.1f ms) of the same M4B4 batch-16 workload, torch %s CPU ops, "
-                      "%d threads" % (len(times), med * 1e3, torch.__version__, cores),
+            "ms_per_step": med * 1e3, "edsr_train_step": edsr,
+            "sample": "%d train steps after 3 warm-ups, same M4B4 batch-16 workload, torch %s CPU ops, %d threads"
+                      % (len(times), torch.__version__.split("+")[0], cores),
             "forward_only": {"value": HR_PIX_PER_BATCH / fmed / 1e6, "unit": "HR Mpixels/s", "ms_per_batch": fmed * 1e3,
                              "sample": "%d forwards after 3 warm-ups" % len(ftimes)}}
 
 
-def full_image_block(dev):
+def full_image_block(dev, extras=False):
     """BASELINE config 5 at N = 1: whole-network inference of one 3 x 339 x 510 LR image (x4 ->
-    1356 x 2040), V1 and V2, device tensor in, device tensor out (upscale()'s H2D / D2H copies of
-    the reference API are not in the timed region)."""
+    1356 x 2040), device tensor in, device tensor out (upscale()'s H2D / D2H copies of the reference API are
+    not in the timed region).  Default: V1; extras: V2 and V2 with 64 filters as well."""
     import importlib
     import torch
     out = {"lr_image": list(FULL_IMAGE), "hr_pixels": 16 * FULL_IMAGE[1] * FULL_IMAGE[2]}
     x = (torch.rand(1, *FULL_IMAGE, generator=torch.Generator().manual_seed(2)) * 255).to(dev)
-    for name, extra in (("LarvaNet", []), ("LarvaNetV2", []), ("LarvaNetV2", ["--num_filters=64"])):
+    nets = [("LarvaNet", [])] + ([("LarvaNetV2", []), ("LarvaNetV2", ["--num_filters=64"])] if extras else [])
+    for name, extra in nets:
         m = importlib.import_module("larvanet_amd.models." + name).create_model()
         m.parse_args(list(FLAGS) + extra)
         torch.manual_seed(0)
@@ -697,28 +658,29 @@ def full_image_block(dev):
             for _ in range(3):
                 m.fwd_runtime(x)
             reps, runs = 10, []
-            for _ in range(3):
+            for _ in range(5):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     m.fwd_runtime(x)
                 torch.cuda.synchronize()
                 runs.append((time.perf_counter() - t0) / reps * 1e3)
-            ms = sorted(runs)[1]
+            ms = sorted(runs)[len(runs) // 2]
         key = name + ("_64ch" if extra else "")   # (BASELINE configs[4] reads "LarvaNetV2, 64ch body": the --num_filters extension)
         flop = infer_flop_per_lr_pixel(BLOCKS, 64 if extra else CH, v2=name.endswith("V2")) * FULL_IMAGE[1] * FULL_IMAGE[2]
-        out[key] = {"ms_per_image": ms, "value": out["hr_pixels"] / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s", "flop": flop,
+        out[key] = {"ms_per_image": ms, "ms_min": min(runs), "ms_max": max(runs),
+                    "value": out["hr_pixels"] / (ms * 1e-3) / 1e6, "unit": "HR Mpixels/s", "flop": flop,
                     "frac_of_peak": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         del m
-    out["roofline"] = full_image_layer_block(dev)
+    out["roofline"] = full_image_layer_block(dev, extras=extras)
     return out
 
 
-def full_image_layer_block(dev, c=CH):
+def full_image_layer_block(dev, c=CH, extras=False):
     """The dominant kernel of the full-image forward the way `roofline` names the training step's: one 48 -> 48 conv3x3 of the
     339 x 510 image (pitch 512) -- what validate.py's forward issues 34 times per image -- as a captured graph of 20
-    dependent launches, per epilogue, on the persistent tiles the library picks for it and (LARVA_PERSIST=0) as one
-    workgroup per tile.  Algorithmic work 2 * 9 * c * c FLOP per LR pixel."""
+    dependent launches on the persistent tiles the library picks for it (conv + ReLU; extras: per epilogue, and as one
+    workgroup per tile under LARVA_PERSIST=0).  Algorithmic work 2 * 9 * c * c FLOP per LR pixel."""
     import torch
     from larvanet_amd import kernels as K
     H, W = FULL_IMAGE[1], FULL_IMAGE[2]
@@ -732,11 +694,15 @@ def full_image_layer_block(dev, c=CH):
     fwd, _ = K.pack_weights(w)
     bufs = [torch.empty_like(x) for _ in range(2)]
     flop = 2 * 9 * c * c * H * W
-    kinds = {"relu": dict(relu=True), "res1": dict(res0=r0), "res2": dict(res0=r0, res1=r1)}
+    kinds = {"relu": dict(relu=True)}
+    modes = [("1", "persistent")]
+    if extras:
+        kinds.update({"res1": dict(res0=r0), "res2": dict(res0=r0, res1=r1)})
+        modes.append(("0", "one_workgroup_per_tile"))
     res = {}
     keep = os.environ.get("LARVA_PERSIST")
     try:
-        for mode, tag in (("1", "persistent"), ("0", "one_workgroup_per_tile")):
+        for mode, tag in modes:
             os.environ["LARVA_PERSIST"] = mode
             res[tag] = {}
             for name, kw in kinds.items():
@@ -750,8 +716,10 @@ def full_image_layer_block(dev, c=CH):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     chain()
-                us = replay_ms(graph, 10) * 1e3 / 20
-                res[tag][name] = {"us_per_layer": us, "frac": flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+                st = replay_stats(graph, 5, sets=5, settle=True)
+                us = st["median"] * 1e3 / 20
+                res[tag][name] = {"us_per_layer": us, "frac": flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                  "us_min": st["min"] * 1e3 / 20, "us_max": st["max"] * 1e3 / 20}
     finally:
         if keep is None:
             os.environ.pop("LARVA_PERSIST", None)
@@ -759,16 +727,119 @@ def full_image_layer_block(dev, c=CH):
             os.environ["LARVA_PERSIST"] = keep
     tiles = ((H + 2) // 3) * ((P + 47) // 48)
     best = res["persistent"]["relu"]
-    return {"bound": "mfma", "achieved": best["frac"] * FP32_MFMA_PEAK_TFLOPS, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": best["frac"],
-            "traffic": hbm_traffic_bytes(PMC_INFER_CSV, "conv3x3_mfma_persist_kernel<48, 1>") if c == 48 else None,
-            "traffic_source": TRAFFIC_NOTE % PMC_INFER_CSV,
-            "algorithmic_bytes": 2 * 4 * c * H * W,
-            "kernel": "conv3x3_mfma_persist_kernel<%d, 1> (fused conv3x3+bias+ReLU on a 1 x %d x %d x %d image: %d tiles of 3 x 48 "
-                      "pixels walked by 512 persistent workgroups)" % (c, c, H, W, tiles),
-            "flop_per_launch": flop, "avg_us": best["us_per_layer"], "by_epilogue": res,
-            "timing": "HIP event pairs around 10 replays of a captured graph of 20 dependent launches (median of 3)",
-            "profile": "profiles/r05_infer_LarvaNet_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/infer_full_image.py)"}
+    kname = "conv3x3_mfma_persist_kernel<%d, 1>" % c
+    blk = {"bound": "mfma", "achieved": best["frac"] * FP32_MFMA_PEAK_TFLOPS, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": best["frac"], "traffic": None, "algorithmic_bytes": 2 * 4 * c * H * W,
+           "kernel": kname + " conv3x3+bias+ReLU on a 1x%dx%dx%d image: %d tiles of 3x48 px, persistent workgroups" % (c, H, W, tiles),
+           "flop_per_launch": flop, "avg_us": best["us_per_layer"], "by_epilogue": res,
+           "timing": "HIP event pairs around 5 replays of a captured graph of 20 dependent launches (settled, median of 5)"}
+    if c == CH:
+        p = profile_csv("pmc_infer")
+        blk["traffic"], blk["traffic_source"] = hbm_traffic_bytes(p, kname), p
+        us, calls, stats = rocprof_avg_us("infer_LarvaNet_kernel_stats", kname)
+        if us is not None:
+            blk["rocprof"] = {"kernel_stats": stats, "launch_us": us, "calls": calls,
+                              "frac": flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    return blk
+
+
+# ------------------------------------------------------------------------------------------------
+# the ONE stdout line
+# ------------------------------------------------------------------------------------------------
+COMPACT_MAX_BYTES = 4096
+STR_MAX = 120
+
+
+def _num(v):
+    """Floats to 6 significant digits (the line is a scoreboard, not an archive: bench_full.json keeps every digit)."""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    return float("%.6g" % v)
+
+
+def _pick(d, keys):
+    """The named keys of a block: strings cut to STR_MAX characters, floats to 6 digits, containers dropped unless they are
+    short lists of numbers.  A missing key is skipped; None is kept (traffic / vs_baseline may be null by contract)."""
+    out = {}
+    for k in keys:
+        if not isinstance(d, dict) or k not in d:
+            continue
+        v = d[k]
+        if isinstance(v, str):
+            out[k] = v[:STR_MAX]
+        elif isinstance(v, (list, tuple)):
+            if len(v) <= 8 and all(isinstance(e, (int, float, bool)) for e in v):
+                out[k] = [_num(e) for e in v]
+        elif isinstance(v, dict):
+            continue
+        else:
+            out[k] = _num(v)
+    return out
+
+
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_min", "frac_max", "sets", "traffic", "avg_ms",
+                 "frac_steady_state", "kernel", "flop_per_layer", "flop_per_launch", "launches_per_layer", "error")
+
+
+def compact_line(full):
+    """The stdout line: the contract's keys + `roofline` + `cpu_baseline` + one-number summaries of the other blocks, no
+    prose.  Everything else stays in the full record.  Raises if the result is not <= COMPACT_MAX_BYTES (tests/test_bench_line.py)."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_min",
+                        "ms_per_step_max", "settle_steps", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                        "bench_wall_s", "gpu_fault", "dry_run", "max_rank_plus_1", "backend"))
+    line["config"] = _pick(full.get("config", {}), ("workload", "global_batch", "parallelism", "loss_sync_per_step",
+                                                    "hip_graph", "hip_graph_fell_back", "final_loss"))
+    if "roofline" in full:
+        r = full["roofline"] or {}
+        line["roofline"] = _pick(r, ROOFLINE_KEYS)
+        if isinstance(r.get("rocprof"), dict):
+            line["roofline"]["rocprof"] = _pick(r["rocprof"], ("kernel_stats", "lone_launch_us", "frac_lone_launch", "mfma_busy_frac"))
+        if "traffic_source" in r:
+            line["roofline"]["traffic_source"] = str(r["traffic_source"])[:STR_MAX]
+    if "cpu_baseline" in full:
+        c = full["cpu_baseline"]
+        line["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "kind", "ms_per_step", "sample", "error"))
+        if isinstance(c.get("edsr_train_step"), dict):
+            line["cpu_baseline"]["edsr_ms_per_step"] = _num(c["edsr_train_step"].get("ms_per_step"))
+        if isinstance(c.get("forward_only"), dict):
+            line["cpu_baseline"]["forward_ms_per_batch"] = _num(c["forward_only"].get("ms_per_batch"))
+    if "step" in full:
+        line["step"] = _pick(full["step"], ("frac_of_peak", "achieved", "flop_per_step", "sustained_clock_ghz"))
+    if "roofline_wgrad" in full:
+        line["roofline_wgrad"] = _pick(full["roofline_wgrad"], ("bound", "frac", "achieved", "ms_all_weight_gradients",
+                                                                "ms_per_launch_pair", "traffic", "kernel", "error"))
+    if "infer" in full:
+        line["infer"] = _pick(full["infer"], ("ms_per_batch", "value", "frac_of_peak"))
+    fi = full.get("infer_full_image")
+    if isinstance(fi, dict):
+        blk = _pick(fi, ("lr_image", "error"))
+        if isinstance(fi.get("LarvaNet"), dict):
+            blk.update(_pick(fi["LarvaNet"], ("ms_per_image", "ms_min", "ms_max", "value", "frac_of_peak")))
+        if isinstance(fi.get("roofline"), dict):
+            blk["roofline"] = _pick(fi["roofline"], ("bound", "frac", "achieved", "peak", "unit", "avg_us", "traffic", "kernel"))
+        line["infer_full_image"] = blk
+    # N > 1: the data-parallel fields
+    line.update(_pick(full, ("rccl_ranks", "dist_backend")))
+    if isinstance(full.get("allreduce_exposed_us"), dict):
+        line["allreduce_exposed_us"] = _pick(full["allreduce_exposed_us"], ("median", "min", "max", "steps", "overlap"))
+    if isinstance(full.get("dp_schedule"), dict):
+        line["dp_schedule"] = _pick(full["dp_schedule"], ("choice", "allreduce_isolated_us", "bucket_bytes", "ranks", "forced"))
+    if isinstance(full.get("ms_per_step_per_rank"), dict):
+        line["ms_per_step_per_rank"] = _pick(full["ms_per_step_per_rank"], ("min", "max", "ranks"))
+    if "full_record" in full:
+        line["full_record"] = str(full["full_record"])[-STR_MAX:]
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text.encode()) > COMPACT_MAX_BYTES:
+        raise AssertionError("bench.py: the compact line is %d bytes (> %d)" % (len(text.encode()), COMPACT_MAX_BYTES))
+    return text
+
+
+def full_record_path():
+    d = os.environ.get("LARVA_BENCH_FULL")
+    if d:
+        return d if d.endswith(".json") else os.path.join(d, "bench_full.json")
+    scratch = os.path.join(ROOT, "gpurun_out")
+    return os.path.join(scratch if os.path.isdir(scratch) else ROOT, "bench_full.json")
 
 
 class GpuFault(Exception):
@@ -919,7 +990,9 @@ def run_dp_probe(a, force_dist):
 
 def dry_run(a, rank, world, emit):
     """LARVA_BENCH_DRY=1: the launcher / rendezvous / collective / JSON plumbing of a multi-rank run
-    with NO kernels (CPU, gloo) -- what the CPU tests drive with 2 and 8 ranks.  Not a measurement."""
+    with NO kernels (CPU, gloo) -- what the CPU tests drive with 2 and 8 ranks.  Not a measurement: the record has the
+    SHAPE of a real one (every N > 1 field present, placeholder numbers) so that the compact line's size and keys are
+    tested at N = 8 without hardware."""
     import torch
     import torch.distributed as td
     if os.environ.get("LARVA_BENCH_DRY_FAIL_RANK") == str(rank):   # test hook: a rank that dies
@@ -929,11 +1002,46 @@ def dry_run(a, rank, world, emit):
         td.barrier()
         td.all_reduce(t, op=td.ReduceOp.MAX)
     if rank == 0:
-        emit({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-              "max_rank_plus_1": float(t.item()), "backend": td.get_backend() if world > 1 else None})
+        full = headline_record(a, world, ms_rounds=[1.0 + 0.001 * i for i in range(max(1, a.rounds))], settle_steps=20,
+                               final_loss=0.0, ref_semantics=True, hip_graph=True, dual_chain=True, fell_back=None, resident=False)
+        full.update({"dry_run": True, "max_rank_plus_1": float(t.item()), "backend": td.get_backend() if world > 1 else None,
+                     "roofline": {"bound": "mfma", "achieved": 0.0, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 0.0,
+                                  "frac_min": 0.0, "frac_max": 0.0, "sets": 7, "traffic": None, "avg_ms": 0.0,
+                                  "kernel": "dry run: no kernel was launched", "flop_per_layer": conv_flop(CH)}})
+        if world > 1:
+            full.update({"rccl_ranks": 0, "dist_backend": td.get_backend(),
+                         "allreduce_exposed_us": {"median": 0.0, "min": 0.0, "max": 0.0, "steps": a.steps * a.rounds, "overlap": False},
+                         "dp_schedule": {"choice": "flat", "allreduce_isolated_us": 0.0, "bucket_bytes": 3330816, "ranks": world,
+                                         "rule": "dry run"},
+                         "ms_per_step_per_rank": {"min": 1.0, "max": 1.0, "ranks": [1.0] * world}})
+        emit(full)
     if world > 1:
         td.barrier()
         td.destroy_process_group()
+
+
+def headline_record(a, world, ms_rounds, settle_steps, final_loss, ref_semantics, hip_graph, dual_chain, fell_back, resident):
+    """The contract's keys of the record from the timed rounds (ms per step of every round, in the order they ran)."""
+    import numpy as np
+    per_step = sorted(ms_rounds)
+    ms_per_step = float(np.median(per_step))
+    return {
+        "metric": "HR Mpixels/s (LarvaNet x4 multi-exit train step, 48x48 LR patches)",
+        "value": world * HR_PIX_PER_BATCH / (ms_per_step * 1e-3) / 1e6, "unit": "HR Mpixels/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup,
+        "settle_steps": settle_steps,   # untimed steps behind the W warm-up steps until the step time had stopped moving (clock ramp)
+        "ms_per_step": ms_per_step, "ms_per_step_min": per_step[0], "ms_per_step_max": per_step[-1],
+        # every timed round in the order it ran, and which of them sat > 1 % over the fastest round
+        "ms_per_step_rounds": list(ms_rounds), "slow_rounds": [bool(v > 1.01 * per_step[0]) for v in ms_rounds],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LarvaNet x4 train_step_larva M4 B4,4,4,4 48ch, batch 16 of 3x48x48 -> 3x192x192 fp32 per GPU (BASELINE config 2)",
+                   "global_batch": BATCH * world, "parallelism": "dp%d" % world,
+                   "inputs": ("resident in the captured step's input buffers" if resident else
+                              "fresh device tensors handed to train_step_larva every step (copied into the captured step's inputs)"),
+                   "loss_sync_per_step": bool(ref_semantics), "hip_graph": bool(hip_graph), "dual_chain": bool(dual_chain),
+                   "hip_graph_fell_back": fell_back, "final_loss": final_loss},
+        "rounds": {"n": len(ms_rounds), "steps_each": a.steps, "value_is": "median round (max over ranks of each round's wall time)"},
+    }
 
 
 def main():
@@ -943,7 +1051,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=5, help="the --steps loop is timed this many times; value = median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements")
+    ap.add_argument("--extras", action="store_true",
+                    help="the extra single-GPU measurements (other widths, V2 inference, one-GPU data-parallel rehearsals, ...): "
+                         "full record only, + ~40 s")
+    ap.add_argument("--no-extras", action="store_true", help="headline + `roofline` only (rocprofv3 --kernel-trace runs)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="only time the dominant kernel (short run for rocprofv3 --pmc passes)")
     ap.add_argument("--wgrad-only", action="store_true",
@@ -960,17 +1071,32 @@ def main():
         # plain `python bench.py --gpus N`: become the launcher BEFORE anything touches the GPU
         sys.exit(self_launch(a.gpus, sys.argv[1:]))
 
-    # stdout carries exactly ONE line, the JSON: everything else any library prints there -- the
+    # stdout carries exactly ONE line, the compact JSON: everything else any library prints there -- the
     # plugin's progress lines, Gloo's / RCCL's C-level connection messages -- goes to stderr (fd level)
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    t_start = time.perf_counter()
 
-    def emit(obj):
+    def emit_raw(obj):   # child modes / PMC helper runs: one plain JSON line, no size rule
         os.write(json_fd, (json.dumps(obj) + "\n").encode())
 
+    def emit(full):
+        """Full record -> bench_full.json + stderr; compact line -> stdout (the only stdout line)."""
+        full["bench_wall_s"] = time.perf_counter() - t_start
+        path = full_record_path()
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            full["full_record"] = os.path.relpath(path, ROOT)
+        except OSError as e:
+            full["full_record"] = "not written: %s" % e
+        sys.stderr.write("bench_full: " + json.dumps(full) + "\n")
+        sys.stderr.flush()
+        os.write(json_fd, (compact_line(full) + "\n").encode())
+
     if a.dp_probe:
-        return dp_probe_child(a, emit)
+        return dp_probe_child(a, emit_raw)
 
     import numpy as np
     import torch
@@ -985,14 +1111,21 @@ def main():
         raise SystemExit("bench.py needs a HIP device")
     dev = torch.device("cuda", torch.cuda.current_device())
     if a.roofline_only:
-        emit({"roofline": roofline_block(dev, quick=True), "roofline_dual": roofline_block(dev, full=False, dual=True, quick=True)})
+        emit_raw({"roofline": roofline_block(dev, dual=False, quick=True), "roofline_dual": roofline_block(dev, dual=True, quick=True)})
         return
     if a.wgrad_only:
-        emit({"roofline_wgrad_isolated": wgrad_block(dev, iters=3)})
+        emit_raw({"roofline_wgrad_isolated": wgrad_block(dev, iters=3)})
         return
 
     import importlib
     import torch.distributed as td
+    sections = {}   # wall seconds of each part of this run (full record: `sections_s`)
+
+    def section(name, t0):
+        torch.cuda.synchronize()
+        sections[name] = round(time.perf_counter() - t0, 3)
+
+    t0 = time.perf_counter()
     model = importlib.import_module("larvanet_amd.models.LarvaNet").create_model()
     model.parse_args(list(FLAGS))
     torch.manual_seed(0)
@@ -1027,19 +1160,20 @@ def main():
         bufs[1].copy_(truth)
     if bufs is not None and not ref_semantics:
         x, truth = bufs
+    section("prepare_and_warmup", t0)
     # Settle: the W warm-up steps above are ~10 ms of GPU work behind the idle time of start-up, and the chip needs longer
     # than that under load to reach the clocks it then holds -- the first 10 steps after ANY idle gap run ~5 % slow
-    # (tools/step_ramp.py: 1.72 ms, then 1.64 flat; again after a 0.5 s pause), which is what put the first of five timed
-    # rounds 2-2.5 % above the others in every round-4 run.  So untimed steps go on in blocks of 10 until two consecutive
-    # blocks agree within 0.5 % (at most 10 blocks); every timed round then starts on a warm chip, back to back.
+    # (tools/step_ramp.py: 1.72 ms, then 1.64 flat; again after a 0.5 s pause).  So untimed steps go on in blocks of 10
+    # until two consecutive blocks agree within 0.5 % (at most 10 blocks); every timed round then starts on a warm chip.
+    t0 = time.perf_counter()
     settle_steps, prev = 0, None
     for _ in range(10):
         barrier_sync(world > 1)
-        t0 = time.perf_counter()
+        t1 = time.perf_counter()
         for _ in range(10):
             model.train_step_larva(args, val, x, truth)
         barrier_sync(world > 1)
-        cur = time.perf_counter() - t0
+        cur = time.perf_counter() - t1
         settle_steps += 10
         ok = prev is not None and abs(cur - prev) <= 0.005 * prev
         if world > 1:   # every rank must take the same decision
@@ -1053,49 +1187,27 @@ def main():
         model.allreduce_events.clear()
     rounds = max(1, a.rounds)
     secs, loss = timed_rounds(model, args, val, x, truth, a.steps, rounds, world > 1)
-    in_order = [s / a.steps * 1e3 for s in secs]
-    per_step = sorted(in_order)
-    ms_per_step = float(np.median(per_step))
-    value = world * HR_PIX_PER_BATCH / (ms_per_step * 1e-3) / 1e6
-    final_loss = float(loss)
+    section("settle_and_timed_rounds", t0)
     exposed = None
     if world > 1 and getattr(model, "allreduce_events", None):
         torch.cuda.synchronize()
         gaps = sorted(s.elapsed_time(e) * 1e3 for s, e in model.allreduce_events)
+        # HIP events on the compute stream: after the last weight-gradient kernel was issued -> after the stream has joined
+        # the collectives (AdamW may start)
         exposed = {"median": gaps[len(gaps) // 2], "min": gaps[0], "max": gaps[-1], "steps": len(gaps),
-                   "definition": "HIP events on the compute stream: after the last weight-gradient kernel was "
-                                 "issued -> after the stream has joined the collectives (AdamW may start)",
                    "overlap": bool(model.overlap_allreduce and getattr(model, "_early_lo", None))}
     model.time_allreduce = False
 
     if rank != 0:
         if world > 1:
-            td.barrier()  # rank 0 finishes its extra single-GPU measurements, then everybody leaves together
+            td.barrier()  # rank 0 finishes its single-GPU measurements, then everybody leaves together
             td.destroy_process_group()
         return
 
-    line = {
-        "metric": "HR Mpixels/s (LarvaNet x4 multi-exit train step, 48x48 LR patches)",
-        "value": value, "unit": "HR Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "settle_steps": settle_steps,   # untimed steps behind the W warm-up steps until the step time had stopped moving (clock ramp)
-        "ms_per_step": ms_per_step, "ms_per_step_min": per_step[0], "ms_per_step_max": per_step[-1],
-        # every timed round in the order it ran, and which of them sat on the slow plateau (> 1 % over the fastest round:
-        # the two half-batch chains of a step have a fast and a slow phase relation)
-        "ms_per_step_rounds": in_order, "slow_rounds": [bool(v > 1.01 * per_step[0]) for v in in_order],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "48ch batch16 3x48x48->3x192x192 fp32 LarvaNet x4 train_step_larva M4 B4,4,4,4 per GPU "
-                               "(BASELINE config 2 at the reference's only channel count)",
-                   "global_batch": BATCH * world, "parallelism": "dp%d" % world,
-                   "inputs": ("fresh device tensors handed to train_step_larva every step (copied into the captured step's inputs)"
-                              if ref_semantics or bufs is None else "resident in the captured step's input buffers"),
-                   "loss_sync_per_step": bool(ref_semantics), "hip_graph": bool(model.use_hip_graph),
-                   "dual_chain": bool(model.dual_chain), "hip_graph_fell_back": model.hip_graph_fell_back,
-                   "final_loss": final_loss},
-        "rounds": {"n": rounds, "steps_each": a.steps, "ms_per_step_median": ms_per_step,
-                   "ms_per_step_min": per_step[0], "ms_per_step_max": per_step[-1],
-                   "value_is": "median round (max over ranks of each round's wall time)"},
-    }
+    line = headline_record(a, world, [s / a.steps * 1e3 for s in secs], settle_steps, float(loss), ref_semantics,
+                           model.use_hip_graph, model.dual_chain, model.hip_graph_fell_back, resident=bufs is not None and not ref_semantics)
+    ms_per_step = line["ms_per_step"]
+    line["sections_s"] = sections
     if world > 1:
         line["rccl_ranks"] = td.get_world_size() if td.get_backend() == "nccl" else 0
         line["dist_backend"] = td.get_backend()
@@ -1105,22 +1217,18 @@ def main():
             # every rank's own ms_per_step (median round): a straggler or an exposed collective shows here
             per = [float(np.median([s / a.steps * 1e3 for s in r])) for r in timed_rounds.per_rank]
             line["ms_per_step_per_rank"] = {"min": min(per), "max": max(per), "ranks": per}
-        line["wgrad_schedule"] = ("data parallel, chosen at prepare() from a timed isolated all-reduce of the bucket (`dp_schedule`): "
-                                  "`split` = the deferred weight gradients go out as two launch groups (the layers of the bucket's "
-                                  "upper ~80 %, then the rest + the head) so that the first group's slice is all-reduced beside the "
-                                  "second group's kernels (`dp_schedule_1gpu` in the N = 1 line prices that schedule without "
-                                  "collectives); `flat` = the single-GPU step's one grid + ONE collective after backward")
 
-    # the whole step against the fp32 matrix peak: the only fraction tied to the driver-timed number
+    # the whole step against the fp32 matrix peak: the only fraction tied to the driver-timed number.  SURVEY 8(d):
+    # forward 40 C->C convs + head, backward dgrad + wgrad per C->C conv + the head's wgrad (elementwise work excluded)
     flop_step = (2 * sum(BLOCKS) + 2 * len(BLOCKS)) * 3 * conv_flop(CH) + 2 * (2 * 9 * 3 * CH * BATCH * PATCH * PATCH)
     line["step"] = {"flop_per_step": flop_step, "achieved": flop_step / (ms_per_step * 1e-3) / 1e12, "unit": "TFLOP/s",
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "frac_of_peak": flop_step / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                    "what": "SURVEY 8(d): forward 40 C->C convs + head, backward dgrad + wgrad per C->C conv + the head's wgrad "
-                            "(elementwise work excluded) over the timed ms_per_step of one rank"}
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "frac_of_peak": flop_step / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    extras = world == 1 and a.extras and not a.no_extras
+    basic = world == 1 and not a.no_extras
 
     # The clock the chip sustains under this load (the guide's 157.3 TFLOP/s is 2.4 GHz): one napping wave on a side stream
     # counts shader cycles against the 100 MHz wall clock while 40 more steps run (measurement library; untimed).
-    if world == 1 and not a.no_extras:
+    if extras:
         D = diag_lib()
         if D is not None:
             try:
@@ -1138,50 +1246,72 @@ def main():
                     ghz = cycles / ticks * 0.1
                     line["step"]["sustained_clock_ghz"] = ghz
                     line["step"]["frac_of_peak_at_sustained_clock"] = line["step"]["frac_of_peak"] * 2.4 / ghz
-                    line["step"]["sustained_clock_is"] = ("s_memtime cycles / s_memrealtime ticks of one napping wave beside 30 ms of the "
-                                                          "timed loop (larva_clock_probe, measurement library); the guide's peak is quoted at 2.4 GHz")
             except Exception as e:   # an extra: never costs the line
                 line["step"]["sustained_clock_error"] = "%s: %s" % (type(e).__name__, e)
 
-    # the REQUIRED blocks first (inference forward, `roofline`, the isolated weight-gradient pair): a fault inside a later
-    # extra then cannot cost the line its roofline
-    with torch.no_grad():
-        for _ in range(5):
-            model.fwd_runtime(x)
-        runs = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(20):
-                model.fwd_runtime(x)
-            torch.cuda.synchronize()
-            runs.append((time.perf_counter() - t0) / 20 * 1e3)
-        infer_ms = sorted(runs)[1]
-    single = roofline_block(dev)
-    dual = roofline_block(dev, full=False, dual=True) if model.dual_chain else None
+    # the REQUIRED block first (`roofline`): a fault inside a later block then cannot cost the line its roofline
+    t0 = time.perf_counter()
+    dual = roofline_block(dev, dual=True, extras=extras) if model.dual_chain else None
     # the dominant kernel as the step runs it: the pair of strip-tile launches when the layer chain
     # runs as two half-batch chains, else the whole-batch launch
-    line["roofline"] = dual if dual is not None else single
-    line["roofline_single_chain"] = single
-    iso = wgrad_block(dev)
-    line["roofline_wgrad"] = iso
-    extras = world == 1 and not a.no_extras
-    if extras and ref_semantics and bufs is not None:
-        # round 2's headline, now an extra: no per-step loss.item() (the loss comes back as a device scalar) and the
-        # batch already resident in the captured step's input buffers (what dataloaders/device_patch_loader does)
-        def async_resident():
-            model.sync_loss = False
-            try:
-                secs2, _ = timed_rounds(model, args, val, bufs[0], bufs[1], a.steps, min(rounds, 3), False)
-            finally:
-                model.sync_loss = True
-            ms2 = float(np.median([s / a.steps * 1e3 for s in secs2]))
-            return {"value": HR_PIX_PER_BATCH / (ms2 * 1e-3) / 1e6, "unit": "HR Mpixels/s", "ms_per_step": ms2,
-                    "what": "--async_loss loop: loss returned as a device scalar, batch written straight into "
-                            "the captured step's input buffers by a device-side producer"}
-        guarded(line, "value_async_resident", async_resident)
+    line["roofline"] = dual if dual is not None else roofline_block(dev, dual=False, extras=extras)
+    section("roofline", t0)
+    if basic:
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(5):
+                model.fwd_runtime(x)
+            runs = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    model.fwd_runtime(x)
+                torch.cuda.synchronize()
+                runs.append((time.perf_counter() - t1) / 20 * 1e3)
+            infer_ms = sorted(runs)[1]
+        infer_flop = infer_flop_per_lr_pixel(BLOCKS, CH, v2=False) * BATCH * PATCH * PATCH     # 52.08 GFLOP
+        line["infer"] = {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
+                         "unit": "HR Mpixels/s", "flop": infer_flop,
+                         "frac_of_peak": infer_flop / (infer_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+        section("infer", t0)
+
+        # priced, like `roofline`, on what the STEP pays: the captured forward+backward with and without its
+        # weight-gradient launches (the back-to-back loop of the launch pair alone -- clock pulled down by sustained
+        # fp32-MFMA load, operands streamed cold from HBM every replay -- is the `isolated_loop` extra)
+        def wgrad_in_the_step():
+            ins = wgrad_in_step(model, x, truth)
+            per_layer, tsrc = wgrad_traffic_per_layer()
+            blk = {"bound": "mfma", "achieved": ins["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ins["frac"],
+                   "kernel": "wgrad3x3_pipe_flat_kernel<48, 48> (one grid of 256 workgroups over the step's 40 layers + the 3->48 head) "
+                             "+ wgrad_reduce_kernel, 16x48x48x48 fp32",
+                   "ms_all_weight_gradients": ins["ms_all_weight_gradients"], "flop": ins["flop"], "layers": ins["layers"],
+                   "traffic": per_layer * ins["layers"], "traffic_source": tsrc, "timing": ins["what"], "in_step": ins}
+            if extras:
+                blk["isolated_loop"] = wgrad_block(dev)
+            return blk
+        t0 = time.perf_counter()
+        guarded(line, "roofline_wgrad", wgrad_in_the_step)
+        section("roofline_wgrad", t0)
+    elif world > 1:
+        line["roofline_wgrad"] = wgrad_block(dev)
 
     if extras:
+        t0 = time.perf_counter()
+        line["roofline_single_chain"] = roofline_block(dev, dual=False, extras=True, sets=3)
+        if ref_semantics and bufs is not None:
+            # round 2's headline, now an extra: no per-step loss.item() (the loss comes back as a device scalar) and the
+            # batch already resident in the captured step's input buffers (what dataloaders/device_patch_loader does)
+            def async_resident():
+                model.sync_loss = False
+                try:
+                    secs2, _ = timed_rounds(model, args, val, bufs[0], bufs[1], a.steps, min(rounds, 3), False)
+                finally:
+                    model.sync_loss = True
+                ms2 = float(np.median([s / a.steps * 1e3 for s in secs2]))
+                return {"value": HR_PIX_PER_BATCH / (ms2 * 1e-3) / 1e6, "unit": "HR Mpixels/s", "ms_per_step": ms2}
+            guarded(line, "value_async_resident", async_resident)
+
         # The weight-gradient schedule a data-parallel rank runs (two launch groups instead of one flat grid, DESIGN
         # section 5) on this one GPU: wall and HOST time per step of both schedules without a communicator
         # (`dp_schedule_1gpu`), and the same under a one-rank RCCL communicator (`rccl_world1`: the collectives really
@@ -1194,15 +1324,9 @@ def main():
                      split_costs_us=(r["split"]["ms_per_step"] - r["flat"]["ms_per_step"]) * 1e3)
             return r
         guarded(line, "dp_schedule_1gpu", dp_schedule)
+        # (ONE rank: a rehearsal of the backend="nccl" code path on the one GPU of this box, NOT a scaling measurement)
+        guarded(line, "rccl_world1", lambda: run_dp_probe(a, True))
 
-        def rccl_world1():
-            r = run_dp_probe(a, True)
-            r["note"] = ("ONE rank: a rehearsal of the backend=\"nccl\" code path on the one GPU of this box (every collective is "
-                         "issued and waited for, a sum over one rank is the identity), NOT a scaling measurement")
-            return r
-        guarded(line, "rccl_world1", rccl_world1)
-
-    if extras:
         # BASELINE configs 2 / 5 name 32- and 64-channel bodies, which the reference cannot express:
         # the same M4B4 network built with --num_filters (every leg's last conv kept at 48 outputs), same batch,
         # same loop semantics.  Extras: the headline stays the reference's 48-channel network.
@@ -1221,54 +1345,38 @@ def main():
                 for _ in range(5):
                     mw.fwd_runtime(x_fresh)
                 torch.cuda.synchronize()
-                t0 = time.perf_counter()
+                t1 = time.perf_counter()
                 for _ in range(20):
                     mw.fwd_runtime(x_fresh)
                 torch.cuda.synchronize()
-                inf_w = (time.perf_counter() - t0) / 20 * 1e3
+                inf_w = (time.perf_counter() - t1) / 20 * 1e3
             cc = (2 * sum(BLOCKS) + len(BLOCKS)) * conv_flop(nf) + len(BLOCKS) * 2 * 9 * nf * 48 * BATCH * PATCH * PATCH
             flop_w = 3 * cc + 2 * (2 * 9 * 3 * nf * BATCH * PATCH * PATCH)
             return {"train_ms_per_step": ms_w, "value": HR_PIX_PER_BATCH / (ms_w * 1e-3) / 1e6, "unit": "HR Mpixels/s",
                     "flop_per_step": flop_w, "frac_of_peak": flop_w / (ms_w * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                    "infer_ms_per_batch": inf_w, "hip_graph_fell_back": mw.hip_graph_fell_back,
-                    "what": "LarvaNet x4 M4B4 with --num_filters=%d (build-side extension, no reference counterpart)" % nf}
+                    "infer_ms_per_batch": inf_w, "hip_graph_fell_back": mw.hip_graph_fell_back}
         line["other_widths"] = {}
         for nf in (32, 64):
             guarded(line["other_widths"], "num_filters_%d" % nf, lambda nf=nf: width(nf))
-
-    if extras:
-        # priced, like `roofline`, on what the STEP pays: the captured forward+backward with and without its
-        # weight-gradient launches; the back-to-back loop of the launch pair alone (clock pulled down by
-        # sustained fp32-MFMA load, operands streamed cold from HBM every replay) stays beside it
-        def wgrad_in_the_step():
-            ins = wgrad_in_step(model, x, truth)
-            return {
-                "bound": "mfma", "achieved": ins["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ins["frac"],
-                "kernel": "all weight-gradient launches of the step: " + iso["kernel"].replace(", 16x48x48x48 fp32", "") +
-                          " with the 3 -> 48 head's tiles as the tail of the grid, 16x48x48x48 fp32",
-                "ms_all_weight_gradients": ins["ms_all_weight_gradients"], "flop": ins["flop"], "layers": ins["layers"],
-                "traffic": iso.get("traffic"), "traffic_source": iso.get("traffic_source"),
-                "timing": ins["what"], "in_step": ins, "isolated_loop": iso}
-        guarded(line, "roofline_wgrad", wgrad_in_the_step)
         guarded(line["roofline"], "in_step", chains_in_step)
-        if "error" in line["roofline_wgrad"]:
-            line["roofline_wgrad"] = dict(iso, in_step_error=line["roofline_wgrad"]["error"])
-    infer_flop = infer_flop_per_lr_pixel(BLOCKS, CH, v2=False) * BATCH * PATCH * PATCH     # 52.08 GFLOP
-    line["infer"] = {"ms_per_batch": infer_ms, "value": HR_PIX_PER_BATCH / (infer_ms * 1e-3) / 1e6,
-                     "unit": "HR Mpixels/s", "flop": infer_flop,
-                     "frac_of_peak": infer_flop / (infer_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
-    if extras:
+
         def two_chain(c):   # two half-batch strip chains, like the 48-channel layer; else one chain
-            blk = roofline_block(dev, c, full=False, dual=True)
-            return blk if blk is not None else roofline_block(dev, c, full=False)
+            blk = roofline_block(dev, c, dual=True, sets=3)
+            return blk if blk is not None else roofline_block(dev, c, dual=False, sets=3)
         for c in (32, 64):
             guarded(line, "roofline_c%d" % c, lambda c=c: two_chain(c))
-            guarded(line, "roofline_c%d_single_chain" % c, lambda c=c: roofline_block(dev, c, full=False))
+            guarded(line, "roofline_c%d_single_chain" % c, lambda c=c: roofline_block(dev, c, dual=False, sets=3))
             guarded(line, "roofline_wgrad_c%d" % c, lambda c=c: wgrad_block(dev, c))
+        section("extras", t0)
+    if basic:
         del model
-        guarded(line, "infer_full_image", lambda: full_image_block(dev))
+        t0 = time.perf_counter()
+        guarded(line, "infer_full_image", lambda: full_image_block(dev, extras=extras))
+        section("infer_full_image", t0)
     if world == 1 and not a.no_cpu_baseline:
+        t0 = time.perf_counter()
         line["cpu_baseline"] = cpu_baseline()
+        sections["cpu_baseline"] = round(time.perf_counter() - t0, 3)
     if guarded.fault is not None:
         line["gpu_fault"] = guarded.fault
     emit(line)

@@ -1344,13 +1344,8 @@ template <int COUT, bool VEC, int EPI>
 static hipError_t launch_conv_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
   using C = ConvCfg<COUT>;
   constexpr size_t lds = VEC ? C::LDS_BYTES_DMA : C::LDS_BYTES_REG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<COUT, VEC, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce lds_set;
+  if (const hipError_t e = ensure_dynamic_lds(lds_set, reinterpret_cast<const void*>(conv3x3_mfma_kernel<COUT, VEC, EPI>), lds); e != hipSuccess) return e;
   const int grid = a.N * a.tiles_x * a.tiles_y;
   constexpr int threads = VEC ? C::THREADS_DMA : 256;
   if (tm)
@@ -1365,13 +1360,8 @@ template <int COUT, int EPI>
 static hipError_t launch_rows4_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
   using C = ConvCfg<COUT, GeoWide4>;
   constexpr size_t lds = C::LDS_BYTES_DMA;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_rows4_kernel<COUT, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce lds_set;
+  if (const hipError_t e = ensure_dynamic_lds(lds_set, reinterpret_cast<const void*>(conv3x3_mfma_rows4_kernel<COUT, EPI>), lds); e != hipSuccess) return e;
   if (tm)
     hipExtLaunchKernelGGL((conv3x3_mfma_rows4_kernel<COUT, EPI>), dim3(a.nwg), dim3(C::THREADS_DMA), lds, stream,
                           tm->start, tm->stop, 0, a);
@@ -1381,28 +1371,14 @@ static hipError_t launch_rows4_e(const ConvArgs& a, hipStream_t stream, const La
 }
 
 // workgroup slots of the device for the 16-byte-path kernels (kWgPerCu per CU)
-static int conv_slots() {
-  static int slots = 0;
-  if (!slots) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-    slots = kWgPerCu * cus;
-  }
-  return slots;
-}
+static int conv_slots() { return kWgPerCu * device_cu_count(); }
 
 template <int COUT, int EPI>
 static hipError_t launch_persist_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
   using C = ConvCfg<COUT>;
   constexpr size_t lds = C::LDS_BYTES_DMA;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_persist_kernel<COUT, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce lds_set;
+  if (const hipError_t e = ensure_dynamic_lds(lds_set, reinterpret_cast<const void*>(conv3x3_mfma_persist_kernel<COUT, EPI>), lds); e != hipSuccess) return e;
   const int grid = a.nwg < conv_slots() ? a.nwg : conv_slots();
   if (tm)
     hipExtLaunchKernelGGL((conv3x3_mfma_persist_kernel<COUT, EPI>), dim3(grid), dim3(C::THREADS_DMA), lds, stream, tm->start, tm->stop, 0, a);
@@ -1464,13 +1440,8 @@ static hipError_t launch_conv(const ConvArgs& a, bool vec, int epi, hipStream_t 
 template <int COUT, int EPI>
 static hipError_t launch_batch_e(const ConvBatch& b, int njobs, hipStream_t stream) {
   using C = ConvCfg<COUT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_batch_kernel<COUT, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES_DMA);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce lds_set;
+  if (const hipError_t e = ensure_dynamic_lds(lds_set, reinterpret_cast<const void*>(conv3x3_mfma_batch_kernel<COUT, EPI>), C::LDS_BYTES_DMA); e != hipSuccess) return e;
   const ConvArgs& a = b.job[0];
   hipLaunchKernelGGL((conv3x3_mfma_batch_kernel<COUT, EPI>), dim3(a.N * a.tiles_x * a.tiles_y, njobs),
                      dim3(C::THREADS_DMA), C::LDS_BYTES_DMA, stream, b);
@@ -1496,14 +1467,9 @@ static hipError_t launch_batch(const ConvBatch& b, int njobs, int epi, hipStream
 
 template <int COUT, int EPI>
 static hipError_t launch_strip_e(const ConvArgs& a, hipStream_t stream, const LaunchTiming* tm) {
-  static bool attr_set = false;
   constexpr size_t lds = kStripLdsBytes<COUT>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_strip_kernel<COUT, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce lds_set;
+  if (const hipError_t e = ensure_dynamic_lds(lds_set, reinterpret_cast<const void*>(conv3x3_mfma_strip_kernel<COUT, EPI>), lds); e != hipSuccess) return e;
   if (tm)
     hipExtLaunchKernelGGL((conv3x3_mfma_strip_kernel<COUT, EPI>), dim3(a.nwg), dim3(320), lds, stream,
                           tm->start, tm->stop, 0, a);
@@ -1680,7 +1646,7 @@ static int conv_tile_rows(int N, int H, int pitch, int cout, int epi, bool align
   if (forced == 3 || !can4) return 3;
   if (forced == 4) return 4;
   const long long tiles3 = (long long)N * ((pitch + kTileCols - 1) / kTileCols) * ((H + 2) / 3);
-  return (cout == 32 && tiles3 > 512) ? 4 : 3;
+  return (cout == 32 && tiles3 > conv_slots()) ? 4 : 3;
 }
 
 static int conv_dispatch(const float* const* src, int n_src, int cin_per_src, const float* wpk,
@@ -1955,194 +1921,3 @@ int larva_diag_set_stamps(unsigned long long* buf) {
 #endif
 
 }  // extern "C"
-
-#ifdef LARVA_DIAG_API
-// Measurement entry points that are NOT part of liblarva_hip.so / include/larva_hip.h (tools/build_diag.sh builds
-// tools/_diag/<name>.so = the product's sources + these; declared in tools/larva_diag.h)
-extern "C" {
-// Measurement only (synchronises; not capturable): runs the same launch `iters` times with
-// kernel-attached events and returns the mean and minimum kernel duration in milliseconds.
-extern "C++" {
-template <typename Launch>
-static int timed_launches(int iters, float* mean_ms, float* min_ms, Launch launch) {
-  if (iters < 1 || !mean_ms || !min_ms) return (int)hipErrorInvalidValue;
-  LaunchTiming tm{};
-  hipError_t e = hipEventCreate(&tm.start);
-  if (e != hipSuccess) return (int)e;
-  e = hipEventCreate(&tm.stop);
-  if (e != hipSuccess) return (int)e;
-  double sum = 0.0;
-  float best = 1e30f;
-  int rc = 0;
-  for (int i = 0; i < iters && rc == 0; ++i) {
-    rc = launch(&tm);
-    if (rc) break;
-    e = hipEventSynchronize(tm.stop);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, tm.start, tm.stop);
-    if (e != hipSuccess) { rc = (int)e; break; }
-    sum += ms;
-    best = ms < best ? ms : best;
-  }
-  (void)hipEventDestroy(tm.start);
-  (void)hipEventDestroy(tm.stop);
-  *mean_ms = (float)(sum / iters);
-  *min_ms = best;
-  return rc;
-}
-}  // extern "C++"
-
-int larva_conv3x3_fwd_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                            const float* bias, const float* res0, const float* res1, const float* mask,
-                            const float* base, float* out, int N, int cout, int H, int W, int relu,
-                            int mode, void* stream, int iters, float* mean_ms, float* min_ms) {
-  return timed_launches(iters, mean_ms, min_ms, [&](const LaunchTiming* tm) {
-    return conv_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, 0, relu, mode,
-                         stream, tm);
-  });
-}
-
-// The same for a strip-tile launch (larva_conv3x3_fwd_strips): what a profiler reports for ONE half-batch launch
-// running alone, beside bench.py's time per layer with two such launches running concurrently.
-int larva_conv3x3_fwd_strips_timed(const float* const* src, int n_src, int cin_per_src, const float* wpk,
-                                   const float* bias, const float* res0, const float* res1, const float* mask,
-                                   const float* base, float* out, int N, int cout, int H, int W, int pitch,
-                                   int relu, int mode, const unsigned* tile_tab, const unsigned* tile_tab_host,
-                                   int tiles_per_image, int plain_stores, void* stream, int iters, float* mean_ms,
-                                   float* min_ms) {
-  return timed_launches(iters, mean_ms, min_ms, [&](const LaunchTiming* tm) {
-    return strips_dispatch(src, n_src, cin_per_src, wpk, bias, res0, res1, mask, base, out, N, cout, H, W, pitch, relu,
-                           mode, tile_tab, tile_tab_host, tiles_per_image, plain_stores, stream, tm);
-  });
-}
-
-}  // extern "C"
-#include "conv3x3_pair_chain.inc"
-#include "conv3x3_pipe.inc"
-extern "C" {
-// ---------------------------------------------------------------------------------------------
-// Layer pipeline (conv3x3_pipe.inc): a chain of 48 -> 48 convolutions over one [N][48][H][pitch] tensor shape in ONE
-// launch.  plan(): validates, builds the device-side layer table (synchronous copy: not for a captured region) and
-// fills the caller's host-side plan; run(): one memset node (the band counters) + the launch; stream-ordered,
-// allocation-free, capturable.  Every layer writes a tensor of its own; layer i reads tensors written before the launch
-// (dep = -1) or by layer dep < i.
-// ---------------------------------------------------------------------------------------------
-struct larva_pipe_layer_host {   // == larva_pipe_layer of include/larva_hip.h
-  const float* src[8];
-  int n_src, cin_per_src;
-  const float* wpk;
-  const float* bias;
-  const float* res0;
-  const float* res1;
-  float* out;
-  int relu, dep;
-};
-
-struct PipePlan {
-  unsigned magic;
-  int grid;
-  size_t ctr_bytes;
-  PipeArgs args;
-};
-constexpr unsigned kPipePlanMagic = 0x70697065u;
-
-static size_t pipe_ctr_bytes(int n_layers, int N, int H) {
-  return (size_t)n_layers * N * ((H + kTileRows - 1) / kTileRows) * kPipeCtrStride * sizeof(unsigned);
-}
-
-long long larva_conv3x3_pipeline_workspace_bytes(int n_layers, int N, int H) {
-  if (n_layers <= 0 || n_layers > kPipeMaxLayers || N <= 0 || H <= 0) return 0;
-  return (long long)(pipe_ctr_bytes(n_layers, N, H) + (size_t)n_layers * sizeof(PipeLayer) + 256);
-}
-
-long long larva_conv3x3_pipeline_plan_bytes(void) { return (long long)sizeof(PipePlan); }
-
-int larva_conv3x3_pipeline_plan(const void* layers_v, int n_layers, int N, int cout, int H, int W, int pitch,
-                                void* workspace, unsigned* error_word, void* plan_v) {
-  const larva_pipe_layer_host* layers = static_cast<const larva_pipe_layer_host*>(layers_v);
-  if (!layers || !workspace || !error_word || !plan_v || n_layers <= 0 || n_layers > kPipeMaxLayers || cout != 48)
-    return (int)hipErrorInvalidValue;
-  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return (int)hipErrorInvalidValue;
-  if ((long long)48 * H * (pitch ? pitch : W) * 4 >= (1ll << 31)) return (int)hipErrorNotSupported;   // 32-bit byte offsets inside one image
-  PipePlan* plan = static_cast<PipePlan*>(plan_v);
-  PipeLayer table[kPipeMaxLayers];
-  ConvArgs shape{};
-  for (int i = 0; i < n_layers; ++i) {
-    const larva_pipe_layer_host& l = layers[i];
-    ConvArgs a;
-    bool aligned;
-    int epi;
-    const int rc = conv_build(l.src, l.n_src, l.cin_per_src, l.wpk, l.bias, l.res0, l.res1, nullptr, nullptr, l.out, N, H, W,
-                              pitch, l.relu, 0, a, aligned, epi);
-    if (rc) return rc;
-    if (!aligned) return (int)hipErrorNotSupported;   // (the 16-byte LDS-DMA path only)
-    if (l.dep < -1 || l.dep >= i) return (int)hipErrorInvalidValue;
-    // every operand written inside the launch is the output of layer dep or of a layer dep waits for (through its own
-    // dep, and so on): only dep's band counters are polled, the older producers are done by transitivity
-    {
-      bool anc[kPipeMaxLayers] = {};
-      for (int d = l.dep; d >= 0; d = layers[d].dep) anc[d] = true;
-      auto ok = [&](const float* t) {
-        for (int j = 0; j < n_layers; ++j)
-          if (t && layers[j].out == t && !(j < i && anc[j])) return false;
-        return true;
-      };
-      for (int k = 0; k < l.n_src; ++k)
-        if (!ok(l.src[k])) return (int)hipErrorInvalidValue;
-      if (!ok(l.res0) || !ok(l.res1)) return (int)hipErrorInvalidValue;
-    }
-    // every output is a tensor of its own (nothing is overwritten while the launch may still read it)
-    for (int j = 0; j < n_layers; ++j)
-      if (j != i && layers[j].out == l.out) return (int)hipErrorInvalidValue;
-    PipeLayer& t = table[i];
-    t = PipeLayer{};
-    for (int k = 0; k < kMaxSrc; ++k) t.src[k] = a.src[k];
-    t.wpk = a.wpk; t.bias = a.bias; t.res0 = a.res0; t.res1 = a.res1; t.out = a.out;
-    t.cin_per_src = a.cin_per_src; t.n_chunks = a.n_chunks; t.magic_cps = a.magic_cps;
-    t.epi = epi; t.dep = l.dep;
-    if (i == 0) shape = a;
-  }
-  shape.src[0] = nullptr; shape.wpk = nullptr; shape.bias = nullptr; shape.res0 = shape.res1 = nullptr; shape.out = nullptr;
-  char* ws = static_cast<char*>(workspace);
-  const size_t ctr_bytes = pipe_ctr_bytes(n_layers, N, H);
-  PipeLayer* table_dev = reinterpret_cast<PipeLayer*>(ws + ((ctr_bytes + 255) & ~(size_t)255));
-  hipError_t e = hipMemcpy(table_dev, table, (size_t)n_layers * sizeof(PipeLayer), hipMemcpyHostToDevice);
-  if (e != hipSuccess) return (int)e;
-  {
-    static bool attr_set = false;
-    if (!attr_set) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ConvCfg<48>::LDS_BYTES_DMA);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
-  }
-  plan->magic = kPipePlanMagic;
-  plan->ctr_bytes = ctr_bytes;
-  const long long positions = (long long)n_layers * shape.nwg;
-  plan->grid = positions < conv_slots() ? (int)positions : conv_slots();
-  plan->args = PipeArgs{};
-  plan->args.a = shape;
-  plan->args.layers = table_dev;
-  plan->args.done = reinterpret_cast<unsigned*>(ws);
-  plan->args.error = error_word;
-  plan->args.n_layers = n_layers;
-  plan->args.spin_limit = 1 << 20;
-  return 0;
-}
-
-// spin_limit: polls a wait may take before it gives up and sets the error word (0: the default, about two seconds)
-int larva_conv3x3_pipeline_run(const void* plan_v, int spin_limit, void* stream) {
-  const PipePlan* plan = static_cast<const PipePlan*>(plan_v);
-  if (!plan || plan->magic != kPipePlanMagic) return (int)hipErrorInvalidValue;
-  hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(plan->args.done, 0, plan->ctr_bytes, s);
-  if (e != hipSuccess) return (int)e;
-  PipeArgs args = plan->args;
-  if (spin_limit > 0) args.spin_limit = spin_limit;
-  hipLaunchKernelGGL(conv3x3_pipe_kernel, dim3(plan->grid), dim3(ConvCfg<48>::THREADS_DMA), ConvCfg<48>::LDS_BYTES_DMA, s, args);
-  return (int)hipGetLastError();
-}
-
-}  // extern "C"
-#endif

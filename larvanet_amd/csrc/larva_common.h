@@ -24,6 +24,39 @@ constexpr int kMaxSrc = 8;                                 // channel-concatenat
 // LDS row stride of a staged halo row (floats): idx 3 = x0-1, idx 4..51 = x0..x0+47, idx 52 = x0+48.
 constexpr int kRS = 56;
 
+// Host-side launch helpers are PER DEVICE: hipFuncSetAttribute applies to the current device's copy of a kernel, and the
+// number of workgroup slots is a property of the device a launch goes to.  A process that drives a second GPU must not
+// reuse the first one's slot count or skip the second one's LDS-size attribute.
+constexpr int kMaxDevices = 64;
+inline int current_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+  return d < kMaxDevices ? d : kMaxDevices - 1;   // (ids past the table share its last slot: they repeat the set-up, harmlessly)
+}
+struct PerDeviceOnce {
+  bool done[kMaxDevices] = {};
+};
+// hipFuncSetAttribute(kernel, MaxDynamicSharedMemorySize, lds) once per device and kernel instantiation
+inline hipError_t ensure_dynamic_lds(PerDeviceOnce& once, const void* kernel, size_t lds) {
+  const int d = current_device_slot();
+  if (once.done[d] && d != kMaxDevices - 1) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) once.done[d] = true;
+  return e;
+}
+// compute units of the current device (cached per device; 256 = MI355X if the query fails)
+inline int device_cu_count() {
+  static int cus[kMaxDevices] = {};
+  const int d = current_device_slot();
+  if (!cus[d] || d == kMaxDevices - 1) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus[d] = n;
+  }
+  return cus[d];
+}
+
 __host__ __device__ constexpr int cout_stride(int cout) {
   // Row stride (floats) of one [k][cout] weight row in LDS.  The two 16-lane halves of a 32-lane ds_read_b32 group
   // read rows k and k + 1: they must land on disjoint banks.  cout == 16 (mod 32): the stride itself does it.

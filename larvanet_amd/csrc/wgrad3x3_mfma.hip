@@ -1213,33 +1213,24 @@ static hipError_t launch_wgrad(const WgradBatch& b, int njobs, int splits, hipSt
   if constexpr (kPipeHalves<COUT, CIN> == 2) {
     if (b.vec_ok && wgrad_use_pipe()) {
       using P2 = WgPipe<COUT, CIN / 2>;
-      static bool attr2_set = false;
-      if (!attr2_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_pipe_kernel<COUT, CIN / 2>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P2::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr2_set = true;
-      }
+      static PerDeviceOnce lds_half;
+      if (const hipError_t e = ensure_dynamic_lds(lds_half, reinterpret_cast<const void*>(wgrad3x3_pipe_kernel<COUT, CIN / 2>), P2::LDS_BYTES);
+          e != hipSuccess)
+        return e;
       WgradBatch b2 = b;
       b2.halves = 2;
       hipLaunchKernelGGL((wgrad3x3_pipe_kernel<COUT, CIN / 2>), dim3(splits, njobs), dim3(256), P2::LDS_BYTES, stream, b2);
       return hipGetLastError();
     }
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    if constexpr (P::FITS) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_pipe_kernel<COUT, CIN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::LDS_BYTES);
-      if (e != hipSuccess) return e;
-    }
-    attr_set = true;
+  static PerDeviceOnce lds_a, lds_b, lds_c;
+  if (const hipError_t e = ensure_dynamic_lds(lds_a, reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, true>), C::LDS_BYTES); e != hipSuccess)
+    return e;
+  if (const hipError_t e = ensure_dynamic_lds(lds_b, reinterpret_cast<const void*>(wgrad3x3_kernel<COUT, CIN, false>), C::LDS_BYTES); e != hipSuccess)
+    return e;
+  if constexpr (P::FITS) {
+    if (const hipError_t e = ensure_dynamic_lds(lds_c, reinterpret_cast<const void*>(wgrad3x3_pipe_kernel<COUT, CIN>), P::LDS_BYTES); e != hipSuccess)
+      return e;
   }
   if constexpr (P::FITS) {
     if (b.vec_ok && wgrad_use_pipe()) {
@@ -1258,13 +1249,10 @@ template <int COUT, int CIN>
 static hipError_t launch_wgrad_flat(const WgradBatch& b, int nwg, hipStream_t stream) {
   using P = WgPipe<COUT, CIN>;
   static_assert(P::FITS, "the flat launch exists for the pipelined kernel only");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_pipe_flat_kernel<COUT, CIN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce lds_set;
+  if (const hipError_t e = ensure_dynamic_lds(lds_set, reinterpret_cast<const void*>(wgrad3x3_pipe_flat_kernel<COUT, CIN>), P::LDS_BYTES);
+      e != hipSuccess)
+    return e;
   hipLaunchKernelGGL((wgrad3x3_pipe_flat_kernel<COUT, CIN>), dim3(nwg), dim3(256), P::LDS_BYTES, stream, b);
   return hipGetLastError();
 }

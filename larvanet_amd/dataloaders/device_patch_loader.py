@@ -6,10 +6,17 @@ reference (image, x, y, rot90 k in 1..4, flip p = .5) from a per-rank RandomStat
 made on the host (80 integers per batch) and shipped as one small tensor.
 
 Source of the images: any loader plugin with get_image_pair() (--device_source, default
-div2k_train_loader; `synthetic_loader` for tests and benchmarks)."""
+div2k_train_loader; `synthetic_loader` for tests and benchmarks).
+
+Data parallel start-up is O(1) in the world size: RANK 0 decodes the dataset once (a thread pool over the source's
+get_image_pair: PIL's PNG decoder releases the GIL) and the uint8 image tables + offset / size tables are BROADCAST to the
+other ranks' HBM (dist.broadcast_tensor: RCCL over xGMI, ~5 GB once) -- eight ranks of one host do not decode 800 PNG
+pairs eight times.  Every rank keeps its own draw stream (seed + 1000 rank)."""
 import argparse
 import copy
 import importlib
+import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -47,6 +54,64 @@ def apply_draw_numpy(draw, lr, hr, scale, p):
     return np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
 
 
+def decode_workers():
+    """Threads of the one-time decode: this process's share of the host (dist.host_threads), at most 32."""
+    return max(1, min(32, int(os.environ.get("LARVA_DECODE_THREADS", ldist.host_threads()))))
+
+
+def build_host_tables(source, scales, workers=1):
+    """Decode every image pair of `source` once -> ({scale: {"lr", "hr": uint8 [bytes], "lr_off", "hr_off": int64 [n],
+    "lr_hw", "hr_hw": int32 [2n]}}, [(lr_h, lr_w)] of the first scale).  Images are rounded / clipped to uint8 exactly as
+    the sampler's kernel expects them (PNG sources are uint8-valued already).  Host only: runs on rank 0."""
+    n = source.get_num_images()
+    shapes, tables = [], {}
+    for scale in scales:
+        def one(i, scale=scale):
+            lr, hr, _ = source.get_image_pair(i, scale)
+            return (np.ascontiguousarray(np.clip(np.round(lr), 0, 255).astype(np.uint8)),
+                    np.ascontiguousarray(np.clip(np.round(hr), 0, 255).astype(np.uint8)))
+        if workers > 1 and n > 1:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                pairs = list(pool.map(one, range(n)))      # (map keeps the image order)
+        else:
+            pairs = [one(i) for i in range(n)]
+        lr_off = np.zeros(n, np.int64)
+        hr_off = np.zeros(n, np.int64)
+        lr_off[1:] = np.cumsum([p[0].size for p in pairs])[:-1]
+        hr_off[1:] = np.cumsum([p[1].size for p in pairs])[:-1]
+        tables[scale] = {
+            "lr": np.concatenate([p[0].ravel() for p in pairs]), "hr": np.concatenate([p[1].ravel() for p in pairs]),
+            "lr_off": lr_off, "hr_off": hr_off,
+            "lr_hw": np.asarray([d for p in pairs for d in p[0].shape[1:]], np.int32),
+            "hr_hw": np.asarray([d for p in pairs for d in p[1].shape[1:]], np.int32)}
+        if scale == scales[0]:
+            shapes = [tuple(int(d) for d in p[0].shape[1:]) for p in pairs]
+    return tables, shapes
+
+
+TABLE_DTYPES = {"lr": torch.uint8, "hr": torch.uint8, "lr_off": torch.int64, "hr_off": torch.int64,
+                "lr_hw": torch.int32, "hr_hw": torch.int32}
+
+
+def share_tables(host_tables, shapes, scales, device):
+    """Rank 0's decoded tables -> device tensors on EVERY rank.  Without a communicator: a plain upload.  With one: rank 0
+    announces the table sizes (one small object broadcast), every rank allocates, and each table travels as one
+    tensor broadcast from rank 0 (host_tables / shapes are None on the other ranks)."""
+    if not ldist.active():
+        return ({s: {k: torch.from_numpy(v).to(device) for k, v in t.items()} for s, t in host_tables.items()}, shapes)
+    main = ldist.is_main()
+    meta = ldist.broadcast_object(({s: {k: int(v.size) for k, v in host_tables[s].items()} for s in scales}, shapes) if main else None)
+    sizes, shapes = meta
+    out = {}
+    for s in scales:
+        out[s] = {}
+        for k in ("lr", "hr", "lr_off", "hr_off", "lr_hw", "hr_hw"):
+            t = (torch.from_numpy(host_tables[s][k]).to(device) if main
+                 else torch.empty(sizes[s][k], dtype=TABLE_DTYPES[k], device=device))
+            out[s][k] = ldist.broadcast_tensor(t, src=0)
+    return out, [tuple(hw) for hw in shapes]
+
+
 class DevicePatchLoader(BaseLoader):
     is_device = True
 
@@ -69,31 +134,14 @@ class DevicePatchLoader(BaseLoader):
         self.scale_list = scales
         self.source.prepare(scales)
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.shapes, self.tables = [], {}
         seed = self.args.data_seed
         self.rng = np.random.RandomState(None if seed is None else ldist.seed_for_rank(seed))
-        n = self.source.get_num_images()
-        for scale in scales:
-            lr_chunks, hr_chunks, lr_off, hr_off, lr_hw, hr_hw = [], [], [], [], [], []
-            lo = ho = 0
-            for i in range(n):
-                lr, hr, _ = self.source.get_image_pair(i, scale)
-                lr8 = np.ascontiguousarray(np.clip(np.round(lr), 0, 255).astype(np.uint8))
-                hr8 = np.ascontiguousarray(np.clip(np.round(hr), 0, 255).astype(np.uint8))
-                lr_chunks.append(lr8.ravel()); hr_chunks.append(hr8.ravel())
-                lr_off.append(lo); hr_off.append(ho)
-                lo += lr8.size; ho += hr8.size
-                lr_hw += [lr8.shape[1], lr8.shape[2]]; hr_hw += [hr8.shape[1], hr8.shape[2]]
-                if scale == scales[0]:
-                    self.shapes.append((lr8.shape[1], lr8.shape[2]))
-
-            def dev(a, dt):
-                return torch.from_numpy(np.asarray(a, dtype=dt)).to(self.device)
-
-            self.tables[scale] = {
-                "lr": dev(np.concatenate(lr_chunks), np.uint8), "hr": dev(np.concatenate(hr_chunks), np.uint8),
-                "lr_off": dev(lr_off, np.int64), "hr_off": dev(hr_off, np.int64),
-                "lr_hw": dev(lr_hw, np.int32), "hr_hw": dev(hr_hw, np.int32)}
+        # decode once (rank 0, thread pool), broadcast to the other ranks' HBM
+        host, shapes = (build_host_tables(self.source, scales, decode_workers())
+                        if (ldist.is_main() or not ldist.active()) else (None, None))
+        self.tables, self.shapes = share_tables(host, shapes, scales, self.device)
+        del host
+        n = len(self.shapes)
         print("data: %d image pairs resident on %s (%.1f MB)" % (
             n, self.device, sum(t["lr"].numel() + t["hr"].numel() for t in self.tables.values()) / 1e6))
 

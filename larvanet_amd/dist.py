@@ -53,19 +53,9 @@ def init_from_env(backend=None):
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if is_initialized() or (ws <= 1 and not forced()):
         return rank(), world_size()
-    if ws <= 1:
-        # forced one-rank communicator (see forced()): a rendezvous of its own on the loopback
-        import socket
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("LOCAL_RANK", "0")
-        os.environ["WORLD_SIZE"] = "1"
-        if "MASTER_PORT" not in os.environ:
-            s = socket.socket()
-            s.bind(("127.0.0.1", 0))
-            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
-            s.close()
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if ws > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     ndev = torch.cuda.device_count()   # (counting devices does not initialise the runtime)
     use_gpu = ndev > 0
     # LARVA_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
@@ -77,7 +67,16 @@ def init_from_env(backend=None):
                                "(one process per GPU; LARVA_DIST_BACKEND=gloo rehearses more ranks than GPUs)"
                                % (local, ndev))
         torch.cuda.set_device(local % ndev)
-    td.init_process_group(backend=backend)
+    if ws <= 1:
+        # forced one-rank communicator (see forced()): a rendezvous of its own through a FileStore created in-process --
+        # no port to race for, and nothing exported into os.environ (a child started later must not look like a torchrun rank)
+        import tempfile
+        fd, path = tempfile.mkstemp(prefix="larva_rdzv_")
+        os.close(fd)
+        os.unlink(path)    # (FileStore creates the file itself and removes it when the last reference goes)
+        td.init_process_group(backend=backend, store=td.FileStore(path, 1), rank=0, world_size=1)
+    else:
+        td.init_process_group(backend=backend)
     return rank(), world_size()
 
 
@@ -92,6 +91,62 @@ def broadcast_parameters(module, src=0):
     td.broadcast(flat, src=src)
     for t, synced in zip(tensors, torch._utils._unflatten_dense_tensors(flat, tensors)):
         t.copy_(synced)
+
+
+def broadcast_object(obj, src=0):
+    """Rank `src`'s (small, picklable) python object on every rank."""
+    if not active():
+        return obj
+    box = [obj if rank() == src else None]
+    td.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def broadcast_tensor(t, src=0):
+    """In-place broadcast of rank `src`'s tensor (same shape / dtype allocated on every rank) -> t.  One collective over
+    RCCL for device tensors; under gloo (the CPU rehearsal, or LARVA_DIST_BACKEND=gloo with HIP tensors) device tensors
+    are staged through the host."""
+    if not active():
+        return t
+    if t.is_cuda and td.get_backend() != "nccl":
+        host = t.cpu()
+        td.broadcast(host, src=src)
+        t.copy_(host)
+        return t
+    td.broadcast(t, src=src)
+    return t
+
+
+def host_threads():
+    """This rank's share of the host's cores: usable cores (affinity mask, cgroup quota) // ranks on this host
+    (LOCAL_WORLD_SIZE, torchrun sets it), at least 1.  Eight ranks of one node each defaulting to `all cores` intra-op
+    threads oversubscribe the host 8x and stretch every rank's launch loop."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    return max(1, cores // max(1, local_world))
+
+
+def limit_host_threads():
+    """Called by the drivers right after init_from_env(): torch's intra-op pool (CPU restatement of nothing on the product
+    path, but numpy / PIL / torch host ops of loaders and validation use it) is capped at this rank's share unless the
+    user set OMP_NUM_THREADS.  No CPU affinity is set here: under torchrun the expected launch is one rank per GPU with
+    the default (unpinned) affinity; pin with `numactl` / `taskset` per rank outside if the node's NUMA layout calls for
+    it.  -> the thread count in use."""
+    if os.environ.get("OMP_NUM_THREADS"):
+        return torch.get_num_threads()
+    n = host_threads()
+    torch.set_num_threads(n)
+    return n
 
 
 def allreduce_sum(t, async_op=False):

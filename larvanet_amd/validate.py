@@ -54,6 +54,7 @@ def main(argv=None):
     if args.cuda_device is not None and "LOCAL_RANK" not in os.environ:
         os.environ["HIP_VISIBLE_DEVICES"] = args.cuda_device
     rank, world = ldist.init_from_env()
+    ldist.limit_host_threads()   # this rank's share of the host's cores (LOCAL_WORLD_SIZE ranks per node)
     scales = [int(s) for s in args.scales.split(",")]
 
     print("prepare data loader - %s" % args.dataloader)

@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "diag: tests of the measurement library tools/_diag/diag.so, not of the product (-m diag on a GPU box)")
 
 
 @pytest.fixture(scope="session")

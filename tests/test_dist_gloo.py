@@ -188,3 +188,90 @@ def test_helpers_stay_inert_without_a_communicator():
     t = torch.ones(3)
     assert ldist.allreduce_sum(t) is None and ldist.time_allreduce_us(t) == 0.0
     assert ldist.all_gather_tensor(t).shape == (1, 3) and ldist.gather_objects(1) == [1]
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: decode once on rank 0, broadcast the resident tables (dataloaders/device_patch_loader.py)
+# ------------------------------------------------------------------------------------------------
+class _CountingSource:
+    """synthetic_loader with a decode counter: only rank 0 may ever decode."""
+
+    def __init__(self):
+        from larvanet_amd.dataloaders import synthetic_loader
+        self.inner = synthetic_loader.create_loader()
+        self.inner.parse_args(["--synthetic_images=6", "--synthetic_lr_size=20"])
+        self.inner.prepare([4])
+        self.decodes = 0
+
+    def get_num_images(self):
+        return self.inner.get_num_images()
+
+    def get_image_pair(self, i, scale):
+        self.decodes += 1
+        return self.inner.get_image_pair(i, scale)
+
+
+def _tables_worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import torch.distributed as td
+    from larvanet_amd import dist as ldist
+    from larvanet_amd.dataloaders import device_patch_loader as D
+    ldist.init_from_env(backend="gloo")
+    threads = ldist.limit_host_threads() if "OMP_NUM_THREADS" not in os.environ else None
+    src = _CountingSource()
+    host, shapes = D.build_host_tables(src, [4], workers=3) if ldist.is_main() else (None, None)
+    tables, shapes = D.share_tables(host, shapes, [4], torch.device("cpu"))
+    # the rank's own draw stream over the shared shapes (seed + 1000 rank)
+    rng = np.random.RandomState(ldist.seed_for_rank(7))
+    draws = D.draw_batch(rng, shapes, 4, 12)
+    t = tables[4]
+    digest = (int(t["lr"].to(torch.int64).sum()), int(t["hr"].to(torch.int64).sum()), t["lr_off"].tolist(), t["hr_off"].tolist(),
+              t["lr_hw"].tolist(), t["hr_hw"].tolist(), [str(v.dtype) for v in t.values()])
+    q.put((rank, src.decodes, digest, shapes, draws.tolist(), threads, ldist.host_threads()))
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_resident_tables_are_decoded_once_and_broadcast():
+    """start-up O(1) in the world size.  Rank 0 decodes (thread pool), the uint8 tables and the
+    offset / size tables reach rank 1 by broadcast (rank 1 never calls get_image_pair), both ranks hold identical tables
+    equal to a serial single-process build, and their draw streams differ."""
+    from larvanet_amd.dataloaders import device_patch_loader as D
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tables_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, dec0, dig0, sh0, dr0, th0, ht0), (_, dec1, dig1, sh1, dr1, th1, ht1) = out
+    assert dec0 == 6 and dec1 == 0
+    assert dig0 == dig1 and sh0 == sh1 and dr0 != dr1
+    # ... and equal to the serial build without a communicator (this process)
+    src = _CountingSource()
+    host, shapes = D.build_host_tables(src, [4], workers=1)
+    tables, shapes2 = D.share_tables(host, shapes, [4], torch.device("cpu"))
+    t = tables[4]
+    assert dig0[:2] == (int(t["lr"].to(torch.int64).sum()), int(t["hr"].to(torch.int64).sum()))
+    assert dig0[2] == t["lr_off"].tolist() and dig0[5] == t["hr_hw"].tolist() and [tuple(s) for s in sh0] == shapes2
+    assert t["lr_off"][1] == 3 * shapes[0][0] * shapes[0][1]            # offsets count bytes of the CHW uint8 images
+    assert dig0[6] == ["torch.uint8", "torch.uint8", "torch.int64", "torch.int64", "torch.int32", "torch.int32"]
+    # each rank took half of the host's cores for itself
+    assert ht0 == ht1 >= 1
+    if th0 is not None:
+        assert th0 == ht0
+
+
+def test_host_threads_divides_the_cores_among_the_local_ranks(monkeypatch):
+    from larvanet_amd import dist as ldist
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    one = ldist.host_threads()
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert ldist.host_threads() == max(1, one // 8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "100000")
+    assert ldist.host_threads() == 1

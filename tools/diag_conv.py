@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "_diag")
-SRC = os.path.join(ROOT, "larvanet_amd", "csrc", "conv3x3_mfma.hip")
+SRC = os.path.join(ROOT, "tools", "csrc", "conv3x3_diag.hip")   # the product's conv3x3_mfma.hip + the timed-launch entry points
 TIMELINE = 32   # full kernel + in-kernel wall-clock stamps (--timeline)
 TIMELINE_MFMA = 38   # the same without staging and epilogue traffic
 TIMELINE_CLK = 96    # full kernel, stamps in shader-clock cycles (s_memtime)
@@ -37,7 +37,7 @@ def build():
     for v in only:
         so = os.path.join(OUT, "libconv_diag%d%s.so" % (v, TAG))
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLARVA_DIAG=%d" % v,
-               "-DLARVA_DIAG_ONLY48=1", "-DLARVA_DIAG_API=1"] + EXTRA + [SRC, "-o", so]
+               "-DLARVA_DIAG_ONLY48=1", "-I" + os.path.join(ROOT, "larvanet_amd", "csrc"), "-I" + os.path.join(ROOT, "tools", "csrc")] + EXTRA + [SRC, "-o", so]
         procs.append(subprocess.Popen(cmd))
     for p in procs:
         assert p.wait() == 0
