@@ -1170,3 +1170,60 @@ def test_persistent_tiles_equal_one_workgroup_per_tile_bit_for_bit(hip_device, m
     torch.cuda.synchronize()
     assert torch.equal(persistent, per_tile)
     assert float(persistent.abs().max()) > 1.0   # (something was computed)
+
+
+@pytest.mark.parametrize("C,H,P,strips", [(48, 3345, 3344, True), (32, 4100, 4096, False)])
+def test_images_whose_cout_planes_exceed_2gib_take_the_per_tile_launch(hip_device, monkeypatch, C, H, P, strips):
+    """csrc/conv3x3_mfma.hip launch_persist / strips_dispatch: the strip and persistent kernels fetch their residual /
+    mask operands by buffer loads with 32-BIT byte offsets inside one image, so an image whose cout planes reach 2 GiB is
+    refused (hipErrorNotSupported, before anything is launched) and the one-workgroup-per-tile launch -- 64-bit
+    addressing -- takes over: kernels.conv3x3's `code == 801` fall-through for strips, conv_dispatch's own for persistent
+    tiles.  Checked on a REAL tensor of that size (cout * H * pitch * 4 >= 2^31): the strip entry point returns 801 and
+    leaves the output untouched; conv3x3(strips=True) and the default whole-tensor launch (more tiles than workgroup
+    slots) then produce the same bits as LARVA_PERSIST=0, and windows at the image's first and LAST bytes (where a 32-bit
+    offset would have wrapped) match the C oracle, residual operand included.  (32 channels: strip tables end at 4095 rows /
+    columns, so 2 GiB of 32 planes is out of the strips' reach; the whole-tensor launches -- 4-row tiles by default,
+    persistent 3-row tiles when asked for -- are checked the same way.)"""
+    from larvanet_amd import hip_lib, kernels as K
+    from oracle import larva_ref as R
+    assert C * H * P * 4 >= 2 ** 31 and 8 * H * P * 4 < 2 ** 31
+    gen = torch.Generator(device=hip_device).manual_seed(C + H)
+    x = torch.randn(1, C, H, P, device=hip_device, generator=gen) * 20
+    r0 = torch.randn(1, C, H, P, device=hip_device, generator=gen) * 20
+    rng = np.random.default_rng(7)
+    w, b = _rand(rng, (C, C, 3, 3), 0.05), _rand(rng, (C,), 1.0)
+    fwd, _ = K.pack_weights(_dev(w, hip_device))
+    bias = _dev(b, hip_device)
+    lib = hip_lib.load()
+    seen = []
+    real = lib.larva_conv3x3_fwd_strips
+    out_s = torch.full((1, C, H, P), float("nan"), device=hip_device)
+
+    def spy(*a):
+        rc = real(*a)
+        torch.cuda.synchronize()
+        seen.append((rc, bool(torch.isnan(out_s).all())))   # refused -> nothing may have been launched on `out`
+        return rc
+    monkeypatch.setattr(lib, "larva_conv3x3_fwd_strips", spy)
+    assert (K.strip_tile_table(H, P, hip_device) is not None) == strips   # (48: a shape the strips themselves accept)
+    K.conv3x3(x, fwd, C, bias=bias, res0=r0, out=out_s, strips=True)
+    torch.cuda.synchronize()
+    assert seen == ([(801, True)] if strips else []), seen    # hipErrorNotSupported, output untouched at that point
+    slots = 2 * torch.cuda.get_device_properties(hip_device).multi_processor_count
+    assert ((H + 2) // 3) * ((P + 47) // 48) > slots           # the default launch would pick persistent tiles
+    out_p = K.conv3x3(x, fwd, C, bias=bias, res0=r0)           # persistent refused inside conv_dispatch -> per-tile
+    out_3 = K.conv3x3(x, fwd, C, bias=bias, res0=r0, tile_rows=3)
+    monkeypatch.setenv("LARVA_PERSIST", "0")
+    out_t = K.conv3x3(x, fwd, C, bias=bias, res0=r0, tile_rows=3)
+    torch.cuda.synchronize()
+    assert torch.equal(out_s, out_t) and torch.equal(out_p, out_t) and torch.equal(out_3, out_t)
+    del out_s, out_p, out_3
+    # windows against the oracle: first bytes, the middle, and the last rows / columns / channels of the image
+    for (ya, yb, xa, xb) in ((0, 24, 0, 40), (H // 2 - 12, H // 2 + 12, P // 2 - 20, P // 2 + 20), (H - 24, H, P - 40, P)):
+        xc, rc_ = x[:, :, ya:yb, xa:xb].cpu().numpy(), r0[:, :, ya:yb, xa:xb].cpu().numpy()
+        ref = R.conv3x3(xc, w, b) + rc_
+        got = out_t[:, :, ya:yb, xa:xb].cpu().numpy()
+        # the crop's own zero padding is the image's only at the image border: drop the crop's inner edges
+        ys = slice(0 if ya == 0 else 1, (yb - ya) if yb == H else (yb - ya) - 1)
+        xs = slice(0 if xa == 0 else 1, (xb - xa) if xb == P else (xb - xa) - 1)
+        _report("conv3x3 over 2 GiB window (%d, %d)" % (ya, xa), got[:, :, ys, xs], ref[:, :, ys, xs], 2e-5)
