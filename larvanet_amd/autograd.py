@@ -687,6 +687,25 @@ class _NullCtx:
         return False
 
 
+# ONE rule for "a large inference batch" (a whole validation image rather than a batch of patches): above it the
+# inference forward runs as eager launches (models/LarvaNet.py `_infer`: 36 launches of ~60 us each, the host is
+# milliseconds ahead) and the head takes the direct K = 27 kernel (33 MB of output: HBM-bound).  Both decisions use
+# the same count -- N x H x W LR pixels of the INPUT, unpadded -- so that no shape takes one without the other.
+LARGE_INFERENCE_PIXELS = 100000
+
+
+def is_large_inference(n, h, w):
+    return int(n) * int(h) * int(w) > LARGE_INFERENCE_PIXELS
+
+
+def _head_direct_setting():
+    """LARVA_HEAD_DIRECT: auto (default) | 0 = never the direct head kernel | 1 = always."""
+    v = os.environ.get("LARVA_HEAD_DIRECT", "auto")
+    if v not in ("auto", "0", "1"):
+        raise RuntimeError("larvanet_amd: LARVA_HEAD_DIRECT=%r (auto, 0 or 1)" % v)
+    return {"0": False, "1": True}.get(v, "auto")
+
+
 class HeadFn(torch.autograd.Function):
     """LarvaHead.forward (models/LarvaNet.py:223-233): conv3x3 3->48, no activation.
     Forward: the MFMA conv kernel on the image zero-padded to two 8-channel K chunks (13/16 of its
@@ -697,11 +716,10 @@ class HeadFn(torch.autograd.Function):
 
     # rocprofv3 A/B at 16 x 3 x 48 x 48 (profiles/README.md, r02_head_*): padded-MFMA launch 7.2 us, direct
     # kernel 9.0 us (LDS-broadcast weights; 12.8 us with scalar-loaded weights) -> MFMA at the training size.  A whole
-    # validation image is another matter: 33 MB of output, the padded MFMA launch 26-31 us against 20 us for the direct
-    # kernel's 4-pixel x 8-channel threads with 16-byte stores (round 5, tools/bench_head_bicubic.py): "auto" = direct for
-    # inference on more than DIRECT_ABOVE_PIXELS LR pixels; 0 / 1 = never / always.
-    direct = {"0": False, "1": True}.get(os.environ.get("LARVA_HEAD_DIRECT", "auto"), "auto")
-    DIRECT_ABOVE_PIXELS = 100000
+    # validation image is another matter: 33 MB of output, the padded MFMA launch 25-31 us against 15 us for the direct
+    # kernel's 4-pixel x 8-channel threads with 16-byte stores (profiles/r06_head_bicubic_ab.txt): "auto" = direct for
+    # inference on more than LARGE_INFERENCE_PIXELS LR pixels (is_large_inference); 0 / 1 = never / always.
+    direct = _head_direct_setting()
 
     @staticmethod
     def forward(ctx, x, weight, bias, pc, x16=None, training=True):
@@ -711,7 +729,7 @@ class HeadFn(torch.autograd.Function):
         P = PaddedWidth.pitch_of(W) if _lw() is not None else W
         cout = int(weight.shape[0])
         training = bool(training) and bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        want = HeadFn.direct if HeadFn.direct != "auto" else (not training and N * H * P > HeadFn.DIRECT_ABOVE_PIXELS)
+        want = HeadFn.direct if HeadFn.direct != "auto" else (not training and is_large_inference(N, H, W))
         use_direct = want and C == 3 and cout % 16 == 0
         if x16 is not None:      # prepared by the step's prologue launch (step_prologue)
             pass

@@ -19,10 +19,16 @@ __global__ void bicubic4_kernel(const float* __restrict__ in, float* __restrict_
                 (long long)gridDim.x * blockDim.x);
 }
 
-// The same arithmetic, one thread per LR pixel = its 4 x 4 block of HR pixels (round 5, the stand-alone launch of the
-// inference forward: a 339 x 510 image is 33 MB of base image).  The 16 outputs of a block read the same 5 x 5 window of
-// LR pixels -- 25 loads instead of 4 x 20 --, the row / column weights are computed once per block, the index is decoded
-// once with 32-bit divisions, and a wave stores four 1 KiB runs.  bicubic4_kernel took 23.1 us for that image (1.44 TB/s).
+// The same arithmetic, one thread per LR pixel = its 4 x 4 block of HR pixels (the stand-alone launch of the inference
+// forward: a 339 x 510 image is 33 MB of base image).  Round 6: SEPARABLE inside the thread and free of run-time tap
+// selection.  The four sub-pixel phases of a x4 upscale are constants -- src - floor(src) = .625, .875, .125, .375 for output
+// j = 0..3 of a block, taps starting at column x - 2 + (j >> 1) -- and their Keys weights are dyadic rationals that every
+// evaluation order produces exactly (A = -3/4, t a multiple of 1/8: no rounding anywhere in cubic_coeffs), so the weights
+// fold to literals that equal bicubic4_body's run-time ones bit for bit.  The row pass is done ONCE per source row and
+// phase (5 x 4 four-tap sums) and shared by the four output rows (16 four-tap column sums): 144 fused multiply-adds per
+// block instead of 320 + 768 selects, in the same order per output as bicubic4_body (row sums first, then the column
+// weights: ATen's separable path), i.e. the same bits.  Round 5's form took 16.7 us for that image (2.0 TB/s, vector-ALU
+// bound), bicubic4_kernel 23.1.
 __global__ __launch_bounds__(256) void bicubic4_block_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                               unsigned planes, unsigned H, unsigned W) {
   const unsigned total = planes * H * W;   // (< 2^31: checked by the launcher)
@@ -30,46 +36,40 @@ __global__ __launch_bounds__(256) void bicubic4_block_kernel(const float* __rest
   if (i >= total) return;
   const unsigned x = i % W, t2 = i / W, y = t2 % H, p = t2 / H;
   const float* src = in + (size_t)p * H * W;
+  int col[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) col[c] = min(max((int)x - 2 + c, 0), (int)W - 1);
   float v[5][5];
 #pragma unroll
   for (int r = 0; r < 5; ++r) {
-    const int yy = min(max((int)y - 2 + r, 0), (int)H - 1);
+    const float* row = src + (size_t)min(max((int)y - 2 + r, 0), (int)H - 1) * W;
 #pragma unroll
-    for (int c = 0; c < 5; ++c) v[r][c] = src[(size_t)yy * W + min(max((int)x - 2 + c, 0), (int)W - 1)];
+    for (int c = 0; c < 5; ++c) v[r][c] = row[col[c]];
   }
-  float wx[4][4];
-  int c0[4];
+  float wq[4][4];   // [phase j][tap]: compile-time constants after unrolling
+  cubic_coeffs(0.625f, wq[0]);
+  cubic_coeffs(0.875f, wq[1]);
+  cubic_coeffs(0.125f, wq[2]);
+  cubic_coeffs(0.375f, wq[3]);
+  float h[5][4];    // row pass: source row r, output column phase jj
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int X = 4 * (int)x + jj;
-    const float sx = 0.25f * ((float)X + 0.5f) - 0.5f;
-    const float fx = floorf(sx);
-    cubic_coeffs(sx - fx, wx[jj]);
-    c0[jj] = (int)fx - 1 - ((int)x - 2);   // 0 for jj < 2, 1 for jj >= 2
-  }
+  for (int r = 0; r < 5; ++r)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float rowv = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rowv += wq[jj][c] * v[r][(jj >> 1) + c];
+      h[r][jj] = rowv;
+    }
   float* o = out + ((size_t)p * (4 * H) + 4 * y) * (4 * W) + 4 * x;
 #pragma unroll
   for (int ii = 0; ii < 4; ++ii) {
-    const int Y = 4 * (int)y + ii;
-    const float sy = 0.25f * ((float)Y + 0.5f) - 0.5f;
-    const float fy = floorf(sy);
-    float wy[4];
-    cubic_coeffs(sy - fy, wy);
-    const int r0 = (int)fy - 1 - ((int)y - 2);   // 0 for ii < 2, 1 for ii >= 2
     f32x4 q;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       float acc = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float rowv = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float a = r0 == 0 ? (c0[jj] == 0 ? v[r][c] : v[r][c + 1]) : (c0[jj] == 0 ? v[r + 1][c] : v[r + 1][c + 1]);
-          rowv += wx[jj][c] * a;
-        }
-        acc += wy[r] * rowv;
-      }
+      for (int r = 0; r < 4; ++r) acc += wq[ii][r] * h[(ii >> 1) + r][jj];
       q[jj] = acc;
     }
     *reinterpret_cast<f32x4*>(o + (size_t)ii * (4 * W)) = q;
@@ -192,22 +192,22 @@ __global__ __launch_bounds__(256) void head_conv3_direct_kernel(const float* __r
   }
 }
 
-// The same layer for LARGE images (round 5: the head of a 339 x 510 validation image writes 33 MB; on the padded MFMA launch
-// it took 31.6 us = 1.05 TB/s): one thread = 4 consecutive pixels of a row x 8 output channels -- 54 inputs in registers,
-// the block's 8 x 27 weights broadcast from LDS, every output channel's 4 pixels leave as ONE 16-byte store (a wave
-// writes 1 KiB runs instead of 256-byte ones).  Same fma chain per output as head_conv3_direct_kernel.  pitch % 4 == 0.
+// The same layer for LARGE images (the head of a 339 x 510 validation image writes 33 MB; on the padded MFMA launch it took
+// 31.6 us = 1.05 TB/s): one thread = 4 consecutive pixels of a row x 8 output channels -- 54 inputs in registers, every
+// output channel's 4 pixels leave as ONE 16-byte store (a wave writes 1 KiB runs instead of 256-byte ones).  Same fma chain
+// per output as head_conv3_direct_kernel.  pitch % 4 == 0.
 constexpr int kHead4Couts = 8;
 
+// Round 6 (profiles/r06_head_bicubic_ab.txt: 19.8 -> 15.2 us for that image):
+//  * the block's weights are NOT staged in LDS: `w + (co0 + j) * 27` is a block-uniform address, the compiler fetches the
+//    27 taps + bias of an output channel with scalar loads into SGPRs and the FMAs take them as scalar operands -- no
+//    ds_read_b128 broadcast per lane (56 per thread before), no 28 VGPRs of weights, no barrier at the head of the block;
+//  * threads whose 3 x 6 input window lies inside the image (all but the border ring) load it without clamps or selects,
+//    a window row as one 16-byte + one 8-byte load (global loads need dword alignment only).
 __global__ __launch_bounds__(256) void head_conv3_direct4_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                 const float* __restrict__ bias, float* __restrict__ out,
-                                                                 int N, int cout, int H, int W, int pitch) {
-  __shared__ __attribute__((aligned(16))) float wl[kHead4Couts][28];
+                                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                                  int N, int cout, int H, int W, int pitch) {
   const int co0 = blockIdx.y * kHead4Couts;
-  for (int i = threadIdx.x; i < kHead4Couts * 28; i += 256) {
-    const int j = i / 28, k = i - j * 28;
-    wl[j][k] = k < 27 ? w[(co0 + j) * 27 + k] : (bias ? bias[co0 + j] : 0.f);   // slot 27 = the bias
-  }
-  __syncthreads();
   const unsigned q4 = (unsigned)pitch >> 2;
   const unsigned total = (unsigned)N * H * q4;          // groups of 4 pixels (< 2^31: checked by the launcher)
   const unsigned gidx = blockIdx.x * 256u + threadIdx.x;
@@ -217,20 +217,35 @@ __global__ __launch_bounds__(256) void head_conv3_direct4_kernel(const float* __
   const float* xb = x + (size_t)n * 3 * H * W;
   const int cplane = H * W;
   float v[3][3][6];   // [channel][row y-1..y+1][column x0-1..x0+4], zero outside the image
+  if (y >= 1 && y + 1 < H && x0 >= 1 && x0 + 4 < W) {
+    // (global loads need dword alignment only: the six floats of a window row travel as one 16-byte + one 8-byte load)
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+    const float* p0 = xb + (size_t)(y - 1) * W + (x0 - 1);
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int yy = y + ky - 1;
-    const bool rok = yy >= 0 && yy < H;
-    const int roff = min(max(yy, 0), H - 1) * W;
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int kx = 0; kx < 6; ++kx) {
-      const int xc = x0 + kx - 1;
-      const bool ok = rok && xc >= 0 && xc < W;
-      const int off = roff + min(max(xc, 0), W - 1);
+      for (int ky = 0; ky < 3; ++ky) {
+        const f32x4_u a = *reinterpret_cast<const f32x4_u*>(p0 + c * cplane + ky * W);
+        const f32x2_u b = *reinterpret_cast<const f32x2_u*>(p0 + c * cplane + ky * W + 4);
+        v[c][ky][0] = a[0]; v[c][ky][1] = a[1]; v[c][ky][2] = a[2]; v[c][ky][3] = a[3]; v[c][ky][4] = b[0]; v[c][ky][5] = b[1];
+      }
+  } else {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float val = xb[c * cplane + off];
-        v[c][ky][kx] = ok ? val : 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+      const bool rok = yy >= 0 && yy < H;
+      const int roff = min(max(yy, 0), H - 1) * W;
+#pragma unroll
+      for (int kx = 0; kx < 6; ++kx) {
+        const int xc = x0 + kx - 1;
+        const bool ok = rok && xc >= 0 && xc < W;
+        const int off = roff + min(max(xc, 0), W - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float val = xb[c * cplane + off];
+          v[c][ky][kx] = ok ? val : 0.f;
+        }
       }
     }
   }
@@ -238,16 +253,12 @@ __global__ __launch_bounds__(256) void head_conv3_direct4_kernel(const float* __
   float* o = out + ((size_t)n * cout + co0) * plane + (size_t)y * pitch + x0;
 #pragma unroll
   for (int j = 0; j < kHead4Couts; ++j) {
-    float wj[28];
-#pragma unroll
-    for (int q = 0; q < 7; ++q) {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(&wl[j][4 * q]);
-      wj[4 * q] = w4[0]; wj[4 * q + 1] = w4[1]; wj[4 * q + 2] = w4[2]; wj[4 * q + 3] = w4[3];
-    }
+    const float* wj = w + (co0 + j) * 27;            // block-uniform: scalar loads
+    const float bj = bias ? bias[co0 + j] : 0.f;
     f32x4 r;
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
-      float acc = wj[27];
+      float acc = bj;
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll

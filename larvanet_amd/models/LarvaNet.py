@@ -21,7 +21,7 @@ import torch.nn as nn
 from .. import dist as ldist
 from .. import kernels as K
 from ..autograd import (BodyFn, DualChain, ExitFn, ExitsFn, GradBucket, HeadFn, L1LossFn, LegFn, LossTerm, PackedConv, PaddedWidth, mean_of_terms,
-                        SideStreams, StepScope, pack_all)
+                        SideStreams, StepScope, is_large_inference, pack_all)
 from ..autograd import step_prologue as autograd_step_prologue
 from ..optim import FlatAdamW, flatten_parameters
 from ..metrics import image_psnr, image_to_uint8, fit_truth_image_size
@@ -825,8 +825,6 @@ class LarvaNet(BaseModel):
         return StepScope(defer_wgrad=False, joint_input_grads=False, dual_chain=self.dual_chain,
                          lazy_chain_joins=(True, False))
 
-    INFER_GRAPH_BELOW_PIXELS = 100000   # LR pixels per batch above which the inference forward is not captured (see _infer)
-
     def _infer(self, x):
         """self.model(x) without gradients.  A batch shape seen for the second time is captured into a
         hipGraph (launched one by one from Python the ~36 kernels of a 16 x 3 x 48 x 48 forward are
@@ -839,7 +837,7 @@ class LarvaNet(BaseModel):
         # A whole validation image is 36 launches of 60 us each: the host is ~2 ms ahead of the GPU after the first few,
         # and eager launches have no replay boundary and no copy into a static input: 2.162 against 2.178 ms per
         # 339 x 510 image (tools/infer_modes.py, round 5).  The capture pays where the launches are short.
-        if int(x.shape[0]) * int(x.shape[2]) * int(x.shape[3]) > self.INFER_GRAPH_BELOW_PIXELS:
+        if is_large_inference(x.shape[0], x.shape[2], x.shape[3]):   # (the same rule picks the direct head kernel)
             return self.model(x)
         cache = self.__dict__.setdefault("_infer_graphs", {})
         seen = self.__dict__.setdefault("_infer_seen", {})

@@ -217,3 +217,22 @@ def test_train_larva_v2_driver_flags():
     assert not hasattr(train_larva.build_parser().parse_known_args([])[0], "steps_per_epoch")
     assert train_larva.round_to_1(300 * 1024 ** 2 / (48 ** 2 * 16 * 3)) == 3000.0   # 2844.4 -> one significant digit
     assert train_larva.round_to_1(0.0234) == 0.02
+
+
+def test_one_rule_decides_eager_inference_and_the_direct_head_kernel(monkeypatch):
+    """`_infer` (capture or eager) and HeadFn (MFMA or direct head kernel) used two differently computed
+    thresholds; both now ask autograd.is_large_inference(N, H, W) on the unpadded input.  An unknown LARVA_HEAD_DIRECT
+    value is refused instead of silently meaning `auto`."""
+    import inspect
+    from larvanet_amd import autograd as A
+    from larvanet_amd.models import LarvaNet as L
+    assert A.is_large_inference(1, 339, 510) and not A.is_large_inference(16, 48, 48)
+    assert not A.is_large_inference(1, 250, 400) and A.is_large_inference(1, 250, 401)
+    assert "is_large_inference" in inspect.getsource(L.LarvaNet._infer)
+    assert "is_large_inference" in inspect.getsource(A.HeadFn.forward)
+    for ok, want in (("auto", "auto"), ("0", False), ("1", True)):
+        monkeypatch.setenv("LARVA_HEAD_DIRECT", ok)
+        assert A._head_direct_setting() == want
+    monkeypatch.setenv("LARVA_HEAD_DIRECT", "yes")
+    with pytest.raises(RuntimeError, match="LARVA_HEAD_DIRECT"):
+        A._head_direct_setting()

@@ -402,13 +402,13 @@ def test_train_step_on_a_patch_larger_than_the_direct_head_threshold(hip_device)
     autograd.Function the grad mode is always off: the flag comes from the module).  Loss and every gradient against
     oracle/larva_torch.py; the same image through upscale() afterwards takes the direct kernel and matches too."""
     from oracle import larva_torch as T
-    from larvanet_amd.autograd import HeadFn
+    from larvanet_amd.autograd import is_large_inference
     blocks = [1]
     m = _model("LarvaNet", ["--num_modules=1", "--num_blocks=1"], training=True, seed=7)
     sd = {k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()}
     rng = np.random.RandomState(77)
     n, p = 2, 232
-    assert n * p * p > HeadFn.DIRECT_ABOVE_PIXELS
+    assert is_large_inference(n, p, p)
     x = torch.from_numpy(rng.randint(0, 256, size=(n, 3, p, p)).astype(np.float32))
     t = torch.from_numpy(rng.randint(0, 256, size=(n, 3, 4 * p, 4 * p)).astype(np.float32))
     m.use_hip_graph = False
