@@ -343,6 +343,23 @@ def chain_graphs(dev, c, dual, chain=CHAIN_SHORT, decaying=False, lengths=(CHAIN
     return graphs, rms
 
 
+def dual_chain_time_ms(dev, c=CH, chain=CHAIN_SHORT, reps=10, decaying=False, dual=True):
+    """(steady-state slope in ms per layer, rms of the last output, replay / 40 in ms) of the two-chain graph, settled,
+    median of 5 sets: the short form the tools under tools/ use (diag_overlap.py, probe_pair_chain.py)."""
+    res = chain_graphs(dev, c, dual, chain, decaying)
+    if res is None:
+        return None
+    graphs, rms = res
+    t40 = replay_stats(graphs[CHAIN_SHORT], reps, sets=5)["median"]
+    t160 = replay_stats(graphs[CHAIN_LONG], reps, sets=3, settle=False)["median"]
+    return (t160 - t40) / (CHAIN_LONG - CHAIN_SHORT), rms, t40 / CHAIN_SHORT
+
+
+def chain_time_ms(dev, c, chain=CHAIN_SHORT, reps=10, decaying=False):
+    """The same for one chain of whole-batch launches."""
+    return dual_chain_time_ms(dev, c, chain, reps, decaying, dual=False)
+
+
 def diag_lib():
     """tools/diag_lib.py (the measurement library tools/build_diag.sh builds: kernel-attached launch timing lives there,
     not in the product's C ABI), or None when it has not been built."""

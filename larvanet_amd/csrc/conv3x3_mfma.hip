@@ -360,7 +360,7 @@ __device__ __forceinline__ void run_loader(const ConvArgs& a, float* smem, int l
   for (int chunk = 0; chunk <= last; ++chunk) {
     // everything but the youngest chunk's pieces has landed: for chunk >= 2 that is chunk `chunk` itself (chunks 0 and
     // 1 come from the MFMA waves, which wait for them on their side)
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((C::AHEAD - 1) * C::PIECES) : "memory");
+    asm volatile("; LARVA_RING loader chunk_pieces=%1 ahead=%2\n\ts_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((C::AHEAD - 1) * C::PIECES), "n"(C::PIECES), "n"(C::AHEAD) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     const int nstage = (stage + C::AHEAD) % C::NST;   // the stage chunk - 1 has just vacated
     const unsigned dst = lds_addr_of(smem + nstage * C::STAGE_FLOATS);
@@ -541,9 +541,14 @@ __device__ __forceinline__ void mfma_chunk(const float* stage, int ct0, int lane
 
 // Wait until all but the `KEEP` youngest vector-memory operations of this wave are done, then
 // meet the other waves.  Raw barrier on purpose: __syncthreads() would drain every LDS-DMA.
-template <int KEEP>
+// PIECES / AUX: what KEEP is made of -- the LDS-DMA pieces of the NEXT chunk this wave has in flight and the epilogue
+// operand loads behind them (kAuxLoads).  They travel into the device assembly as a comment in front of the wait
+// ("; LARVA_RING pieces=P aux=A"): tools/check_aux_loads.py compares the loads hipcc really emitted against these VALUES,
+// not against plausible ranges.
+template <int KEEP, int PIECES, int AUX>
 __device__ __forceinline__ void wait_and_barrier() {
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+  static_assert(KEEP == PIECES + AUX, "a ring wait keeps exactly the next chunk's pieces and the operand loads in flight");
+  asm volatile("; LARVA_RING pieces=%1 aux=%2\n\ts_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(KEEP), "n"(PIECES), "n"(AUX) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -794,8 +799,8 @@ __device__ __forceinline__ void run_role(const ConvArgs& a, float* smem, int ct0
       // stage that chunk + 2 is about to overwrite.
       if constexpr ((LARVA_DIAG & 256) != 0) {
         // timing ablation (with bit 1: nothing is staged): no barrier between the chunks
-      } else if (chunk == 0) wait_and_barrier<((LARVA_DIAG & 2) ? 0 : C::NPW) + kAuxLoads>();
-      else wait_and_barrier<kAuxLoads>();
+      } else if (chunk == 0) wait_and_barrier<((LARVA_DIAG & 2) ? 0 : C::NPW) + kAuxLoads, ((LARVA_DIAG & 2) ? 0 : C::NPW), kAuxLoads>();
+      else wait_and_barrier<kAuxLoads, 0, kAuxLoads>();
       if (chunk == 0) stamp(2);
       stamp(8 + (chunk < 7 ? chunk : 7));
       if constexpr (!(LARVA_DIAG & 1)) mfma_chunk<COUT, G, NCT, PG0, NPG, kPixMajor>(smem + stage * C::STAGE_FLOATS, ct0, lane, acc);

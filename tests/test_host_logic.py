@@ -236,3 +236,38 @@ def test_one_rule_decides_eager_inference_and_the_direct_head_kernel(monkeypatch
     monkeypatch.setenv("LARVA_HEAD_DIRECT", "yes")
     with pytest.raises(RuntimeError, match="LARVA_HEAD_DIRECT"):
         A._head_direct_setting()
+
+
+def test_ring_wait_checker_compares_against_the_constants_the_kernel_emits(tmp_path):
+    """tools/check_aux_loads.py (run by larvanet_amd/build.py on every build): a counted `s_waitcnt vmcnt(N)` of the LDS-DMA
+    ring is checked against the `; LARVA_RING pieces=P aux=A` comment the kernel emits in front of it -- exact values, not
+    plausible ranges.  A role whose compiler-emitted operand loads fall short of A, a wait that is not P + A
+    and a loader wait that is not (ahead - 1) x pieces are all refused."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "check_aux_loads.py")
+
+    def listing(first_n, loads, later_n, loader_n):
+        body = ["_ZN5larva9fake_kernEv:"]
+        body += ["\tbuffer_load_dwordx4 v1, s[0:3], 0 offen lds"] * 5
+        body += ["\tbuffer_load_dwordx4 v[2:5], v6, s[0:3], 0 offen"] * loads
+        body += ["\t; LARVA_RING pieces=5 aux=3", "\ts_waitcnt vmcnt(%d)" % first_n, "\ts_barrier"]
+        body += ["\t; LARVA_RING pieces=0 aux=3", "\ts_waitcnt vmcnt(%d)" % later_n, "\ts_barrier"]
+        body += ["\t; LARVA_RING loader chunk_pieces=20 ahead=2", "\ts_waitcnt vmcnt(%d)" % loader_n, "\ts_barrier"]
+        body += [".Lfunc_end0:"]
+        return "\n".join(body) + "\n"
+
+    def run(text):
+        p = tmp_path / "k.s"
+        p.write_text(text)
+        return subprocess.run([sys.executable, tool, str(p)], capture_output=True, text=True)
+
+    ok = run(listing(8, 3, 3, 20))
+    assert ok.returncode == 0 and "3 ring waits checked" in ok.stdout, ok.stdout
+    for bad in (listing(8, 2, 3, 20),     # the compiler emitted one operand load fewer than the constant counts
+                listing(7, 3, 3, 20),     # the first wait keeps fewer than pieces + aux in flight
+                listing(8, 3, 2, 20),     # a later wait
+                listing(8, 3, 3, 12)):    # the loader's
+        r = run(bad)
+        assert r.returncode == 1 and "MISMATCH" in r.stdout, r.stdout

@@ -9,6 +9,12 @@ global loads between the last LDS-DMA piece in front of it and the wait:
   first wait of a role   vmcnt(N):  N - (global loads since the last piece) must equal the role's pieces per wave (NPW)
   later waits            vmcnt(N):  N must equal the first wait's load count
 
+Since round 6 every ring wait carries its constants into the assembly as a comment in front of it
+("; LARVA_RING pieces=P aux=A", wait_and_barrier; "; LARVA_RING loader chunk_pieces=P ahead=K", run_loader): where the tag
+is present the check is EXACT -- N == P + A, and for a role's first wait the loads emitted since the last piece == A,
+for the loader N == (K - 1) * P -- and the older range heuristics (3..9 pieces per wave, >= 12 per chunk) only serve
+assembly without tags.
+
   hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S -o /tmp/conv.s larvanet_amd/csrc/conv3x3_mfma.hip
   python tools/check_aux_loads.py /tmp/conv.s
 larvanet_amd/build.py runs it on the device assembly of every build of conv3x3_mfma.hip (-save-temps) and fails the
@@ -43,8 +49,16 @@ while i < len(lines):
             state["loads_since_dma"] += 1
         elif ln.startswith("s_waitcnt vmcnt(") and i + 1 < len(lines) and lines[i + 1].strip() == "s_barrier":
             n = int(re.search(r"vmcnt\((\d+)\)", ln).group(1))
-            if n > 0:   # (vmcnt(0) waits for everything: always safe -- the persistent loader's last hand-overs)
-                rows[kernel].append((n, state["loads_since_dma"], state["dma_run"]))
+            tag = None
+            prev = lines[i - 1].strip() if i > 0 else ""
+            mt = re.match(r"^; LARVA_RING pieces=(\d+) aux=(\d+)", prev)
+            ml = re.match(r"^; LARVA_RING loader chunk_pieces=(\d+) ahead=(\d+)", prev)
+            if mt:
+                tag = ("role", int(mt.group(1)), int(mt.group(2)))
+            elif ml:
+                tag = ("loader", int(ml.group(1)), int(ml.group(2)))
+            if n > 0 or tag:   # (an untagged vmcnt(0) waits for everything: always safe -- the persistent loader's last hand-overs)
+                rows[kernel].append((n, state["loads_since_dma"], state["dma_run"], tag))
             state["dma_run"] = 0
         elif ln.startswith(".Lfunc_end"):
             kernel, state = None, None
@@ -57,6 +71,7 @@ def demangle(n):
     except Exception:
         return n
 
+tagged = 0
 for k, r in rows.items():
     if not r:
         continue
@@ -64,7 +79,22 @@ for k, r in rows.items():
     out, first_loads = [], None
     j = 0
     while j < len(r):
-        n, loads, run = r[j]
+        n, loads, run, tag = r[j]
+        if tag is not None:
+            tagged += 1
+            if tag[0] == "loader":
+                ok = n == (tag[2] - 1) * tag[1]
+                out.append("loader wave: vmcnt(%d) = (%d - 1) x %d pieces%s" % (n, tag[2], tag[1], "" if ok else "  <-- MISMATCH"))
+            elif tag[1] > 0 or run > 0:      # a role's first wait: the next chunk's pieces + the operand loads behind them
+                ok = n == tag[1] + tag[2] and (run == 0 or loads == tag[2])
+                out.append("first vmcnt(%d) = %d pieces + %d operand loads (emitted since the last piece: %d)%s"
+                           % (n, tag[1], tag[2], loads, "" if ok else "  <-- MISMATCH"))
+            else:
+                ok = n == tag[2]
+                out.append("later vmcnt(%d) = %d operand loads%s" % (n, tag[2], "" if ok else "  <-- MISMATCH"))
+            bad += 0 if ok else 1
+            j += 1
+            continue
         if run > 0 and loads == 0 and n >= 12:
             out.append("loader wave: vmcnt(%d) = one chunk's pieces" % n)     # (run_loader: a whole chunk in flight)
             first_loads = None
@@ -73,7 +103,7 @@ for k, r in rows.items():
             if loads <= n and 3 <= npw <= 9:
                 first_loads = loads
                 out.append("first vmcnt(%d) = %d pieces + %d operand loads" % (n, npw, loads))
-            elif n == loads and j + 1 < len(r) and r[j + 1][2] == 0 and 3 <= r[j + 1][0] - loads <= 9:
+            elif n == loads and j + 1 < len(r) and r[j + 1][2] == 0 and r[j + 1][3] is None and 3 <= r[j + 1][0] - loads <= 9:
                 # the loop was laid out in front of its entry: this is the LATER wait, the next one the first
                 first_loads = loads
                 out.append("first vmcnt(%d) = %d pieces + %d operand loads; later vmcnt(%d)   (loop rotated in the listing)"
@@ -98,5 +128,5 @@ for k, r in rows.items():
     print(demangle(k))
     for o, c in uniq:
         print("    %s%s" % (o, " (x%d)" % c if c > 1 else ""))
-print("%d suspicious waits" % bad)
+print("%d ring waits checked against their LARVA_RING constants; %d suspicious waits" % (tagged, bad))
 sys.exit(1 if bad else 0)

@@ -32,7 +32,7 @@ for arg in sys.argv[2:]:
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
     for (kern, ctr), (n, v) in sorted(agg.items()):
-        if not re.search(r"larva::(conv3x3|wgrad)", kern):
+        if not re.search(r"larva::(conv3x3|wgrad|head_conv3|bicubic4)", kern):
             continue
         d_us = sum(dur[kern]) / len(dur[kern]) if dur.get(kern) else float("nan")
         rows.append((tag, kern, ctr, n, "%.1f" % (v / n), "%.2f" % d_us))
