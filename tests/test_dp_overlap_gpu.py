@@ -67,12 +67,20 @@ def _worker(rank, world, port, q, backend="gloo"):
             out[mode] = {"losses": losses, "split_at": getattr(m, "_early_lo", None),
                          "graph": bool(m.use_hip_graph),
                          "sd": {k: v.cpu().numpy().copy() for k, v in m.model.state_dict().items()}}
+        # round 6: rank 0 decodes the resident dataset, rank 1 receives it (gloo here: device tensors staged through the host)
+        from larvanet_amd.dataloaders import device_patch_loader as D
+        calls = []
+        real = D.build_host_tables
+        D.build_host_tables = lambda *a_, **k_: (calls.append(rank), real(*a_, **k_))[1]
+        out_loader = _resident_loader_digest()
+        D.build_host_tables = real
+        out_loader["decoded_here"] = len(calls)
         torch.cuda.synchronize()
-        q.put((rank, None, out))
+        q.put((rank, None, out, out_loader))
         td.destroy_process_group()
     except Exception as e:  # hand the failure to the parent instead of hanging its queue
         import traceback
-        q.put((rank, "%s\n%s" % (e, traceback.format_exc()), None))
+        q.put((rank, "%s\n%s" % (e, traceback.format_exc()), None, None))
 
 
 @pytest.mark.timeout(600)
@@ -91,9 +99,14 @@ def test_two_ranks_overlapped_allreduce_trains_like_one_collective(hip_device, b
     res = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
-    for rank, err, _ in res:
+    for rank, err, _, _ in res:
         assert err is None, "rank %d: %s" % (rank, err)
-    (_, _, a), (_, _, b) = res
+    (_, _, a, la), (_, _, b, lb) = res
+    # the resident dataset: decoded once (rank 0), identical tables on both ranks, different draws (seed + 1000 rank)
+    assert (la.pop("decoded_here"), lb.pop("decoded_here")) == (1, 0)
+    xa, xb = la.pop("x"), lb.pop("x")
+    ya, yb = la.pop("y_sum"), lb.pop("y_sum")
+    assert la == lb and not np.array_equal(xa, xb) and ya != yb
     assert a.pop("choices") == b.pop("choices")    # both ranks chose the same schedule every time (MAX over ranks)
     assert a["whole"]["split_at"] is None
     for mode in ("overlap_eager", "overlap_graph"):
@@ -181,6 +194,20 @@ def _train_three_steps(dev, mode):
                "sd": {k: v.cpu().numpy().copy() for k, v in m.model.state_dict().items()}}
 
 
+def _resident_loader_digest():
+    """device_patch_loader over the synthetic source: its tables and one batch drawn from a fixed seed."""
+    from larvanet_amd.dataloaders import device_patch_loader as D
+    ld = D.create_loader()
+    ld.parse_args(["--device_source=synthetic_loader", "--synthetic_images=5", "--synthetic_lr_size=40", "--data_seed=3"])
+    ld.prepare([4])
+    t = ld.tables[4]
+    x, y = ld.get_device_batch(4, 4, 16)
+    torch.cuda.synchronize()
+    return {"shapes": [tuple(s) for s in ld.shapes], "lr_sum": int(t["lr"].to(torch.int64).sum()), "hr_sum": int(t["hr"].to(torch.int64).sum()),
+            "lr_off": t["lr_off"].tolist(), "hr_hw": t["hr_hw"].tolist(), "dtypes": [str(v.dtype) for v in t.values()],
+            "x": x.cpu().numpy().copy(), "y_sum": float(y.double().sum())}
+
+
 def _rccl_world1_worker(q):
     os.environ.update({"LARVA_DIST_FORCE": "1", "LARVA_DIST_BACKEND": "nccl"})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
@@ -204,6 +231,9 @@ def _rccl_world1_worker(q):
             whole = m.upscale_tensor(input_list=[lr])[0]
         out["band_equal"] = bool(torch.equal(banded, whole))
         out["psnr_sum"] = ldist.allreduce_scalar_sum(12.5, dev)
+        # round 6: the resident dataset is decoded on rank 0 and BROADCAST (device_patch_loader.share_tables): the size
+        # announcement (broadcast_object_list) and one device broadcast per table go through RCCL here
+        out["loader"] = _resident_loader_digest()
         torch.manual_seed(0)
         out["validate"] = validate.main(_VALIDATE_ARGS + ["--band_gpus"])[4]["per_image"]
         torch.cuda.synchronize()
@@ -243,4 +273,7 @@ def test_one_rank_rccl_communicator_runs_every_collective_of_the_data_parallel_s
         for k in plain["sd"]:
             assert np.array_equal(out[mode]["sd"][k], plain["sd"][k]), (mode, k)
     assert out["band_equal"] and out["psnr_sum"] == 12.5
+    ref = _resident_loader_digest()      # the same loader without a communicator: a plain upload
+    got = out["loader"]
+    assert np.array_equal(got.pop("x"), ref.pop("x")) and got == ref
     assert [r[:2] for r in out["validate"]] == [r[:2] for r in plain_val]
