@@ -549,7 +549,9 @@ def chains_in_step():
     spec.loader.exec_module(sm)
     names, queued, lone, event_us, host_us = sm.measure(link_marks=())
     ph = sm.chain_phases(names, queued)
-    out = {"graph_replay_us_with_markers": event_us, "host_us_per_graph_launch": host_us,
+    # (the markers perturb the two chains' phase relation: the backward chain of a marked graph often sits in the slow mode
+    # -- 580-600 us against ~485 in the unmarked step, profiles/r06_step_timeline_stamped.txt -- so these are upper bounds)
+    out = {"graph_replay_us_with_markers": event_us, "host_us_per_graph_launch": host_us, "perturbed_by_markers": True,
            "what": "tools/step_marks.py: markers between the product kernels of the captured forward+backward, last of 10 "
                    "back-to-back replays; fork -> the later chain's end"}
     head_flop = 2 * 9 * 3 * CH * BATCH * PATCH * PATCH
