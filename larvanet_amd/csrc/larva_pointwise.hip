@@ -637,6 +637,7 @@ static inline int grid_for(long long work, int block) {
   return (int)g;
 }
 
+
 }  // namespace larva
 
 using namespace larva;

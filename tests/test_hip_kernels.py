@@ -717,32 +717,52 @@ def test_exits_scored_inside_the_conv_launch(hip_device, njobs, N, H, W):
         assert torch.equal(res2[1][j], parts[j])
 
 
-@pytest.mark.parametrize("N,H,W,pitch", [(16, 48, 48, None), (1, 9, 13, 16), (2, 5, 7, None), (1, 339, 510, 512)])
-def test_direct_head_conv_against_oracle_and_mfma_path(hip_device, N, H, W, pitch):
+@pytest.mark.parametrize("N,H,W,pitch,cout", [(16, 48, 48, None, 48), (1, 9, 13, 16, 48), (2, 5, 7, None, 48), (1, 339, 510, 512, 48),
+                                              (1, 7, 18, 20, 48), (2, 33, 50, 64, 32), (1, 20, 95, 96, 64), (3, 1, 16, None, 48),
+                                              (1, 2, 40, 48, 48)])
+def test_direct_head_conv_against_oracle_and_mfma_path(hip_device, N, H, W, pitch, cout):
     """larva_head_conv3_direct (LarvaHead, K = 27) against the C oracle and against the same layer on
-    the MFMA kernel (image zero-padded to 16 channels); padding columns of a pitched output are zero."""
+    the MFMA conv kernel (image zero-padded to 16 channels); padding columns of a pitched output are zero.  The entry point
+    picks the 4-pixel direct kernel (pitch % 4 == 0) or the scalar one: both are covered, at 32 / 48 / 64 channels, at image
+    borders, with padding columns (up to 8 of them), one-row and two-row images."""
     from larvanet_amd import kernels as K
     from oracle import larva_ref as R
-    rng = np.random.default_rng(H * 31 + W)
+    rng = np.random.default_rng(H * 31 + W + cout)
     x = _rand(rng, (N, 3, H, W), 70.0)
-    w = _rand(rng, (48, 3, 3, 3), 0.1)
-    b = _rand(rng, (48,), 1.0)
+    w = _rand(rng, (cout, 3, 3, 3), 0.1)
+    b = _rand(rng, (cout,), 1.0)
     out = K.head_conv3_direct(_dev(x, hip_device), _dev(w, hip_device), _dev(b, hip_device), pitch=pitch)
     torch.cuda.synchronize()
     P = pitch or W
-    assert tuple(out.shape) == (N, 48, H, P)
+    assert tuple(out.shape) == (N, cout, H, P)
     got = out.cpu().numpy()
     if P > W:
         assert not got[..., W:].any()
     if N * H * W <= 16 * 48 * 48:
         _report("head", got[..., :W], R.conv3x3(x, w, b), 2e-5)
-    x16 = torch.zeros((N, 16, H, P), device=hip_device)
-    x16[:, :3, :, :W] = _dev(x, hip_device)
-    fwd, _ = K.pack_weights(_dev(w, hip_device), cin_pad=16, want_bwd=False)
-    ref = K.conv3x3(x16, fwd, 48, bias=_dev(b, hip_device), logical_w=W if P > W else None)
+    if P % 4 == 0:
+        x16 = torch.zeros((N, 16, H, P), device=hip_device)
+        x16[:, :3, :, :W] = _dev(x, hip_device)
+        fwd, _ = K.pack_weights(_dev(w, hip_device), cin_pad=16, want_bwd=False)
+        ref = K.conv3x3(x16, fwd, cout, bias=_dev(b, hip_device), logical_w=W if P > W else None)
+        torch.cuda.synchronize()
+        scale = float(ref.abs().max())
+        assert float((out - ref).abs().max()) <= 1e-5 * scale
+
+
+def test_head_conv_kernels_agree_bit_for_bit(hip_device):
+    """The two kernels behind larva_head_conv3_direct compute every output as the same fmaf chain in tap order from the
+    bias: the 4-pixel kernel (pitch % 4 == 0) and the one-pixel kernel (any pitch) produce identical bits."""
+    from larvanet_amd import kernels as K
+    rng = np.random.default_rng(11)
+    N, H, W = 2, 37, 90
+    x = _dev(_rand(rng, (N, 3, H, W), 70.0), hip_device)
+    w = _dev(_rand(rng, (48, 3, 3, 3), 0.1), hip_device)
+    b = _dev(_rand(rng, (48,), 1.0), hip_device)
+    direct4 = K.head_conv3_direct(x, w, b, pitch=92)  # 4 pixels x 8 channels per thread
+    scalar = K.head_conv3_direct(x, w, b, pitch=91)   # one pixel per thread
     torch.cuda.synchronize()
-    scale = float(ref.abs().max())
-    assert float((out - ref).abs().max()) <= 1e-5 * scale
+    assert torch.equal(direct4[..., :W], scalar[..., :W])
 
 
 def test_step_prologue_equals_its_three_launches(hip_device):
